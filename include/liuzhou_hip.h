@@ -1,0 +1,168 @@
+/*
+ * liuzhou_hip.h -- C ABI of libliuzhou_hip.so (MI355X / gfx950).
+ *
+ * This is the drop-in boundary for the self-play hot path of kuailehaha/liuzhou.  Every entry point
+ * replaces one operator of the reference's PyBind11 module `v0_core`
+ * (v0/src/bindings/module.cpp:874-1482) or one stage of the v1 wave loop
+ * (v1/python/self_play_gpu_runner.py:159-256, v1/python/mcts_gpu.py:1249-1457); the replaced
+ * reference interface is cited at each declaration (paths relative to the reference repo).
+ *
+ * Conventions (same for all entry points):
+ *   - plain pointers + sizes, all pointers are DEVICE pointers unless stated otherwise;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream);
+ *   - no allocation, no host synchronisation inside -> every call is hipGraph-capturable;
+ *   - returns LZ_OK (0) or a negative LzStatus; on error nothing has been launched;
+ *   - inputs are borrowed, outputs are caller-allocated with the documented shapes;
+ *   - tensors are dense row-major; state batches use the reference's 12-tensor SoA layout
+ *     (v0/include/v0/tensor_state_batch.hpp:11-35, v1/python/mcts_gpu.py:40-57).
+ */
+#ifndef LIUZHOU_HIP_H
+#define LIUZHOU_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(_WIN32)
+#define LZ_API
+#else
+#define LZ_API __attribute__((visibility("default")))
+#endif
+
+typedef enum LzStatus {
+    LZ_OK = 0,
+    LZ_ERR_ARG = -1,          /* null pointer / negative size / inconsistent dims */
+    LZ_ERR_UNSUPPORTED = -2,  /* dims outside what the kernels are built for */
+    LZ_ERR_LAUNCH = -3,       /* hipGetLastError() != hipSuccess after launch */
+    LZ_ERR_ALIGN = -4         /* pointer not aligned as documented */
+} LzStatus;
+
+/* 12-tensor state batch.  board int8[B,36] in {-1,0,1}; marks bool(uint8)[B,36]; the rest int64[B].
+ * board / marks rows must be 4-byte aligned (they are for any contiguous torch tensor). */
+typedef struct LzStateSoA {
+    int8_t*  board;
+    uint8_t* marks_black;
+    uint8_t* marks_white;
+    int64_t* phase;
+    int64_t* current_player;
+    int64_t* pending_marks_required;
+    int64_t* pending_marks_remaining;
+    int64_t* pending_captures_required;
+    int64_t* pending_captures_remaining;
+    int64_t* forced_removals_done;
+    int64_t* move_count;
+    int64_t* moves_since_capture;
+} LzStateSoA;
+
+LZ_API const char* lz_version(void);
+LZ_API const char* lz_status_string(int status);
+
+/* ---- rule operators ------------------------------------------------------------------------- */
+
+/* v0_core.encode_actions_fast  (module.cpp:1294-1310; fast_legal_mask.cpp:253-418, _cuda.cu:282-485)
+ * mask uint8[B,T], metadata int32[B,T,4] with T = 36+144+36+auxiliary_dim; both fully written
+ * (illegal entries: mask 0, metadata -1).  placement/movement/selection dims must be 36/144/36. */
+LZ_API int lz_encode_actions_fast(const LzStateSoA* states, int64_t batch,
+                                  int64_t placement_dim, int64_t movement_dim,
+                                  int64_t selection_dim, int64_t auxiliary_dim,
+                                  uint8_t* mask, int32_t* metadata, void* stream);
+
+/* v0_core.batch_apply_moves  (module.cpp:1311-1327; fast_apply_moves_cuda.cu:548-744)
+ * child i = apply(action_codes[i], states[parent_indices[i]]).  Illegal action => child == parent
+ * with the reference GPU bookkeeping (move_count bumped for every kind except placement).
+ * A parent index outside [0,batch) leaves child i untouched. */
+LZ_API int lz_batch_apply_moves(const LzStateSoA* states, int64_t batch,
+                                const int32_t* action_codes /*[N,4]*/,
+                                const int64_t* parent_indices /*[N]*/, int64_t num_actions,
+                                const LzStateSoA* out /*[N]*/, void* stream);
+
+/* in-place variant (fast_apply_moves_cuda.cu:746-917): slot_indices must be unique. */
+LZ_API int lz_batch_apply_moves_inplace(const LzStateSoA* states, int64_t batch,
+                                        const int32_t* action_codes /*[N,4]*/,
+                                        const int64_t* slot_indices /*[N]*/, int64_t num_actions,
+                                        void* stream);
+
+/* v0_core.states_to_model_input  (module.cpp:1286-1293; v0/src/net/encoding.cpp:26-79)
+ * out float32[B,11,6,6]: own, opp, own marks, opp marks, 7 phase one-hot planes. */
+LZ_API int lz_states_to_model_input(const int8_t* board, const uint8_t* marks_black,
+                                    const uint8_t* marks_white, const int64_t* phase,
+                                    const int64_t* current_player, int64_t batch,
+                                    float* out, void* stream);
+
+/* v0_core.project_policy_logits_fast  (module.cpp:1328-1338; project_policy_logits_fast.cpp:16-164)
+ * float32 heads [B,36] x3 + legal mask uint8[B,T] -> probs, masked_logits float32[B,T]. */
+LZ_API int lz_project_policy_logits_fast(const float* log_p1, const float* log_p2,
+                                         const float* log_pmc, const uint8_t* legal_mask,
+                                         int64_t batch, int64_t placement_dim, int64_t movement_dim,
+                                         int64_t selection_dim, int64_t auxiliary_dim,
+                                         float* probs, float* masked_logits, void* stream);
+
+/* ---- root search operators (variant R: v1/python/mcts_gpu.py:1249-1457) -------------------- */
+
+/* Row compaction at the heart of v0_core.root_pack_sparse_actions (module.cpp:247-363): for every
+ * row b the legal action indices are packed to the left (ascending), with their priors renormalised
+ * over the row (sum clamped at 1e-8) and their action codes.  Fixed capacity `cap` (>= max legal
+ * count, 80 is always enough) keeps it sync-free; the Python operator slices to the reference's
+ * data-dependent [R, Amax] shapes.
+ *   counts int32[B]; legal_index int32[B,cap] (-1 pad); priors float32[B,cap] (0 pad);
+ *   codes int32[B,cap,4] (0 pad). */
+LZ_API int lz_root_pack_rows(const uint8_t* legal_mask, const float* probs, const int32_t* metadata,
+                             int64_t batch, int64_t total_dim, int64_t cap,
+                             int32_t* counts, int32_t* legal_index, float* priors, int32_t* codes,
+                             void* stream);
+
+/* v0_core.root_puct_allocate_visits  (module.cpp:1349-1356; root_puct_fused.cu:12-117)
+ * fp32 bandit: `num_simulations` serial pulls per root, lowest index wins ties.  A <= 256. */
+LZ_API int lz_root_puct_allocate_visits(const float* priors, const float* leaf_values,
+                                        const uint8_t* valid_mask, int64_t num_roots,
+                                        int64_t num_actions, int64_t num_simulations,
+                                        float exploration_weight, float* visits, float* value_sum,
+                                        float* root_values, void* stream);
+
+/* v0_core.root_finalize_from_visits  (module.cpp:1374-1386, :441-535) fused with the v1 sampling
+ * step (mcts_gpu.py:1410-1424).  `uniforms` float32[R] in [0,1) selects sampled picks from the
+ * log-space stable policy (mcts_gpu.py:853-898) by inverse CDF; NULL = argmax (sample_moves=False).
+ * Outputs are fully written: policy_dense float32[B,T] (0 fill), chosen_index int64[B] (-1),
+ * chosen_codes int32[B,4] (-1), chosen_valid uint8[B] (0), root_value float32[R].  M <= 256. */
+LZ_API int lz_root_finalize_from_visits(const int64_t* legal_index_mat, const int32_t* action_code_mat,
+                                        const uint8_t* valid_mask, const float* visits,
+                                        const float* value_sum, const int64_t* valid_root_indices,
+                                        int64_t num_roots, int64_t max_actions, int64_t batch_size,
+                                        int64_t total_action_dim, const float* root_temperatures,
+                                        const float* uniforms, float* policy_dense,
+                                        int64_t* chosen_index, int32_t* chosen_codes,
+                                        uint8_t* chosen_valid, float* root_value, void* stream);
+
+/* ---- self-play step operators --------------------------------------------------------------- */
+
+/* v0_core.self_play_step_inplace  (module.cpp:1387-1409, :632-871).  Mutates states / plies / done.
+ * Per active row i it reports fin_kind[i] = 0 (game continues), 1 (ended before the move: terminal
+ * root or no valid choice) or 2 (ended by the move: winner / draw / ply cap), with
+ * result_from_black[i] and soft_value[i] = tanh(k*(black-white)/18). */
+LZ_API int lz_self_play_step_inplace(const LzStateSoA* states, int64_t batch, int64_t* plies,
+                                     uint8_t* done, const int64_t* active_idx, int64_t num_active,
+                                     const int32_t* chosen_action_codes, const uint8_t* terminal_mask,
+                                     const uint8_t* chosen_valid_mask, int64_t max_game_plies,
+                                     float soft_value_k, int32_t* fin_kind, float* result_from_black,
+                                     float* soft_value, void* stream);
+
+/* v0_core.finalize_trajectory_inplace  (module.cpp:1410-1420, :547-630).
+ * For each finished slot with step_counts > 0 writes value = sign*result, soft = sign*soft into the
+ * target buffers at that game's step indices; keep[f] = step_counts[slot] > 0,
+ * final_counts[f] = step_counts[slot]; counts_out int64[3] += [black wins, white wins, draws]
+ * (caller zeroes counts_out). */
+LZ_API int lz_finalize_trajectory_inplace(float* value_targets, float* soft_value_targets,
+                                          const int8_t* player_signs, const int64_t* step_index_matrix,
+                                          const int64_t* step_counts, int64_t num_games,
+                                          int64_t max_steps, const int64_t* slots,
+                                          const float* result_from_black,
+                                          const float* soft_value_from_black, int64_t num_slots,
+                                          uint8_t* keep, int64_t* final_counts, int64_t* counts_out,
+                                          void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LIUZHOU_HIP_H */

@@ -1,0 +1,885 @@
+// lz_ops.hip -- gfx950 kernels behind the reference's v0_core operator surface (C ABI in
+// include/liuzhou_hip.h).  Hand-written for CDNA4: 64-lane wavefronts, one wave per game state for
+// the wide-output operators (lane = action slot / output vector, bitboards built with one ballot),
+// one lane per state for the transition operators (a whole state lives in registers as bitboards).
+//
+// All of these are HBM-bound byte/integer kernels; the design goal is full-width coalesced stores
+// (16 B per lane) and no intermediate tensors.  No MFMA here by construction.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "lz_soa.h"
+
+using namespace lz;
+
+namespace {
+
+constexpr int kWave = 64;
+constexpr int kBlock = 256;               // 4 waves
+constexpr int kWavesPerBlock = kBlock / kWave;
+
+inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+inline int launch_status() { return hipGetLastError() == hipSuccess ? LZ_OK : LZ_ERR_LAUNCH; }
+inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & (kWave - 1); }
+// wave-uniform state index (kept in an SGPR so the per-state scalars come through scalar loads)
+__device__ __forceinline__ int64_t wave_item() {
+    int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    return (int64_t)blockIdx.x * kWavesPerBlock + w;
+}
+
+// ---- wave-level helpers -------------------------------------------------------------------------
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        unsigned long long other = __shfl_xor(v, o);
+        v = other > v ? other : v;
+    }
+    return v;
+}
+// order-preserving float -> uint32 (NaN must be filtered by the caller)
+__device__ __forceinline__ uint32_t float_order(float f) {
+    uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float order_float(uint32_t k) {
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
+}
+
+// per-wave load of one SoA row as bitboards: lanes 0..35 read one cell each, one ballot per set
+struct RowBits { uint64_t black, white, empty, mb, mw; };
+__device__ __forceinline__ RowBits load_row_bits(const int8_t* board, const uint8_t* mb, const uint8_t* mw,
+                                                 int64_t st, int lane) {
+    int bv = 2; int b1 = 0, b2 = 0;
+    if (lane < kCells) {
+        bv = board[st * kCells + lane];
+        b1 = mb[st * kCells + lane];
+        b2 = mw[st * kCells + lane];
+    }
+    RowBits r;
+    r.black = __ballot(bv == 1);
+    r.white = __ballot(bv == -1);
+    r.empty = __ballot(bv == 0);
+    r.mb = __ballot(b1 != 0);
+    r.mw = __ballot(b2 != 0);
+    return r;
+}
+__device__ __forceinline__ uint64_t pick(const RowBits& r, int v) {
+    return v == 1 ? r.black : v == -1 ? r.white : v == 0 ? r.empty : 0ull;
+}
+
+// =================================================================================================
+// encode_actions_fast: one wave per state, lane = action slot.  Reads 180 B, writes T + 16 T bytes.
+// =================================================================================================
+template <bool PACKED_MASK>
+__global__ __launch_bounds__(kBlock) void encode_actions_kernel(LzStateSoA s, int64_t B, int T,
+                                                                uint8_t* __restrict__ mask,
+                                                                int32_t* __restrict__ meta) {
+    const int lane = lane_id();
+    const int64_t st = wave_item();
+    if (st >= B) return;
+    const RowBits rb = load_row_bits(s.board, s.marks_black, s.marks_white, st, lane);
+    const int phase = (int)s.phase[st];
+    const int cur = (int)s.current_player[st];
+    const int pm_rem = (int)s.pending_marks_remaining[st];
+    const int pc_rem = (int)s.pending_captures_remaining[st];
+    const int forced = (int)s.forced_removals_done[st];
+    const Legal L = legal_actions(rb.black, rb.white, pick(rb, cur), pick(rb, -cur), rb.empty, rb.mb, rb.mw,
+                                  phase, cur, pm_rem, pc_rem, forced, /*fallback_forced=*/1);
+    int4* mrow = reinterpret_cast<int4*>(meta) + st * T;
+    uint8_t* krow = mask + st * T;
+    const int iters = (T + kWave - 1) / kWave;
+    for (int it = 0; it < iters; ++it) {
+        const int a = it * kWave + lane;
+        int kind = -1, p = -1, q = -1, e = -1;
+        bool lg = false;
+        if (a < 36) {
+            lg = (L.place >> a) & 1;
+            if (lg) { kind = kActPlace; p = a; }
+        } else if (a < 180) {
+            const int from = (a - 36) >> 2, d = (a - 36) & 3;
+            lg = (move_set(L, d) >> from) & 1;
+            if (lg) { kind = kActMove; p = from; q = d; e = move_dest(from, d); }
+        } else if (a < 216) {
+            const int c = a - 180;
+            lg = (L.sel >> c) & 1;
+            if (lg) { kind = L.sel_kind; p = c; }
+        } else if (a == 216) {
+            lg = L.process != 0;
+            if (lg) kind = kActProcess;
+        }
+        const bool in_range = a < T;
+        lg = lg && in_range;
+        if (in_range) mrow[a] = make_int4(kind, p, q, e);
+        if (PACKED_MASK) {
+            const uint64_t bal = __ballot(lg);
+            const int a4 = it * kWave + lane * 4;
+            if (lane < 16 && a4 < T) {
+                const uint32_t nib = (uint32_t)(bal >> (lane * 4)) & 0xFu;
+                *reinterpret_cast<uint32_t*>(krow + a4) = (nib * 0x00204081u) & 0x01010101u;
+            }
+        } else {
+            if (in_range) krow[a] = lg ? 1 : 0;
+        }
+    }
+}
+
+// =================================================================================================
+// batch_apply_moves: one lane per (action, parent).  The parent row is gathered as 27 dwords (children
+// of one parent are adjacent, so these hit L1/L2), the move is applied on bitboards in registers and
+// the child row is written back as dwords.
+// =================================================================================================
+__device__ __forceinline__ void load_row_words(const void* base, int64_t row, uint32_t (&w)[9]) {
+    const uint32_t* p = reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(base) + row * kCells);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) w[i] = p[i];
+}
+__device__ __forceinline__ void store_row_words(void* base, int64_t row, const uint32_t (&w)[9]) {
+    uint32_t* p = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(base) + row * kCells);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) p[i] = w[i];
+}
+__device__ __forceinline__ uint64_t words_eq(const uint32_t (&w)[9], uint32_t byte_value) {
+    uint64_t m = 0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) m |= (uint64_t)(((w[i] >> (8 * k)) & 0xFFu) == byte_value) << (i * 4 + k);
+    }
+    return m;
+}
+__device__ __forceinline__ uint64_t words_nonzero(const uint32_t (&w)[9]) {
+    uint64_t m = 0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) m |= (uint64_t)(((w[i] >> (8 * k)) & 0xFFu) != 0u) << (i * 4 + k);
+    }
+    return m;
+}
+__device__ __forceinline__ void board_words(uint64_t black, uint64_t white, uint32_t (&w)[9]) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        uint32_t v = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = i * 4 + k;
+            const uint32_t byte = ((black >> c) & 1) ? 0x01u : (((white >> c) & 1) ? 0xFFu : 0u);
+            v |= byte << (8 * k);
+        }
+        w[i] = v;
+    }
+}
+__device__ __forceinline__ void mark_words(uint64_t m, uint32_t (&w)[9]) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const uint32_t nib = (uint32_t)(m >> (i * 4)) & 0xFu;
+        w[i] = (nib * 0x00204081u) & 0x01010101u;
+    }
+}
+
+struct LoadedState { State s; uint64_t other; int64_t raw_player; };   // `other` = cells that are neither -1/0/1
+
+__device__ __forceinline__ State load_state(const LzStateSoA& s, int64_t row) {
+    uint32_t w[9];
+    State st;
+    load_row_words(s.board, row, w);
+    st.black = words_eq(w, 0x01u);
+    st.white = words_eq(w, 0xFFu);
+    load_row_words(s.marks_black, row, w);
+    st.mb = words_nonzero(w);
+    load_row_words(s.marks_white, row, w);
+    st.mw = words_nonzero(w);
+    st.phase = (int)s.phase[row];
+    st.player = (int)s.current_player[row];
+    st.pm_req = (int)s.pending_marks_required[row];
+    st.pm_rem = (int)s.pending_marks_remaining[row];
+    st.pc_req = (int)s.pending_captures_required[row];
+    st.pc_rem = (int)s.pending_captures_remaining[row];
+    st.forced = (int)s.forced_removals_done[row];
+    st.move_count = (int)s.move_count[row];
+    st.msc = (int)s.moves_since_capture[row];
+    return st;
+}
+__device__ __forceinline__ void store_state(const LzStateSoA& o, int64_t row, const State& st) {
+    uint32_t w[9];
+    board_words(st.black, st.white, w);
+    store_row_words(o.board, row, w);
+    mark_words(st.mb, w);
+    store_row_words(o.marks_black, row, w);
+    mark_words(st.mw, w);
+    store_row_words(o.marks_white, row, w);
+    o.phase[row] = st.phase;
+    o.current_player[row] = st.player;
+    o.pending_marks_required[row] = st.pm_req;
+    o.pending_marks_remaining[row] = st.pm_rem;
+    o.pending_captures_required[row] = st.pc_req;
+    o.pending_captures_remaining[row] = st.pc_rem;
+    o.forced_removals_done[row] = st.forced;
+    o.move_count[row] = st.move_count;
+    o.moves_since_capture[row] = st.msc;
+}
+
+__global__ __launch_bounds__(kBlock) void apply_moves_kernel(LzStateSoA in, int64_t B,
+                                                             const int4* __restrict__ codes,
+                                                             const int64_t* __restrict__ parents,
+                                                             int64_t N, LzStateSoA out) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= N) return;
+    const int64_t p = parents[i];
+    if (p < 0 || p >= B) return;
+    const int4 code = codes[i];
+    State st = load_state(in, p);
+    apply(st, code.x, code.y, code.z);
+    store_state(out, i, st);
+}
+
+__global__ __launch_bounds__(kBlock) void apply_moves_inplace_kernel(LzStateSoA s, int64_t B,
+                                                                     const int4* __restrict__ codes,
+                                                                     const int64_t* __restrict__ slots,
+                                                                     int64_t N) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= N) return;
+    const int64_t p = slots[i];
+    if (p < 0 || p >= B) return;
+    const int4 code = codes[i];
+    State st = load_state(s, p);
+    apply(st, code.x, code.y, code.z);
+    store_state(s, p, st);
+}
+
+// =================================================================================================
+// states_to_model_input: one wave per state; 11*36 floats = 99 float4, lane = output float4.
+// =================================================================================================
+__global__ __launch_bounds__(kBlock) void model_input_kernel(const int8_t* __restrict__ board,
+                                                             const uint8_t* __restrict__ mb,
+                                                             const uint8_t* __restrict__ mw,
+                                                             const int64_t* __restrict__ phase,
+                                                             const int64_t* __restrict__ player, int64_t B,
+                                                             float* __restrict__ out) {
+    const int lane = lane_id();
+    const int64_t st = wave_item();
+    if (st >= B) return;
+    const int64_t cur64 = player[st];
+    const int cur8 = (int)(int8_t)cur64;                 // encoding.cpp:48 casts the player to int8
+    const int neg8 = (int)(int8_t)(-(int8_t)cur64);
+    int bv = 0x7FFF; int b1 = 0, b2 = 0;
+    if (lane < kCells) {
+        bv = board[st * kCells + lane];
+        b1 = mb[st * kCells + lane];
+        b2 = mw[st * kCells + lane];
+    }
+    const uint64_t own = __ballot(bv == cur8);
+    const uint64_t opp = __ballot(bv == neg8);
+    const uint64_t m1 = __ballot(b1 != 0), m2 = __ballot(b2 != 0);
+    const bool is_black = cur64 == 1;
+    const uint64_t self_marks = is_black ? m1 : m2;
+    const uint64_t opp_marks = is_black ? m2 : m1;
+    const int64_t ph = phase[st];
+    float4* orow = reinterpret_cast<float4*>(out + st * 11 * kCells);
+    for (int j = lane; j < 99; j += kWave) {
+        const int plane = j / 9;
+        const int cell0 = (j - plane * 9) * 4;
+        uint32_t bits;
+        if (plane < 4) {
+            const uint64_t src = plane == 0 ? own : plane == 1 ? opp : plane == 2 ? self_marks : opp_marks;
+            bits = (uint32_t)(src >> cell0) & 0xFu;
+        } else {
+            bits = (ph == (int64_t)(plane - 3)) ? 0xFu : 0u;
+        }
+        orow[j] = make_float4((bits & 1) ? 1.f : 0.f, (bits & 2) ? 1.f : 0.f, (bits & 4) ? 1.f : 0.f,
+                              (bits & 8) ? 1.f : 0.f);
+    }
+}
+
+// =================================================================================================
+// project_policy_logits_fast: one wave per row; the three 36-wide heads live in lanes 0..35 and are
+// gathered with wave shuffles; masked softmax over T <= 256 columns with wave reductions.
+// =================================================================================================
+__global__ __launch_bounds__(kBlock) void project_policy_kernel(const float* __restrict__ lp1,
+                                                                const float* __restrict__ lp2,
+                                                                const float* __restrict__ lpmc,
+                                                                const uint8_t* __restrict__ mask, int64_t B,
+                                                                int T, float* __restrict__ probs,
+                                                                float* __restrict__ masked_logits) {
+    const int lane = lane_id();
+    const int64_t row = wave_item();
+    if (row >= B) return;
+    float h1 = 0.f, h2 = 0.f, hm = 0.f;
+    if (lane < kCells) {
+        h1 = lp1[row * kCells + lane];
+        h2 = lp2[row * kCells + lane];
+        hm = lpmc[row * kCells + lane];
+    }
+    const float ninf = -INFINITY;
+    float v[4];
+    bool lg[4];
+    float mx = ninf;
+    bool any_legal = false;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int a = it * kWave + lane;
+        // shuffles are executed by every lane (uniform control flow)
+        int from = 0, dest = 0, cell = 0;
+        bool dest_ok = false;
+        if (a >= 36 && a < 180) {
+            from = (a - 36) >> 2;
+            const int d = (a - 36) & 3;
+            const int r = from / 6, c = from - 6 * r;
+            dest_ok = !((d == 0 && r == 0) || (d == 1 && r == 5) || (d == 2 && c == 0) || (d == 3 && c == 5));
+            dest = dest_ok ? move_dest(from, d) : 0;
+        } else if (a >= 180 && a < 216) {
+            cell = a - 180;
+        } else if (a < 36) {
+            cell = a;
+        }
+        const float p1_dest = __shfl(h1, dest);
+        const float p2_from = __shfl(h2, from);
+        const float p1_cell = __shfl(h1, cell);
+        const float pm_cell = __shfl(hm, cell);
+        float x;
+        if (a < 36) x = p1_cell;
+        else if (a < 180) x = dest_ok ? (p2_from + p1_dest) : ninf;
+        else if (a < 216) x = pm_cell;
+        else x = 0.f;
+        const bool legal = (a < T) && mask[row * T + (a < T ? a : 0)] != 0;
+        v[it] = legal ? x : ninf;
+        lg[it] = legal;
+        any_legal = any_legal || legal;
+        if (v[it] > mx) mx = v[it];          // NaN never becomes the max (matches isfinite gating below)
+    }
+    any_legal = __ballot(any_legal) != 0ull;
+    bool fin = false;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) fin = fin || isfinite(v[it]);
+    const bool any_finite = __ballot(fin) != 0ull;
+    mx = wave_max(mx);
+    float e[4];
+    float sum = 0.f;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        e[it] = (v[it] == ninf) ? 0.f : expf(v[it] - mx);
+        sum += e[it];
+    }
+    sum = wave_sum(sum);
+    const bool do_softmax = any_legal && any_finite;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int a = it * kWave + lane;
+        if (a >= T) continue;
+        float pr = 0.f, ml = v[it];
+        if (do_softmax) pr = e[it] / sum;
+        else if (any_legal && lg[it]) ml = 0.f;      // project_policy_logits_fast.cpp:153-160
+        probs[row * T + a] = pr;
+        masked_logits[row * T + a] = ml;
+    }
+}
+
+// =================================================================================================
+// root_pack_rows: one wave per row; ballot + popcount prefix gives each legal action its packed slot.
+// =================================================================================================
+__global__ __launch_bounds__(kBlock) void root_pack_kernel(const uint8_t* __restrict__ mask,
+                                                           const float* __restrict__ probs,
+                                                           const int4* __restrict__ meta, int64_t B, int T,
+                                                           int cap, int32_t* __restrict__ counts,
+                                                           int32_t* __restrict__ legal_index,
+                                                           float* __restrict__ priors,
+                                                           int4* __restrict__ codes) {
+    const int lane = lane_id();
+    const int64_t row = wave_item();
+    if (row >= B) return;
+    const int iters = (T + kWave - 1) / kWave;
+    // pass 1: row sum of legal probabilities (module.cpp:337: priors / sum.clamp_min(1e-8))
+    float part = 0.f;
+    for (int it = 0; it < iters; ++it) {
+        const int a = it * kWave + lane;
+        if (a < T && mask[row * T + a]) part += probs[row * T + a];
+    }
+    const float denom = fmaxf(wave_sum(part), 1e-8f);
+    // clear the row's padding
+    for (int j = lane; j < cap; j += kWave) {
+        legal_index[row * cap + j] = -1;
+        priors[row * cap + j] = 0.f;
+        codes[row * cap + j] = make_int4(0, 0, 0, 0);
+    }
+    int base = 0;
+    for (int it = 0; it < iters; ++it) {
+        const int a = it * kWave + lane;
+        const bool lg = a < T && mask[row * T + a] != 0;
+        const uint64_t bal = __ballot(lg);
+        if (lg) {
+            const int slot = base + __popcll(bal & ((1ull << lane) - 1ull));
+            if (slot < cap) {
+                legal_index[row * cap + slot] = a;
+                priors[row * cap + slot] = probs[row * T + a] / denom;
+                codes[row * cap + slot] = meta[row * T + a];
+            }
+        }
+        base += __popcll(bal);
+    }
+    if (lane == 0) counts[row] = base;
+}
+
+// =================================================================================================
+// root_puct_allocate_visits: one wave per root, statistics in registers for all simulations.
+// SLOTS actions per lane (A <= 64*SLOTS).  Each pull is a single 64-bit wave max over
+// (order(score) << 32 | ~index): highest score, lowest index on ties -- no LDS, no barrier.
+// =================================================================================================
+template <int SLOTS>
+__global__ __launch_bounds__(kBlock) void root_puct_kernel(const float* __restrict__ priors,
+                                                           const float* __restrict__ leaf,
+                                                           const uint8_t* __restrict__ valid, int64_t R,
+                                                           int A, int64_t sims, float c,
+                                                           float* __restrict__ visits,
+                                                           float* __restrict__ value_sum,
+                                                           float* __restrict__ root_values) {
+    const int lane = lane_id();
+    const int64_t root = wave_item();
+    if (root >= R) return;
+    float p[SLOTS], lv[SLOTS], vis[SLOTS], vs[SLOTS];
+    bool ok[SLOTS];
+#pragma unroll
+    for (int j = 0; j < SLOTS; ++j) {
+        const int a = j * kWave + lane;
+        ok[j] = a < A && valid[root * A + (a < A ? a : 0)] != 0;
+        p[j] = a < A ? priors[root * A + a] : 0.f;
+        lv[j] = a < A ? leaf[root * A + a] : 0.f;
+        vis[j] = 0.f;
+        vs[j] = 0.f;
+    }
+    float total = 0.f;
+    for (int64_t sim = 0; sim < sims; ++sim) {
+        const float sqrt_total = sqrtf(total + 1.0f);      // correctly rounded (hipcc default)
+        unsigned long long key = 0ull;                  // 0 == "no candidate"
+#pragma unroll
+        for (int j = 0; j < SLOTS; ++j) {
+            const float v = vis[j];
+            // same operation order as root_puct_fused.cu:53-56; built with -ffp-contract=off
+            const float q = v > 0.f ? (vs[j] / fmaxf(v, 1e-8f)) : 0.f;
+            const float u = c * p[j] * sqrt_total / (1.0f + v);
+            const float score = (q + u) + 0.0f;                      // +0 canonicalises -0
+            if (ok[j] && score == score) {
+                const unsigned long long k = ((unsigned long long)float_order(score) << 32) |
+                                             (unsigned long long)(0xFFFFFFFFu - (uint32_t)(j * kWave + lane));
+                key = k > key ? k : key;
+            }
+        }
+        key = wave_max_u64(key);
+        if (key != 0ull) {
+            const int chosen = (int)(0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFull));
+#pragma unroll
+            for (int j = 0; j < SLOTS; ++j) {
+                if (chosen == j * kWave + lane) { vis[j] += 1.0f; vs[j] += lv[j]; }
+            }
+            total += 1.0f;
+        }
+    }
+    float sv = 0.f, sw = 0.f;
+#pragma unroll
+    for (int j = 0; j < SLOTS; ++j) {
+        const int a = j * kWave + lane;
+        if (a < A) { visits[root * A + a] = vis[j]; value_sum[root * A + a] = vs[j]; }
+        sv += vis[j];
+        sw += vs[j];
+    }
+    sv = wave_sum(sv);
+    sw = wave_sum(sw);
+    if (lane == 0) root_values[root] = sw / fmaxf(sv, 1.0f);
+}
+
+// =================================================================================================
+// root_finalize_from_visits (+ sampled pick): fill kernel, then one wave per root.
+// =================================================================================================
+__global__ __launch_bounds__(kBlock) void finalize_fill_kernel(float* policy, int64_t n_policy, int64_t* cidx,
+                                                               int32_t* ccodes, uint8_t* cvalid, int64_t B) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t j = i; j < n_policy; j += stride) policy[j] = 0.f;
+    for (int64_t j = i; j < B; j += stride) { cidx[j] = -1; cvalid[j] = 0; }
+    for (int64_t j = i; j < B * 4; j += stride) ccodes[j] = -1;
+}
+
+template <int SLOTS>
+__global__ __launch_bounds__(kBlock) void root_finalize_kernel(
+    const int64_t* __restrict__ lidx, const int4* __restrict__ codes, const uint8_t* __restrict__ valid,
+    const float* __restrict__ visits, const float* __restrict__ value_sum, const int64_t* __restrict__ roots,
+    int64_t R, int M, int64_t B, int T, const float* __restrict__ temps, const float* __restrict__ uniforms,
+    float* __restrict__ policy, int64_t* __restrict__ cidx, int4* __restrict__ ccodes,
+    uint8_t* __restrict__ cvalid, float* __restrict__ root_value) {
+    const int lane = lane_id();
+    const int64_t r = wave_item();
+    if (r >= R) return;
+    const int64_t b = roots[r];
+    const float temp = fmaxf(temps[r], 1e-6f);
+    const float inv_t = 1.0f / temp;
+    float pol[SLOTS], vraw[SLOTS];
+    bool ok[SLOTS];
+    float psum = 0.f, sv = 0.f, sw = 0.f;
+#pragma unroll
+    for (int j = 0; j < SLOTS; ++j) {
+        const int a = j * kWave + lane;
+        const bool in = a < M;
+        ok[j] = in && valid[r * M + (in ? a : 0)] != 0;
+        const float v = in ? visits[r * M + a] : 0.f;
+        vraw[j] = v;
+        const float w = in ? value_sum[r * M + a] : 0.f;
+        // module.cpp:493-495: pow(clamp_min(visits,1e-8), 1/T) * mask, normalised (sum clamp 1e-8)
+        pol[j] = ok[j] ? powf(fmaxf(v, 1e-8f), inv_t) : 0.f;
+        psum += pol[j];
+        sv += v;
+        sw += w;
+    }
+    psum = fmaxf(wave_sum(psum), 1e-8f);
+    sv = wave_sum(sv);
+    sw = wave_sum(sw);
+    // argmax of the normalised policy, first index wins (module.cpp:501)
+    unsigned long long key = 0ull;
+#pragma unroll
+    for (int j = 0; j < SLOTS; ++j) {
+        pol[j] = pol[j] / psum;
+        const int a = j * kWave + lane;
+        if (a < M && pol[j] == pol[j]) {
+            const unsigned long long k = ((unsigned long long)float_order(pol[j]) << 32) |
+                                         (unsigned long long)(0xFFFFFFFFu - (uint32_t)a);
+            key = k > key ? k : key;
+        }
+    }
+    key = wave_max_u64(key);
+    int pick_local = key ? (int)(0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFull)) : 0;
+
+    if (uniforms != nullptr && M > 1) {
+        // mcts_gpu.py:853-898: softmax(log(visits)/T) over legal actions, then inverse-CDF sampling
+        float lg[SLOTS];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < SLOTS; ++j) {
+            float v = vraw[j];
+            if (!(v == v) || isinf(v)) v = 0.f;
+            lg[j] = ok[j] ? logf(fmaxf(v, 1e-8f)) * inv_t : -INFINITY;
+            mx = fmaxf(mx, lg[j]);
+        }
+        mx = wave_max(mx);
+        if (!isfinite(mx)) mx = 0.f;
+        float ex[SLOTS];
+        float esum = 0.f;
+        int nvalid = 0;
+#pragma unroll
+        for (int j = 0; j < SLOTS; ++j) {
+            ex[j] = ok[j] ? expf(lg[j] - mx) : 0.f;
+            if (!(ex[j] == ex[j]) || isinf(ex[j])) ex[j] = 0.f;
+            esum += ex[j];
+            nvalid += ok[j] ? 1 : 0;
+        }
+        esum = wave_sum(esum);
+        nvalid = (int)wave_sum((float)nvalid);
+        if (!(esum > 0.f) || !isfinite(esum)) {          // fallback: uniform over legal
+#pragma unroll
+            for (int j = 0; j < SLOTS; ++j) ex[j] = ok[j] ? 1.0f : 0.f;
+            esum = (float)(nvalid > 0 ? nvalid : 1);
+        }
+        // inclusive prefix over action order: slot-major (j), then lane
+        const float target = uniforms[r] * esum;
+        float run = 0.f;
+        int chosen = -1, last_valid = -1;
+#pragma unroll
+        for (int j = 0; j < SLOTS; ++j) {
+            float incl = ex[j];
+#pragma unroll
+            for (int o = 1; o < kWave; o <<= 1) {
+                const float t = __shfl_up(incl, o);
+                if (lane >= o) incl += t;
+            }
+            const float cum = run + incl;
+            const bool hit = ok[j] && ex[j] > 0.f && cum > target;
+            const uint64_t hb = __ballot(hit);
+            if (chosen < 0 && hb) chosen = j * kWave + (__ffsll((unsigned long long)hb) - 1);
+            const uint64_t vb = __ballot(ok[j] && ex[j] > 0.f);
+            if (vb) last_valid = j * kWave + (63 - __clzll((unsigned long long)vb));
+            run += __shfl(incl, kWave - 1);
+        }
+        if (chosen < 0) chosen = last_valid;             // rounding at the top end
+        if (chosen >= 0) pick_local = chosen;
+    }
+
+    // dense scatter (policy_dense_valid.scatter_add_ + index_copy_), chosen index / code
+#pragma unroll
+    for (int j = 0; j < SLOTS; ++j) {
+        const int a = j * kWave + lane;
+        if (a < M && ok[j]) {
+            const int64_t col = lidx[r * M + a];
+            if (col >= 0 && col < T) atomicAdd(&policy[b * T + col], pol[j]);
+        }
+    }
+    if (lane == 0) {
+        cidx[b] = lidx[r * M + pick_local];
+        ccodes[b] = codes[r * M + pick_local];
+        cvalid[b] = 1;
+        root_value[r] = sw / fmaxf(sv, 1.0f);
+    }
+}
+
+// =================================================================================================
+// self_play_step_inplace: one lane per active game.
+// =================================================================================================
+__device__ __forceinline__ float soft_value(uint64_t black, uint64_t white, float k) {
+    const float delta = (float)(popc(black) - popc(white)) / 18.0f;
+    return tanhf(delta * k);
+}
+
+__global__ __launch_bounds__(kBlock) void self_play_step_kernel(
+    LzStateSoA s, int64_t B, int64_t* __restrict__ plies, uint8_t* __restrict__ done,
+    const int64_t* __restrict__ active, int64_t n_active, const int4* __restrict__ codes,
+    const uint8_t* __restrict__ terminal, const uint8_t* __restrict__ cvalid, int64_t max_plies, float k,
+    int32_t* __restrict__ fin_kind, float* __restrict__ result, float* __restrict__ soft) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n_active) return;
+    const int64_t slot = active[i];
+    if (slot < 0 || slot >= B) { fin_kind[i] = 0; result[i] = 0.f; soft[i] = 0.f; return; }
+    State st = load_state(s, slot);
+    const bool term = terminal[i] != 0;
+    if (term || cvalid[i] == 0) {                      // module.cpp:724-741
+        done[slot] = 1;
+        fin_kind[i] = 1;
+        result[i] = term ? -(float)s.current_player[slot] : 0.f;
+        soft[i] = soft_value(st.black, st.white, k);
+        return;
+    }
+    const int4 code = codes[i];
+    apply(st, code.x, code.y, code.z);
+    store_state(s, slot, st);
+    const int64_t np = plies[slot] + 1;
+    plies[slot] = np;
+    int winner = 0;                                     // module.cpp:822-836
+    const bool post = st.phase == kMovement || st.phase == kCaptureSelection || st.phase == kCounterRemoval;
+    if (post && popc(st.black) < kLoseThreshold) winner = -1;
+    if (post && popc(st.white) < kLoseThreshold) winner = 1;
+    const bool draw = st.move_count >= kMaxMoveCount || st.msc >= kNoCaptureLimit;
+    const bool cap = np >= max_plies;
+    if (winner != 0 || draw || cap) {
+        done[slot] = 1;
+        fin_kind[i] = 2;
+        result[i] = (float)winner;
+        soft[i] = soft_value(st.black, st.white, k);
+    } else {
+        fin_kind[i] = 0;
+        result[i] = 0.f;
+        soft[i] = 0.f;
+    }
+}
+
+// =================================================================================================
+// finalize_trajectory_inplace: one wave per finished game, lanes stride over its recorded steps.
+// =================================================================================================
+__global__ __launch_bounds__(kBlock) void finalize_trajectory_kernel(
+    float* __restrict__ value_t, float* __restrict__ soft_t, const int8_t* __restrict__ signs,
+    const int64_t* __restrict__ step_index, const int64_t* __restrict__ step_counts, int64_t G, int64_t Tmax,
+    const int64_t* __restrict__ slots, const float* __restrict__ result, const float* __restrict__ softv,
+    int64_t F, uint8_t* __restrict__ keep, int64_t* __restrict__ final_counts,
+    unsigned long long* __restrict__ counts_out) {
+    const int lane = lane_id();
+    const int64_t f = wave_item();
+    if (f >= F) return;
+    const int64_t g = slots[f];
+    int64_t n = (g >= 0 && g < G) ? step_counts[g] : 0;
+    if (n > Tmax) n = Tmax;
+    const float res = result[f], sft = softv[f];
+    if (lane == 0) {
+        keep[f] = n > 0 ? 1 : 0;
+        final_counts[f] = n;
+        if (n > 0) atomicAdd(&counts_out[res > 0.f ? 0 : (res < 0.f ? 1 : 2)], 1ull);
+    }
+    for (int64_t j = lane; j < n; j += kWave) {
+        const int64_t idx = step_index[g * Tmax + j];
+        const float sg = (float)signs[idx];
+        value_t[idx] = sg * res;
+        soft_t[idx] = sg * sft;
+    }
+}
+
+inline unsigned grid_waves(int64_t items) { return (unsigned)((items + kWavesPerBlock - 1) / kWavesPerBlock); }
+inline unsigned grid_threads(int64_t items) { return (unsigned)((items + kBlock - 1) / kBlock); }
+
+inline bool soa_ok(const LzStateSoA* s) {
+    return s && s->board && s->marks_black && s->marks_white && s->phase && s->current_player &&
+           s->pending_marks_required && s->pending_marks_remaining && s->pending_captures_required &&
+           s->pending_captures_remaining && s->forced_removals_done && s->move_count && s->moves_since_capture;
+}
+inline bool soa_aligned(const LzStateSoA* s) {
+    return aligned(s->board, 4) && aligned(s->marks_black, 4) && aligned(s->marks_white, 4);
+}
+
+}  // namespace
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+extern "C" {
+
+const char* lz_version(void) { return "liuzhou-hip 0.1 (gfx950)"; }
+
+const char* lz_status_string(int status) {
+    switch (status) {
+        case LZ_OK: return "ok";
+        case LZ_ERR_ARG: return "invalid argument";
+        case LZ_ERR_UNSUPPORTED: return "unsupported dimensions";
+        case LZ_ERR_LAUNCH: return "kernel launch failed";
+        case LZ_ERR_ALIGN: return "misaligned pointer";
+        default: return "unknown status";
+    }
+}
+
+int lz_encode_actions_fast(const LzStateSoA* s, int64_t B, int64_t pd, int64_t md, int64_t sd, int64_t ad,
+                           uint8_t* mask, int32_t* meta, void* stream) {
+    if (!soa_ok(s) || B < 0 || !mask || !meta || ad < 0) return LZ_ERR_ARG;
+    if (pd != 36 || md != 144 || sd != 36 || ad > 40) return LZ_ERR_UNSUPPORTED;
+    if (!aligned(meta, 16)) return LZ_ERR_ALIGN;
+    if (B == 0) return LZ_OK;
+    const int T = (int)(pd + md + sd + ad);
+    if ((T % 4) == 0 && aligned(mask, 4))
+        hipLaunchKernelGGL(encode_actions_kernel<true>, dim3(grid_waves(B)), dim3(kBlock), 0, as_stream(stream), *s, B, T, mask, meta);
+    else
+        hipLaunchKernelGGL(encode_actions_kernel<false>, dim3(grid_waves(B)), dim3(kBlock), 0, as_stream(stream), *s, B, T, mask, meta);
+    return launch_status();
+}
+
+int lz_batch_apply_moves(const LzStateSoA* s, int64_t B, const int32_t* codes, const int64_t* parents,
+                         int64_t N, const LzStateSoA* out, void* stream) {
+    if (!soa_ok(s) || !soa_ok(out) || B < 0 || N < 0 || (N > 0 && (!codes || !parents))) return LZ_ERR_ARG;
+    if (!soa_aligned(s) || !soa_aligned(out) || !aligned(codes, 16)) return LZ_ERR_ALIGN;
+    if (N == 0) return LZ_OK;
+    hipLaunchKernelGGL(apply_moves_kernel, dim3(grid_threads(N)), dim3(kBlock), 0, as_stream(stream), *s, B,
+                       reinterpret_cast<const int4*>(codes), parents, N, *out);
+    return launch_status();
+}
+
+int lz_batch_apply_moves_inplace(const LzStateSoA* s, int64_t B, const int32_t* codes, const int64_t* slots,
+                                 int64_t N, void* stream) {
+    if (!soa_ok(s) || B < 0 || N < 0 || (N > 0 && (!codes || !slots))) return LZ_ERR_ARG;
+    if (!soa_aligned(s) || !aligned(codes, 16)) return LZ_ERR_ALIGN;
+    if (N == 0) return LZ_OK;
+    hipLaunchKernelGGL(apply_moves_inplace_kernel, dim3(grid_threads(N)), dim3(kBlock), 0, as_stream(stream), *s, B,
+                       reinterpret_cast<const int4*>(codes), slots, N);
+    return launch_status();
+}
+
+int lz_states_to_model_input(const int8_t* board, const uint8_t* mb, const uint8_t* mw, const int64_t* phase,
+                             const int64_t* player, int64_t B, float* out, void* stream) {
+    if (!board || !mb || !mw || !phase || !player || !out || B < 0) return LZ_ERR_ARG;
+    if (!aligned(out, 16)) return LZ_ERR_ALIGN;
+    if (B == 0) return LZ_OK;
+    hipLaunchKernelGGL(model_input_kernel, dim3(grid_waves(B)), dim3(kBlock), 0, as_stream(stream), board, mb, mw,
+                       phase, player, B, out);
+    return launch_status();
+}
+
+int lz_project_policy_logits_fast(const float* lp1, const float* lp2, const float* lpmc, const uint8_t* mask,
+                                  int64_t B, int64_t pd, int64_t md, int64_t sd, int64_t ad, float* probs,
+                                  float* masked_logits, void* stream) {
+    if (!lp1 || !lp2 || !lpmc || !mask || !probs || !masked_logits || B < 0 || ad < 0) return LZ_ERR_ARG;
+    if (pd != 36 || md != 144 || sd != 36 || ad > 40) return LZ_ERR_UNSUPPORTED;
+    if (B == 0) return LZ_OK;
+    const int T = (int)(pd + md + sd + ad);
+    hipLaunchKernelGGL(project_policy_kernel, dim3(grid_waves(B)), dim3(kBlock), 0, as_stream(stream), lp1, lp2, lpmc,
+                       mask, B, T, probs, masked_logits);
+    return launch_status();
+}
+
+int lz_root_pack_rows(const uint8_t* mask, const float* probs, const int32_t* meta, int64_t B, int64_t T,
+                      int64_t cap, int32_t* counts, int32_t* legal_index, float* priors, int32_t* codes,
+                      void* stream) {
+    if (!mask || !probs || !meta || !counts || !legal_index || !priors || !codes || B < 0 || T <= 0 || cap <= 0)
+        return LZ_ERR_ARG;
+    if (T > 4096 || cap > 4096) return LZ_ERR_UNSUPPORTED;
+    if (!aligned(meta, 16) || !aligned(codes, 16)) return LZ_ERR_ALIGN;
+    if (B == 0) return LZ_OK;
+    hipLaunchKernelGGL(root_pack_kernel, dim3(grid_waves(B)), dim3(kBlock), 0, as_stream(stream), mask, probs,
+                       reinterpret_cast<const int4*>(meta), B, (int)T, (int)cap, counts, legal_index, priors,
+                       reinterpret_cast<int4*>(codes));
+    return launch_status();
+}
+
+int lz_root_puct_allocate_visits(const float* priors, const float* leaf, const uint8_t* valid, int64_t R,
+                                 int64_t A, int64_t sims, float c, float* visits, float* value_sum,
+                                 float* root_values, void* stream) {
+    if (!priors || !leaf || !valid || !visits || !value_sum || !root_values || R < 0 || A < 0 || sims <= 0)
+        return LZ_ERR_ARG;
+    if (A > 256) return LZ_ERR_UNSUPPORTED;
+    if (R == 0 || A == 0) return LZ_OK;
+    const dim3 grid(grid_waves(R)), block(kBlock);
+    hipStream_t st = as_stream(stream);
+    if (A <= 64) hipLaunchKernelGGL(root_puct_kernel<1>, grid, block, 0, st, priors, leaf, valid, R, (int)A, sims, c, visits, value_sum, root_values);
+    else if (A <= 128) hipLaunchKernelGGL(root_puct_kernel<2>, grid, block, 0, st, priors, leaf, valid, R, (int)A, sims, c, visits, value_sum, root_values);
+    else hipLaunchKernelGGL(root_puct_kernel<4>, grid, block, 0, st, priors, leaf, valid, R, (int)A, sims, c, visits, value_sum, root_values);
+    return launch_status();
+}
+
+int lz_root_finalize_from_visits(const int64_t* lidx, const int32_t* codes, const uint8_t* valid,
+                                 const float* visits, const float* value_sum, const int64_t* roots, int64_t R,
+                                 int64_t M, int64_t B, int64_t T, const float* temps, const float* uniforms,
+                                 float* policy, int64_t* cidx, int32_t* ccodes, uint8_t* cvalid,
+                                 float* root_value, void* stream) {
+    if (B < 0 || T <= 0 || R < 0 || M < 0 || !policy || !cidx || !ccodes || !cvalid) return LZ_ERR_ARG;
+    if (R > 0 && M > 0 && (!lidx || !codes || !valid || !visits || !value_sum || !roots || !temps || !root_value))
+        return LZ_ERR_ARG;
+    if (M > 256) return LZ_ERR_UNSUPPORTED;
+    if (!aligned(ccodes, 16) || (codes && !aligned(codes, 16))) return LZ_ERR_ALIGN;
+    hipStream_t st = as_stream(stream);
+    if (B > 0) {
+        const int64_t work = B * T;
+        const unsigned g = (unsigned)((work + kBlock - 1) / kBlock);
+        hipLaunchKernelGGL(finalize_fill_kernel, dim3(g > 2048u ? 2048u : (g ? g : 1u)), dim3(kBlock), 0, st, policy,
+                           work, cidx, ccodes, cvalid, B);
+    }
+    if (R > 0 && M > 0) {
+        const dim3 grid(grid_waves(R)), block(kBlock);
+        const int4* c4 = reinterpret_cast<const int4*>(codes);
+        int4* o4 = reinterpret_cast<int4*>(ccodes);
+        if (M <= 64) hipLaunchKernelGGL(root_finalize_kernel<1>, grid, block, 0, st, lidx, c4, valid, visits, value_sum, roots, R, (int)M, B, (int)T, temps, uniforms, policy, cidx, o4, cvalid, root_value);
+        else if (M <= 128) hipLaunchKernelGGL(root_finalize_kernel<2>, grid, block, 0, st, lidx, c4, valid, visits, value_sum, roots, R, (int)M, B, (int)T, temps, uniforms, policy, cidx, o4, cvalid, root_value);
+        else hipLaunchKernelGGL(root_finalize_kernel<4>, grid, block, 0, st, lidx, c4, valid, visits, value_sum, roots, R, (int)M, B, (int)T, temps, uniforms, policy, cidx, o4, cvalid, root_value);
+    }
+    return launch_status();
+}
+
+int lz_self_play_step_inplace(const LzStateSoA* s, int64_t B, int64_t* plies, uint8_t* done,
+                              const int64_t* active, int64_t n_active, const int32_t* codes,
+                              const uint8_t* terminal, const uint8_t* cvalid, int64_t max_plies, float k,
+                              int32_t* fin_kind, float* result, float* soft, void* stream) {
+    if (!soa_ok(s) || !plies || !done || B < 0 || n_active < 0 || max_plies <= 0) return LZ_ERR_ARG;
+    if (n_active > 0 && (!active || !codes || !terminal || !cvalid || !fin_kind || !result || !soft)) return LZ_ERR_ARG;
+    if (!soa_aligned(s) || (codes && !aligned(codes, 16))) return LZ_ERR_ALIGN;
+    if (n_active == 0) return LZ_OK;
+    hipLaunchKernelGGL(self_play_step_kernel, dim3(grid_threads(n_active)), dim3(kBlock), 0, as_stream(stream), *s, B,
+                       plies, done, active, n_active, reinterpret_cast<const int4*>(codes), terminal, cvalid,
+                       max_plies, k, fin_kind, result, soft);
+    return launch_status();
+}
+
+int lz_finalize_trajectory_inplace(float* value_t, float* soft_t, const int8_t* signs, const int64_t* step_index,
+                                   const int64_t* step_counts, int64_t G, int64_t Tmax, const int64_t* slots,
+                                   const float* result, const float* softv, int64_t F, uint8_t* keep,
+                                   int64_t* final_counts, int64_t* counts_out, void* stream) {
+    if (F < 0 || G < 0 || Tmax < 0) return LZ_ERR_ARG;
+    if (F == 0) return LZ_OK;
+    if (!value_t || !soft_t || !signs || !step_index || !step_counts || !slots || !result || !softv || !keep ||
+        !final_counts || !counts_out)
+        return LZ_ERR_ARG;
+    hipLaunchKernelGGL(finalize_trajectory_kernel, dim3(grid_waves(F)), dim3(kBlock), 0, as_stream(stream), value_t,
+                       soft_t, signs, step_index, step_counts, G, Tmax, slots, result, softv, F, keep, final_counts,
+                       reinterpret_cast<unsigned long long*>(counts_out));
+    return launch_status();
+}
+
+}  // extern "C"

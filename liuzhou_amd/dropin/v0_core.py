@@ -1,0 +1,4 @@
+"""Drop-in shim: with `liuzhou_amd/dropin` (and the repo root) on PYTHONPATH, `import v0_core`
+resolves to the MI355X operator surface instead of the reference's CUDA extension."""
+from liuzhou_amd.v0_core import *  # noqa: F401,F403
+from liuzhou_amd.v0_core import Phase, version  # noqa: F401

@@ -1,0 +1,137 @@
+"""Wave loop of v1 self-play on MI355X (mirror of v1/python/self_play_gpu_runner.py:21-307).
+
+`self_play_v1_gpu(**kwargs)` keeps the reference's 22 parameters / defaults and returns
+`(TensorSelfPlayBatch, SelfPlayV1Stats)`.  All active games of a wave are searched and stepped together;
+per ply: search -> append trajectory rows -> `self_play_step_inplace` -> finalize finished games.
+"""
+from __future__ import annotations
+
+import time
+from typing import Dict, Tuple
+
+import torch
+
+from . import v0_core
+from .mcts_gpu import GpuStateBatch, TOTAL_ACTION_DIM, V1RootMCTS, V1RootMCTSConfig
+from .self_play_types import SelfPlayV1Stats
+from .trajectory_buffer import TensorSelfPlayBatch, TensorTrajectoryBuffer
+
+_DELTA_MIN, _DELTA_MAX = -18, 18
+_TRACKED = ("root_puct_ms", "pack_writeback_ms", "self_play_step_ms", "finalize_ms")
+
+
+def self_play_v1_gpu(model, num_games: int, mcts_simulations: int, temperature_init: float,
+                     temperature_final: float, temperature_threshold: int, exploration_weight: float, device: str,
+                     add_dirichlet_noise: bool = True, dirichlet_alpha: float = 0.3, dirichlet_epsilon: float = 0.25,
+                     soft_value_k: float = 2.0, opening_random_moves: int = 0, max_game_plies: int = 512,
+                     sample_moves: bool = True, concurrent_games: int = 8, child_eval_mode: str = "value_only",
+                     sparse_ply: int = 1, sparse_top_k: int = 8, inference_engine=None,
+                     collect_step_timing: bool = False, verbose: bool = False,
+                     autocast_dtype: str = "float16") -> Tuple[TensorSelfPlayBatch, SelfPlayV1Stats]:
+    if num_games <= 0:
+        raise ValueError("num_games must be positive.")
+    dev = torch.device(device)
+    max_plies = max(1, int(max_game_plies))
+    opening_n = max(0, int(opening_random_moves))
+    wave = max(1, min(int(concurrent_games), int(num_games)))
+    cfg = V1RootMCTSConfig(
+        num_simulations=max(1, int(mcts_simulations)), exploration_weight=float(exploration_weight),
+        temperature=float(temperature_init), add_dirichlet_noise=bool(add_dirichlet_noise),
+        dirichlet_alpha=float(dirichlet_alpha), dirichlet_epsilon=float(dirichlet_epsilon),
+        sample_moves=bool(sample_moves), child_eval_mode=str(child_eval_mode), soft_value_k=float(soft_value_k),
+        sparse_ply=max(1, int(sparse_ply)), sparse_top_k=max(1, int(sparse_top_k)), autocast_dtype=autocast_dtype)
+    mcts = V1RootMCTS(model=model, config=cfg, device=dev, inference_engine=inference_engine,
+                      collect_timing=bool(collect_step_timing))
+    buffer = TensorTrajectoryBuffer(dev, TOTAL_ACTION_DIM, max_steps_hint=max_plies, concurrent_games_hint=wave)
+
+    outcome = torch.zeros((3,), dtype=torch.int64, device=dev)
+    delta_hist = torch.zeros((_DELTA_MAX - _DELTA_MIN + 1,), dtype=torch.int64, device=dev)
+    lengths = torch.zeros((int(num_games),), dtype=torch.int64, device=dev)
+    timing_ms: Dict[str, float] = {k: 0.0 for k in _TRACKED}
+    timing_calls: Dict[str, int] = {k: 0 for k in _TRACKED}
+    events = []
+
+    class _timed:
+        def __init__(self, name):
+            self.n = name
+
+        def __enter__(self):
+            if collect_step_timing:
+                self.s = torch.cuda.Event(enable_timing=True); self.e = torch.cuda.Event(enable_timing=True)
+                self.s.record()
+
+        def __exit__(self, *a):
+            if collect_step_timing:
+                self.e.record(); events.append((self.n, self.s, self.e))
+
+    started = time.perf_counter()
+    for base in range(0, int(num_games), wave):
+        g = min(wave, int(num_games) - base)
+        states = GpuStateBatch.initial(dev, g)
+        step_index = torch.full((g, max_plies), -1, dtype=torch.int64, device=dev)
+        step_counts = torch.zeros((g,), dtype=torch.int64, device=dev)
+        plies = torch.zeros((g,), dtype=torch.int64, device=dev)
+        done = torch.zeros((g,), dtype=torch.bool, device=dev)
+        ones = torch.ones((g,), dtype=torch.int64, device=dev)
+        while True:
+            active = torch.nonzero(~done).view(-1)
+            n_active = int(active.numel())
+            if n_active == 0:
+                break
+            act_states = states if n_active == g else states.select(active)
+            act_plies = plies.index_select(0, active)
+            temps = torch.where(act_plies < int(temperature_threshold), float(temperature_init),
+                                float(temperature_final)).to(torch.float32)
+            force = (act_plies < opening_n) if opening_n > 0 else None
+            search = mcts.search_batch(act_states, temperatures=temps, add_dirichlet_noise=add_dirichlet_noise,
+                                       force_uniform_random_mask=force)
+            rows = buffer.append_steps(search.model_input, search.legal_mask, search.policy_dense,
+                                       act_states.current_player)
+            step_index[active, step_counts.index_select(0, active)] = rows
+            step_counts.index_add_(0, active, ones[:n_active])
+            with _timed("self_play_step_ms"):
+                fin_slots, result, _soft = v0_core.self_play_step_inplace(
+                    *states.tensors(), plies, done, active, search.chosen_action_codes, search.terminal_mask,
+                    search.chosen_valid_mask, int(max_plies), float(soft_value_k))
+            if int(fin_slots.numel()) > 0:
+                boards = states.board.index_select(0, fin_slots)
+                black = boards.eq(1).sum(dim=(1, 2)); white = boards.eq(-1).sum(dim=(1, 2))
+                bucket = (black - white - _DELTA_MIN).clamp(0, _DELTA_MAX - _DELTA_MIN)
+                delta_hist.add_(torch.bincount(bucket, minlength=_DELTA_MAX - _DELTA_MIN + 1))
+                soft = V1RootMCTS._soft_tanh_from_board_black(boards, float(soft_value_k))
+                with _timed("finalize_ms"):
+                    f_slots, f_len, f_out = buffer.finalize_games_inplace(
+                        step_index_matrix=step_index, step_counts=step_counts, slots=fin_slots,
+                        result_from_black=result, soft_value_from_black=soft)
+                if int(f_slots.numel()) > 0:
+                    lengths.index_copy_(0, f_slots + base, f_len)
+                outcome.add_(f_out)
+        if verbose:
+            o = outcome.tolist()
+            print(f"[v1.self_play] games={min(base + g, num_games)}/{num_games} W/L/D={o[0]}/{o[1]}/{o[2]}")
+
+    if dev.type == "cuda":
+        torch.cuda.synchronize(dev)
+    elapsed = max(1e-9, time.perf_counter() - started)
+    for name, s, e in events:
+        timing_ms[name] += float(s.elapsed_time(e)); timing_calls[name] += 1
+    batch = buffer.build()
+    mt = mcts.get_timing(reset=False)
+    for k, v in mt["timing_ms"].items():
+        timing_ms[k] = timing_ms.get(k, 0.0) + float(v)
+    for k, v in mt["timing_calls"].items():
+        timing_calls[k] = timing_calls.get(k, 0) + int(v)
+    total = sum(timing_ms[k] for k in _TRACKED)
+    o = outcome.tolist()
+    hist = delta_hist.tolist()
+    stats = SelfPlayV1Stats(
+        num_games=num_games, num_positions=batch.num_samples, black_wins=int(o[0]), white_wins=int(o[1]),
+        draws=int(o[2]), avg_game_length=float(lengths.to(torch.float32).mean().item()), elapsed_sec=elapsed,
+        positions_per_sec=float(batch.num_samples / elapsed), games_per_sec=float(num_games / elapsed),
+        step_timing_ms={k: float(timing_ms[k]) for k in _TRACKED},
+        step_timing_ratio={k: (float(timing_ms[k]) / total if total > 0 else 0.0) for k in _TRACKED},
+        step_timing_calls={k: int(timing_calls[k]) for k in _TRACKED},
+        mcts_counters={k: int(v) for k, v in mt["counters"].items()},
+        piece_delta_buckets={str(d): int(hist[d - _DELTA_MIN]) for d in range(_DELTA_MIN, _DELTA_MAX + 1)},
+        device=str(dev))
+    return batch, stats

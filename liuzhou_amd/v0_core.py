@@ -1,0 +1,373 @@
+"""`v0_core` operator surface on MI355X.
+
+Python-side mirror of the reference's PyBind11 module (v0/src/bindings/module.cpp:874-1482): same
+operator names, argument names/order, dtypes, shapes and return tuples, for the operators the v1
+self-play path uses.  Every operator launches hand-written gfx950 kernels through the C ABI of
+libliuzhou_hip.so on the *current* torch stream; tensors must be on a HIP device (no CPU path).
+
+Drop-in use: put `liuzhou_amd/dropin` on PYTHONPATH, then `import v0_core` resolves to this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import enum
+from typing import Tuple
+
+import torch
+
+from . import _lib as L
+
+
+class Phase(enum.IntEnum):
+    """v0/include/v0/game_state.hpp (module.cpp:876-885)"""
+    PLACEMENT = 1
+    MARK_SELECTION = 2
+    REMOVAL = 3
+    MOVEMENT = 4
+    CAPTURE_SELECTION = 5
+    FORCED_REMOVAL = 6
+    COUNTER_REMOVAL = 7
+
+
+def version() -> str:
+    return L.lib().lz_version().decode()
+
+
+def _c(t: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    if t.dtype != dtype:
+        t = t.to(dtype)
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _state12(board, marks_black, marks_white, phase, current_player, pmr_req, pmr_rem, pcr_req, pcr_rem,
+             forced, move_count=None, moves_since_capture=None):
+    b = _c(board, torch.int8)
+    ts = [b, _c(marks_black, torch.bool), _c(marks_white, torch.bool)]
+    for t in (phase, current_player, pmr_req, pmr_rem, pcr_req, pcr_rem, forced):
+        ts.append(_c(t, torch.int64))
+    ts.append(_c(move_count, torch.int64) if move_count is not None else ts[3])
+    ts.append(_c(moves_since_capture, torch.int64) if moves_since_capture is not None else ts[3])
+    return ts
+
+
+def encode_actions_fast(board, marks_black, marks_white, phase, current_player, pending_marks_required,
+                        pending_marks_remaining, pending_captures_required, pending_captures_remaining,
+                        forced_removals_done, placement_dim: int, movement_dim: int, selection_dim: int,
+                        auxiliary_dim: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """module.cpp:1294-1310 -> (mask bool[B,T], metadata int32[B,T,4])"""
+    L.require_hip(board, "encode_actions_fast")
+    ts = _state12(board, marks_black, marks_white, phase, current_player, pending_marks_required,
+                  pending_marks_remaining, pending_captures_required, pending_captures_remaining,
+                  forced_removals_done)
+    B = int(ts[0].shape[0])
+    T = int(placement_dim + movement_dim + selection_dim + auxiliary_dim)
+    mask = torch.empty((B, T), dtype=torch.bool, device=board.device)
+    meta = torch.empty((B, T, 4), dtype=torch.int32, device=board.device)
+    s = L.soa(ts)
+    with torch.cuda.device(board.device):
+        st = L.lib().lz_encode_actions_fast(C.byref(s), L.i64(B), L.i64(placement_dim), L.i64(movement_dim),
+                                            L.i64(selection_dim), L.i64(auxiliary_dim), L.ptr(mask), L.ptr(meta),
+                                            L.stream_ptr(board.device))
+    L.check(st, "encode_actions_fast")
+    return mask, meta
+
+
+def _alloc_states(n: int, device) -> list:
+    out = [torch.empty((n, 6, 6), dtype=torch.int8, device=device),
+           torch.empty((n, 6, 6), dtype=torch.bool, device=device),
+           torch.empty((n, 6, 6), dtype=torch.bool, device=device)]
+    out += [torch.empty((n,), dtype=torch.int64, device=device) for _ in range(9)]
+    return out
+
+
+def batch_apply_moves(board, marks_black, marks_white, phase, current_player, pending_marks_required,
+                      pending_marks_remaining, pending_captures_required, pending_captures_remaining,
+                      forced_removals_done, move_count, moves_since_capture, action_codes, parent_indices):
+    """module.cpp:1311-1327 -> 12-tuple of child tensors [N,...] (GPU semantics: illegal == no-op)."""
+    L.require_hip(board, "batch_apply_moves")
+    ts = _state12(board, marks_black, marks_white, phase, current_player, pending_marks_required,
+                  pending_marks_remaining, pending_captures_required, pending_captures_remaining,
+                  forced_removals_done, move_count, moves_since_capture)
+    codes = _c(action_codes.to(board.device), torch.int32)
+    parents = _c(parent_indices.to(board.device), torch.int64).view(-1)
+    if codes.dim() != 2 or codes.shape[1] != 4:
+        raise RuntimeError("action_codes must be (N, 4).")
+    N = int(codes.shape[0])
+    if int(parents.numel()) != N:
+        raise RuntimeError("parent_indices must align with action_codes.")
+    out = _alloc_states(N, board.device)
+    si, so = L.soa(ts), L.soa(out)
+    with torch.cuda.device(board.device):
+        st = L.lib().lz_batch_apply_moves(C.byref(si), L.i64(ts[0].shape[0]), L.ptr(codes), L.ptr(parents),
+                                          L.i64(N), C.byref(so), L.stream_ptr(board.device))
+    L.check(st, "batch_apply_moves")
+    return tuple(out)
+
+
+def batch_apply_moves_inplace(board, marks_black, marks_white, phase, current_player, pending_marks_required,
+                              pending_marks_remaining, pending_captures_required, pending_captures_remaining,
+                              forced_removals_done, move_count, moves_since_capture, action_codes, slot_indices):
+    """fast_apply_moves_cuda.cu:746-917 (state tensors must be contiguous; they are mutated)."""
+    L.require_hip(board, "batch_apply_moves_inplace")
+    ts = [board, marks_black, marks_white, phase, current_player, pending_marks_required, pending_marks_remaining,
+          pending_captures_required, pending_captures_remaining, forced_removals_done, move_count,
+          moves_since_capture]
+    for t in ts:
+        if not t.is_contiguous():
+            raise RuntimeError("in-place state tensors must be contiguous")
+    codes = _c(action_codes.to(board.device), torch.int32)
+    slots = _c(slot_indices.to(board.device), torch.int64).view(-1)
+    s = L.soa(ts)
+    with torch.cuda.device(board.device):
+        st = L.lib().lz_batch_apply_moves_inplace(C.byref(s), L.i64(board.shape[0]), L.ptr(codes), L.ptr(slots),
+                                                  L.i64(slots.numel()), L.stream_ptr(board.device))
+    L.check(st, "batch_apply_moves_inplace")
+
+
+def states_to_model_input(board, marks_black, marks_white, phase, current_player) -> torch.Tensor:
+    """module.cpp:1286-1293 -> float32[B,11,6,6]"""
+    L.require_hip(board, "states_to_model_input")
+    b = _c(board, torch.int8)
+    mb, mw = _c(marks_black, torch.bool), _c(marks_white, torch.bool)
+    ph, cp = _c(phase, torch.int64), _c(current_player, torch.int64)
+    B = int(b.shape[0])
+    out = torch.empty((B, 11, 6, 6), dtype=torch.float32, device=board.device)
+    with torch.cuda.device(board.device):
+        st = L.lib().lz_states_to_model_input(L.ptr(b), L.ptr(mb), L.ptr(mw), L.ptr(ph), L.ptr(cp), L.i64(B),
+                                              L.ptr(out), L.stream_ptr(board.device))
+    L.check(st, "states_to_model_input")
+    return out
+
+
+def project_policy_logits_fast(log_p1, log_p2, log_pmc, legal_mask, placement_dim: int, movement_dim: int,
+                               selection_dim: int, auxiliary_dim: int):
+    """module.cpp:1328-1338 -> (probs, masked_logits) in the heads' dtype (computed in fp32)."""
+    L.require_hip(log_p1, "project_policy_logits_fast")
+    if legal_mask.dtype != torch.bool:
+        raise RuntimeError("legal_mask must be of dtype bool.")
+    if not (log_p1.dtype == log_p2.dtype == log_pmc.dtype):
+        raise RuntimeError("All policy heads must share the same dtype.")
+    out_dtype = log_p1.dtype
+    B = int(log_p1.shape[0])
+    p1 = _c(log_p1.reshape(B, -1), torch.float32)
+    p2 = _c(log_p2.reshape(B, -1), torch.float32)
+    pm = _c(log_pmc.reshape(B, -1), torch.float32)
+    T = int(placement_dim + movement_dim + selection_dim + auxiliary_dim)
+    if tuple(legal_mask.shape) != (B, T):
+        raise RuntimeError(f"legal_mask expected shape ({B}, {T}), got {tuple(legal_mask.shape)}.")
+    mk = _c(legal_mask, torch.bool)
+    probs = torch.empty((B, T), dtype=torch.float32, device=log_p1.device)
+    ml = torch.empty((B, T), dtype=torch.float32, device=log_p1.device)
+    with torch.cuda.device(log_p1.device):
+        st = L.lib().lz_project_policy_logits_fast(L.ptr(p1), L.ptr(p2), L.ptr(pm), L.ptr(mk), L.i64(B),
+                                                   L.i64(placement_dim), L.i64(movement_dim), L.i64(selection_dim),
+                                                   L.i64(auxiliary_dim), L.ptr(probs), L.ptr(ml),
+                                                   L.stream_ptr(log_p1.device))
+    L.check(st, "project_policy_logits_fast")
+    if out_dtype != torch.float32:
+        return probs.to(out_dtype), ml.to(out_dtype)
+    return probs, ml
+
+
+PACK_CAP = 80   # >= max legal actions of any state (placement 36, movement <= 72)
+
+
+def root_pack_rows(legal_mask, probs, metadata, cap: int = PACK_CAP):
+    """Sync-free fixed-capacity form: (counts i32[B], legal_index i32[B,cap], priors f32[B,cap], codes i32[B,cap,4])."""
+    L.require_hip(legal_mask, "root_pack_sparse_actions")
+    mk = _c(legal_mask, torch.bool)
+    pr = _c(probs, torch.float32)
+    md = _c(metadata, torch.int32)
+    B, T = int(mk.shape[0]), int(mk.shape[1])
+    dev = mk.device
+    counts = torch.empty((B,), dtype=torch.int32, device=dev)
+    lidx = torch.empty((B, cap), dtype=torch.int32, device=dev)
+    pri = torch.empty((B, cap), dtype=torch.float32, device=dev)
+    codes = torch.empty((B, cap, 4), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        st = L.lib().lz_root_pack_rows(L.ptr(mk), L.ptr(pr), L.ptr(md), L.i64(B), L.i64(T), L.i64(cap),
+                                       L.ptr(counts), L.ptr(lidx), L.ptr(pri), L.ptr(codes), L.stream_ptr(dev))
+    L.check(st, "root_pack_sparse_actions")
+    return counts, lidx, pri, codes
+
+
+def root_pack_sparse_actions(legal_mask, probs, metadata):
+    """module.cpp:1357-1362 -> the reference's 10-tuple with data-dependent [R, Amax] shapes.
+    The compaction itself runs in one HIP kernel; the final row/column slicing needs the same two
+    host reads (R and Amax) the reference performs (module.cpp:295,310)."""
+    if legal_mask.dim() != 2 or probs.dim() != 2 or metadata.dim() != 3 or metadata.shape[2] != 4:
+        raise RuntimeError("legal_mask [B,A], probs [B,A], metadata [B,A,4] expected")
+    counts, lidx, pri, codes = root_pack_rows(legal_mask, probs, metadata)
+    dev = legal_mask.device
+    terminal_mask = counts.eq(0)
+    valid_root_indices = torch.nonzero(~terminal_mask).view(-1)
+    counts_v = counts.index_select(0, valid_root_indices).to(torch.int64)
+    if int(valid_root_indices.numel()) == 0:
+        e = lambda shape, dt: torch.empty(shape, dtype=dt, device=dev)
+        return (terminal_mask, valid_root_indices, counts_v, e((0, 0), torch.bool), e((0, 0), torch.int64),
+                e((0, 0), torch.float32), e((0, 0, 4), torch.int32), e((0,), torch.int64),
+                e((0, 4), torch.int32), e((0,), torch.int64))
+    M = int(counts_v.max().item())
+    R = int(valid_root_indices.numel())
+    valid_mask = torch.arange(M, device=dev).view(1, M) < counts_v.view(R, 1)
+    legal_index_mat = lidx.index_select(0, valid_root_indices)[:, :M].to(torch.int64).clamp_min_(0)
+    priors_mat = pri.index_select(0, valid_root_indices)[:, :M].contiguous()
+    action_code_mat = codes.index_select(0, valid_root_indices)[:, :M].contiguous()
+    pack_flat_idx = torch.nonzero(valid_mask.reshape(-1)).view(-1)
+    action_codes_all = action_code_mat.reshape(-1, 4).index_select(0, pack_flat_idx)
+    parent_local = torch.div(pack_flat_idx, M, rounding_mode="floor")
+    parent_indices_all = valid_root_indices.index_select(0, parent_local)
+    return (terminal_mask, valid_root_indices, counts_v, valid_mask, legal_index_mat, priors_mat,
+            action_code_mat, pack_flat_idx, action_codes_all, parent_indices_all)
+
+
+def root_puct_allocate_visits(priors, leaf_values, valid_mask, num_simulations: int, exploration_weight: float):
+    """module.cpp:1349-1356 -> (visits f32[R,A], value_sum f32[R,A], root_values f32[R])"""
+    if priors.dim() != 2 or leaf_values.dim() != 2 or valid_mask.dim() != 2:
+        raise RuntimeError("priors / leaf_values / valid_mask must be 2D [R, A]")
+    if priors.shape != leaf_values.shape or priors.shape != valid_mask.shape:
+        raise RuntimeError("priors, leaf_values and valid_mask shape mismatch")
+    if int(num_simulations) <= 0:
+        raise RuntimeError("num_simulations must be positive")
+    L.require_hip(priors, "root_puct_allocate_visits")
+    p = _c(priors, torch.float32)
+    lv = _c(leaf_values, torch.float32)
+    vm = _c(valid_mask, torch.bool)
+    R, A = int(p.shape[0]), int(p.shape[1])
+    dev = p.device
+    visits = torch.zeros((R, A), dtype=torch.float32, device=dev)
+    vs = torch.zeros((R, A), dtype=torch.float32, device=dev)
+    rv = torch.zeros((R,), dtype=torch.float32, device=dev)
+    if R == 0 or A == 0:
+        return visits, vs, rv
+    with torch.cuda.device(dev):
+        st = L.lib().lz_root_puct_allocate_visits(L.ptr(p), L.ptr(lv), L.ptr(vm), L.i64(R), L.i64(A),
+                                                  L.i64(num_simulations), C.c_float(float(exploration_weight)),
+                                                  L.ptr(visits), L.ptr(vs), L.ptr(rv), L.stream_ptr(dev))
+    L.check(st, "root_puct_allocate_visits")
+    return visits, vs, rv
+
+
+def root_finalize_from_visits(legal_index_mat, action_code_mat, valid_mask, visits, value_sum, valid_root_indices,
+                              batch_size: int, total_action_dim: int, root_temperatures, sample_moves: bool,
+                              uniforms=None):
+    """module.cpp:1374-1386 -> (policy_dense f32[B,T], chosen_action_indices i64[B], chosen_action_codes
+    i32[B,4], chosen_valid_mask bool[B], root_value f32[R]).  sample_moves draws one Philox uniform per
+    root on the device (or uses the injected `uniforms` for parity runs) and samples by inverse CDF from
+    the log-space policy of mcts_gpu.py:853-898."""
+    L.require_hip(visits, "root_finalize_from_visits")
+    dev = visits.device
+    li = _c(legal_index_mat, torch.int64)
+    ac = _c(action_code_mat, torch.int32)
+    vm = _c(valid_mask, torch.bool)
+    vi = _c(visits, torch.float32)
+    vs = _c(value_sum, torch.float32)
+    roots = _c(valid_root_indices, torch.int64)
+    temps = _c(root_temperatures, torch.float32)
+    R = int(li.shape[0])
+    M = int(li.shape[1]) if li.dim() == 2 else 0
+    B, T = int(batch_size), int(total_action_dim)
+    policy = torch.empty((B, T), dtype=torch.float32, device=dev)
+    cidx = torch.empty((B,), dtype=torch.int64, device=dev)
+    ccodes = torch.empty((B, 4), dtype=torch.int32, device=dev)
+    cvalid = torch.empty((B,), dtype=torch.bool, device=dev)
+    rv = torch.empty((R,), dtype=torch.float32, device=dev)
+    u = None
+    if sample_moves and M > 1:
+        u = _c(uniforms, torch.float32) if uniforms is not None else torch.rand((R,), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        st = L.lib().lz_root_finalize_from_visits(L.ptr(li), L.ptr(ac), L.ptr(vm), L.ptr(vi), L.ptr(vs),
+                                                  L.ptr(roots), L.i64(R), L.i64(M), L.i64(B), L.i64(T), L.ptr(temps),
+                                                  L.ptr(u), L.ptr(policy), L.ptr(cidx), L.ptr(ccodes), L.ptr(cvalid),
+                                                  L.ptr(rv), L.stream_ptr(dev))
+    L.check(st, "root_finalize_from_visits")
+    return policy, cidx, ccodes, cvalid, rv
+
+
+def self_play_step_raw(state12, plies, done, active_idx, chosen_action_codes, terminal_mask, chosen_valid_mask,
+                       max_game_plies: int, soft_value_k: float):
+    """Sync-free core of self_play_step_inplace -> (fin_kind i32[A], result f32[A], soft f32[A])."""
+    board = state12[0]
+    dev = board.device
+    for t in list(state12) + [plies, done]:
+        if not t.is_contiguous():
+            raise RuntimeError("self_play_step_inplace: state tensors must be contiguous (they are mutated)")
+    act = _c(active_idx.to(dev), torch.int64).view(-1)
+    codes = _c(chosen_action_codes.to(dev), torch.int32)
+    term = _c(terminal_mask.to(dev), torch.bool).view(-1)
+    cval = _c(chosen_valid_mask.to(dev), torch.bool).view(-1)
+    A = int(act.numel())
+    if codes.dim() != 2 or int(codes.shape[0]) != A or int(codes.shape[1]) != 4:
+        raise RuntimeError("chosen_action_codes must be [A, 4]")
+    if int(term.numel()) != A or int(cval.numel()) != A:
+        raise RuntimeError("terminal_mask / chosen_valid_mask batch mismatch")
+    kind = torch.empty((A,), dtype=torch.int32, device=dev)
+    res = torch.empty((A,), dtype=torch.float32, device=dev)
+    soft = torch.empty((A,), dtype=torch.float32, device=dev)
+    s = L.soa(state12)
+    with torch.cuda.device(dev):
+        st = L.lib().lz_self_play_step_inplace(C.byref(s), L.i64(board.shape[0]), L.ptr(plies), L.ptr(done),
+                                               L.ptr(act), L.i64(A), L.ptr(codes), L.ptr(term), L.ptr(cval),
+                                               L.i64(max_game_plies), C.c_float(float(soft_value_k)), L.ptr(kind),
+                                               L.ptr(res), L.ptr(soft), L.stream_ptr(dev))
+    L.check(st, "self_play_step_inplace")
+    return act, kind, res, soft
+
+
+def self_play_step_inplace(board, marks_black, marks_white, phase, current_player, pending_marks_required,
+                           pending_marks_remaining, pending_captures_required, pending_captures_remaining,
+                           forced_removals_done, move_count, moves_since_capture, plies, done, active_idx,
+                           chosen_action_codes, terminal_mask, chosen_valid_mask, max_game_plies: int,
+                           soft_value_k: float):
+    """module.cpp:1387-1409 -> (finished_slots i64[F], result_from_black f32[F], soft f32[F]); mutates the
+    state tensors, `plies` and `done`.  Output order = games ended before the move, then games ended by it,
+    each in active order (module.cpp:724-741, :838-856)."""
+    if int(max_game_plies) <= 0:
+        raise RuntimeError("max_game_plies must be positive")
+    L.require_hip(board, "self_play_step_inplace")
+    if done.dtype != torch.bool or plies.dtype != torch.int64:
+        raise RuntimeError("plies must be int64 and done must be bool")
+    st12 = [board, marks_black, marks_white, phase, current_player, pending_marks_required,
+            pending_marks_remaining, pending_captures_required, pending_captures_remaining, forced_removals_done,
+            move_count, moves_since_capture]
+    act, kind, res, soft = self_play_step_raw(st12, plies, done, active_idx, chosen_action_codes, terminal_mask,
+                                              chosen_valid_mask, max_game_plies, soft_value_k)
+    if int(act.numel()) == 0:
+        e = torch.empty((0,), dtype=torch.float32, device=board.device)
+        return torch.empty((0,), dtype=torch.int64, device=board.device), e, e.clone()
+    order = torch.cat([torch.nonzero(kind.eq(1)).view(-1), torch.nonzero(kind.eq(2)).view(-1)])
+    return act.index_select(0, order), res.index_select(0, order), soft.index_select(0, order)
+
+
+def finalize_trajectory_inplace(value_targets, soft_value_targets, player_signs, step_index_matrix, step_counts,
+                                slots, result_from_black, soft_value_from_black):
+    """module.cpp:1410-1420 -> (final_slots, final_counts, counts_out i64[3]); mutates the two targets."""
+    L.require_hip(value_targets, "finalize_trajectory_inplace")
+    dev = value_targets.device
+    if not (value_targets.is_contiguous() and soft_value_targets.is_contiguous()):
+        raise RuntimeError("target buffers must be contiguous")
+    if value_targets.dtype != torch.float32 or soft_value_targets.dtype != torch.float32:
+        raise RuntimeError("target buffers must be float32")
+    counts_out = torch.zeros((3,), dtype=torch.int64, device=dev)
+    sl = _c(slots.to(dev), torch.int64).view(-1)
+    F = int(sl.numel())
+    empty = torch.empty((0,), dtype=torch.int64, device=dev)
+    if F == 0:
+        return empty, empty.clone(), counts_out
+    res = _c(result_from_black.to(dev), torch.float32).view(-1)
+    sft = _c(soft_value_from_black.to(dev), torch.float32).view(-1)
+    if int(res.numel()) != F or int(sft.numel()) != F:
+        raise RuntimeError("result_from_black / soft_value_from_black must align with slots")
+    signs = _c(player_signs, torch.int8)
+    sim = _c(step_index_matrix, torch.int64)
+    sc = _c(step_counts, torch.int64)
+    keep = torch.empty((F,), dtype=torch.bool, device=dev)
+    fcounts = torch.empty((F,), dtype=torch.int64, device=dev)
+    with torch.cuda.device(dev):
+        st = L.lib().lz_finalize_trajectory_inplace(L.ptr(value_targets), L.ptr(soft_value_targets), L.ptr(signs),
+                                                    L.ptr(sim), L.ptr(sc), L.i64(sim.shape[0]), L.i64(sim.shape[1]),
+                                                    L.ptr(sl), L.ptr(res), L.ptr(sft), L.i64(F), L.ptr(keep),
+                                                    L.ptr(fcounts), L.ptr(counts_out), L.stream_ptr(dev))
+    L.check(st, "finalize_trajectory_inplace")
+    kidx = torch.nonzero(keep).view(-1)
+    return sl.index_select(0, kidx), fcounts.index_select(0, kidx), counts_out

@@ -1,0 +1,185 @@
+"""CPU ORACLE of the self-play wave loop (test infrastructure / bench cpu_baseline only).
+
+Restates, on top of oracle/lz_oracle.c + numpy host ops + a PyTorch-CPU network:
+  - variant R: v1/python/mcts_gpu.py:1249-1457 + v1/python/self_play_gpu_runner.py:159-256
+  - variant P: v1/python/portable_mcts.py:570-700 + v1/python/portable_self_play.py:82-284
+Pinned by tests/golden/g8_selfplay.npz (the reference's own v1 runner on CPU, 4 games x 32 sims).
+"""
+from __future__ import annotations
+
+import time
+from typing import Callable, Dict, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import lz_oracle as O
+
+
+def _net_eval(model, planes: np.ndarray):
+    with torch.inference_mode():
+        lp1, lp2, lpm, raw = model(torch.from_numpy(planes))
+        probs = torch.softmax(raw.float(), dim=-1)
+        centers = torch.linspace(-1.0, 1.0, steps=raw.shape[-1], dtype=probs.dtype)
+        val = (probs * centers).sum(-1)
+    return lp1.float().numpy(), lp2.float().numpy(), lpm.float().numpy(), val.numpy().astype(np.float32)
+
+
+def root_search_batch(model, states: Dict[str, np.ndarray], temps: np.ndarray, sims: int, c: float,
+                      soft_k: float = 2.0, noise: Optional[np.ndarray] = None, eps: float = 0.25):
+    """variant R on a batch (sample_moves=False): returns dict with model_input, legal_mask, policy_dense,
+    chosen codes/idx/valid, terminal_mask, visits matrices."""
+    B = states["board"].shape[0]
+    planes = O.states_to_model_input(states)
+    lp1, lp2, lpm, values = _net_eval(model, planes)
+    mask, meta = O.encode_actions(states)
+    probs, _ = O.project_policy(lp1, lp2, lpm, mask)
+    (term, roots, counts, valid, lidx, pri, codes, flat, codes_all, parents_all) = O.root_pack_sparse_actions(mask, probs, meta)
+    out = dict(model_input=planes, legal_mask=mask, policy_dense=np.zeros((B, 220), np.float32),
+               chosen_idx=np.full(B, -1, np.int64), chosen_codes=np.full((B, 4), -1, np.int32),
+               chosen_valid=np.zeros(B, bool), terminal_mask=term, root_value=values.copy(), leaf_evals=B)
+    if roots.size == 0:
+        return out
+    R, M = valid.shape
+    if noise is not None and M > 1:
+        nz = noise[:R, :M].astype(np.float32) * valid
+        nz = nz / np.maximum(nz.sum(1, keepdims=True), np.float32(1e-8))
+        mixed = (np.float32(1.0 - eps) * pri + np.float32(eps) * nz).astype(np.float32)
+        pri = np.where((counts > 1)[:, None], mixed, pri)
+    child = O.apply_moves(states, codes_all, parents_all, strict=True)
+    _, _, _, cvals = _net_eval(model, O.states_to_model_input(child))
+    out["leaf_evals"] += int(cvals.shape[0])
+    parent_player = states["current_player"][parents_all]
+    leaf = np.where(child["current_player"] == parent_player, cvals, -cvals).astype(np.float32)
+    tchild = O.terminal_mask_from_next_state(child)
+    soft = O.soft_value_from_board(child["board"], soft_k)
+    sign = np.where(parent_player >= 0, 1.0, -1.0).astype(np.float32)
+    leaf = np.where(tchild, soft * sign, leaf).astype(np.float32)
+    leaf_mat = np.zeros((R, M), np.float32)
+    leaf_mat.reshape(-1)[flat] = leaf
+    visits, vsum, _ = O.root_puct(pri, leaf_mat, valid, sims, c)
+    pol, cidx, ccodes, cvalid, rv = O.root_finalize_from_visits(lidx, codes, valid, visits, vsum, roots, B, 220,
+                                                                temps[roots])
+    out.update(policy_dense=pol, chosen_idx=cidx, chosen_codes=ccodes, chosen_valid=cvalid, visits=visits,
+               valid=valid, lidx=lidx, roots=roots, priors=pri, leaf=leaf_mat)
+    out["root_value"][roots] = rv
+    return out
+
+
+def self_play_root(model, num_games: int, sims: int, temperature_init: float = 1.0, temperature_final: float = 0.1,
+                   temperature_threshold: int = 10, c: float = 1.0, soft_k: float = 2.0, max_game_plies: int = 512,
+                   max_total_plies: Optional[int] = None):
+    """variant-R wave loop, deterministic (sample_moves=False, no noise).  Returns (tensors dict, stats dict)."""
+    states = O.initial_states(num_games)
+    plies = np.zeros(num_games, np.int64); done = np.zeros(num_games, bool)
+    step_index = np.full((num_games, max_game_plies), -1, np.int64); step_counts = np.zeros(num_games, np.int64)
+    S, L, P, signs = [], [], [], []
+    size = 0
+    finished = []
+    leaf_evals = 0
+    t0 = time.perf_counter()
+    waves = 0
+    while True:
+        active = np.nonzero(~done)[0]
+        if active.size == 0 or (max_total_plies is not None and waves >= max_total_plies):
+            break
+        act = O.select_states(states, active)
+        temps = np.where(plies[active] < temperature_threshold, temperature_init, temperature_final).astype(np.float32)
+        sr = root_search_batch(model, act, temps, sims, c, soft_k)
+        leaf_evals += sr["leaf_evals"]
+        n = active.size
+        S.append(sr["model_input"]); L.append(sr["legal_mask"]); P.append(sr["policy_dense"])
+        signs.append(np.where(act["current_player"] >= 0, 1, -1).astype(np.int8))
+        rows = np.arange(size, size + n)
+        step_index[active, step_counts[active]] = rows
+        step_counts[active] += 1
+        size += n
+        slots, res, _ = O.self_play_step_inplace(states, plies, done, active, sr["chosen_codes"], sr["terminal_mask"],
+                                                 sr["chosen_valid"], max_game_plies, soft_k)
+        if slots.size:
+            soft = O.soft_value_from_board(states["board"][slots], soft_k)
+            finished.append((slots.copy(), res.copy(), soft))
+        waves += 1
+    elapsed = time.perf_counter() - t0
+    state_t = np.concatenate(S) if S else np.zeros((0, 11, 6, 6), np.float32)
+    sg = np.concatenate(signs) if signs else np.zeros(0, np.int8)
+    vt = np.full(size, np.nan, np.float32); svt = np.full(size, np.nan, np.float32)
+    outcome = np.zeros(3, np.int64)
+    for slots, res, soft in finished:
+        _, _, co = O.finalize_trajectory_inplace(vt, svt, sg, step_index, step_counts, slots, res, soft)
+        outcome += co
+    tensors = dict(state_tensors=state_t, legal_masks=np.concatenate(L) if L else np.zeros((0, 220), bool),
+                   policy_targets=np.concatenate(P) if P else np.zeros((0, 220), np.float32),
+                   value_targets=vt, soft_value_targets=svt)
+    stats = dict(num_positions=size, elapsed_sec=elapsed, positions_per_sec=size / max(elapsed, 1e-9),
+                 leaf_evals=leaf_evals, black_wins=int(outcome[0]), white_wins=int(outcome[1]), draws=int(outcome[2]),
+                 avg_game_length=float(step_counts.mean()))
+    return tensors, stats
+
+
+# ---------------------------------------------------------------------------------------------
+# variant P (full tree, one leaf per game per simulation)
+# ---------------------------------------------------------------------------------------------
+def tree_search_batch(evaluate: Callable[[Dict[str, np.ndarray]], Tuple[np.ndarray, np.ndarray]], trees, sims: int,
+                      noise_fn: Optional[Callable[[int, int], np.ndarray]] = None, eps: float = 0.25) -> int:
+    """Run `sims` simulations on every OracleTree.  `evaluate(states) -> (priors[B,220], values[B])`.
+    Returns the number of leaf evaluations."""
+    evals = 0
+    pend = [i for i, t in enumerate(trees) if t.prepare_root()]
+    if pend:
+        st = O.batch_from_states([trees[i].pending_state() for i in pend])
+        pri, val = evaluate(st)
+        evals += len(pend)
+        for k, i in enumerate(pend):
+            nz = noise_fn(i, int((O.encode_actions(O.select_states(st, [k]))[0]).sum())) if noise_fn else None
+            trees[i].complete(pri[k], float(val[k]), nz, eps)
+    for _ in range(sims):
+        pend = [i for i, t in enumerate(trees) if t.select()]
+        if not pend:
+            continue
+        st = O.batch_from_states([trees[i].pending_state() for i in pend])
+        pri, val = evaluate(st)
+        evals += len(pend)
+        for k, i in enumerate(pend):
+            trees[i].complete(pri[k], float(val[k]))
+    return evals
+
+
+def make_net_evaluator(model):
+    def evaluate(states):
+        planes = O.states_to_model_input(states)
+        lp1, lp2, lpm, val = _net_eval(model, planes)
+        mask, _ = O.encode_actions(states)   # tensor semantics == python on non-terminal reachable states
+        probs, _ = O.project_policy(lp1, lp2, lpm, mask)
+        return probs, val
+    return evaluate
+
+
+def self_play_tree(model, num_games: int, sims: int, temperature_init: float = 1.0, temperature_final: float = 0.1,
+                   temperature_threshold: int = 10, c: float = 1.0, max_total_plies: Optional[int] = None,
+                   reuse_tree: bool = False):
+    """variant-P deterministic self-play (argmax N, lowest index) used as the CPU baseline."""
+    evaluate = make_net_evaluator(model)
+    cur = [O.state_from_batch(O.initial_states(1), 0) for _ in range(num_games)]
+    done = [False] * num_games
+    positions = 0
+    evals = 0
+    t0 = time.perf_counter()
+    waves = 0
+    while not all(done) and (max_total_plies is None or waves < max_total_plies):
+        act = [i for i in range(num_games) if not done[i]]
+        trees = [O.OracleTree(cur[i], c) for i in act]
+        evals += tree_search_batch(evaluate, trees, sims)
+        for t, i in zip(trees, act):
+            if t.root_terminal():
+                done[i] = True
+                continue
+            idx, vis, _, _, _ = t.root_children()
+            positions += 1
+            cur[i] = O.apply_index(cur[i], int(idx[int(np.argmax(vis))]))
+            if O.game_status(cur[i]) != 0:
+                done[i] = True
+        waves += 1
+    elapsed = time.perf_counter() - t0
+    return dict(num_positions=positions, elapsed_sec=elapsed, positions_per_sec=positions / max(elapsed, 1e-9),
+                leaf_evals=evals)

@@ -1,0 +1,307 @@
+"""GPU parity: every v0_core operator (HIP kernels through the C ABI) against the oracle and the
+reference's golden vectors.  Integer / byte / index outputs bit-exact; float outputs <= 1e-5
+(the tolerance north_star states for policy/value tensors)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import lz_oracle as O
+from tests.golden_utils import load, states, unpack_mask, states_equal, FIELDS
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def v0():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from liuzhou_amd import v0_core
+    return v0_core
+
+
+def to_dev(st):
+    out = []
+    for f in FIELDS:
+        a = np.ascontiguousarray(st[f])
+        if f == "board":
+            out.append(torch.from_numpy(a.astype(np.int8)).to(DEV))
+        elif f.startswith("marks"):
+            out.append(torch.from_numpy(a.astype(bool)).to(DEV))
+        else:
+            out.append(torch.from_numpy(a.astype(np.int64)).to(DEV))
+    return out
+
+
+def from_dev(ts):
+    return {f: t.cpu().numpy() for f, t in zip(FIELDS, ts)}
+
+
+def test_encode_actions_reachable_bit_exact(v0):
+    z = load("g1_rules.npz")
+    t = to_dev(states(z, "s"))
+    mask, meta = v0.encode_actions_fast(*t[:10], 36, 144, 36, 4)
+    assert mask.dtype == torch.bool and meta.dtype == torch.int32
+    assert np.array_equal(mask.cpu().numpy(), unpack_mask(z["legal_mask"], 220))
+    assert np.array_equal(meta.cpu().numpy(), z["metadata"].astype(np.int32))
+
+
+@pytest.mark.parametrize("aux,key", [(1, "t217"), (4, "t220")])
+def test_encode_actions_garbage_bit_exact(v0, aux, key):
+    """tests/v0/cuda/test_fast_legal_mask_cuda.py:179-228 equivalent: synthetic unreachable states."""
+    z = load("g3_garbage.npz")
+    t = to_dev(states(z, "s"))
+    mask, meta = v0.encode_actions_fast(*t[:10], 36, 144, 36, aux)
+    assert np.array_equal(mask.cpu().numpy(), unpack_mask(z[f"mask_{key}"], 216 + aux))
+    assert np.array_equal(meta.cpu().numpy(), z[f"meta_{key}"].astype(np.int32))
+
+
+def test_encode_actions_large_random_vs_oracle(v0):
+    rng = np.random.default_rng(0xF00D)
+    n = 10000
+    st = O.empty_states(n)
+    st["board"] = rng.integers(-1, 2, (n, 6, 6)).astype(np.int8)
+    dense = rng.random(n) < 0.4
+    st["board"][dense] = np.where(rng.random((int(dense.sum()), 6, 6)) < 0.88, 1, -1).astype(np.int8) * rng.choice([-1, 1], (int(dense.sum()), 1, 1)).astype(np.int8)
+    st["marks_black"] = rng.random((n, 6, 6)) < 0.2
+    st["marks_white"] = rng.random((n, 6, 6)) < 0.2
+    st["phase"] = rng.integers(1, 8, n)
+    st["current_player"] = rng.choice([-1, 1], n)
+    st["pending_marks_remaining"] = rng.integers(0, 3, n)
+    st["pending_captures_remaining"] = rng.integers(0, 3, n)
+    st["forced_removals_done"] = rng.integers(0, 3, n)
+    want_mask, want_meta = O.encode_actions(st)
+    t = to_dev(st)
+    mask, meta = v0.encode_actions_fast(*t[:10], 36, 144, 36, 4)
+    assert np.array_equal(mask.cpu().numpy(), want_mask)
+    assert np.array_equal(meta.cpu().numpy(), want_meta)
+
+
+def test_encode_actions_empty_batch(v0):
+    t = to_dev(O.empty_states(0))
+    mask, meta = v0.encode_actions_fast(*t[:10], 36, 144, 36, 4)
+    assert tuple(mask.shape) == (0, 220) and tuple(meta.shape) == (0, 220, 4)
+
+
+def test_batch_apply_moves_all_transitions_bit_exact(v0):
+    z = load("g1_rules.npz")
+    t = to_dev(states(z, "s"))
+    parents = torch.from_numpy(z["child_parent"].astype(np.int64)).to(DEV)
+    codes = torch.from_numpy(z["metadata"].astype(np.int32)[z["child_parent"], z["child_action"].astype(np.int64)]).to(DEV)
+    out = v0.batch_apply_moves(*t, codes, parents)
+    assert out[1].dtype == torch.bool and out[0].dtype == torch.int8 and out[3].dtype == torch.int64
+    ok, field = states_equal(from_dev(out), states(z, "c"))
+    assert ok, field
+
+
+def test_batch_apply_moves_illegal_actions_noop_semantics(v0):
+    z = load("g1_rules.npz")
+    st = states(z, "s")
+    B = st["board"].shape[0]
+    rng = np.random.default_rng(5)
+    N = 50000
+    parents = rng.integers(0, B, N).astype(np.int64)
+    codes = np.stack([rng.integers(0, 10, N), rng.integers(-1, 37, N), rng.integers(-1, 5, N),
+                      rng.integers(-1, 36, N)], axis=1).astype(np.int32)
+    want = O.apply_moves(st, codes, parents, strict=False)
+    out = v0.batch_apply_moves(*to_dev(st), torch.from_numpy(codes).to(DEV), torch.from_numpy(parents).to(DEV))
+    ok, field = states_equal(from_dev(out), want)
+    assert ok, field
+
+
+def test_batch_apply_moves_inplace(v0):
+    z = load("g1_rules.npz")
+    st = states(z, "s")
+    B = st["board"].shape[0]
+    mask = unpack_mask(z["legal_mask"], 220)
+    meta = z["metadata"].astype(np.int32)
+    first = mask.argmax(1)
+    codes = meta[np.arange(B), first]
+    slots = np.arange(B, dtype=np.int64)[::2].copy()
+    want = O.apply_moves(st, codes[slots], slots, strict=True)
+    t = to_dev(st)
+    v0.batch_apply_moves_inplace(*t, torch.from_numpy(codes[slots]).to(DEV), torch.from_numpy(slots).to(DEV))
+    got = from_dev(t)
+    ok, field = states_equal({f: got[f][slots] for f in FIELDS}, want)
+    assert ok, field
+    untouched = np.arange(B)[1::2]
+    ok, field = states_equal({f: got[f][untouched] for f in FIELDS}, {f: np.asarray(st[f])[untouched] for f in FIELDS})
+    assert ok, field
+
+
+def test_states_to_model_input_exact(v0):
+    for name in ("g2_edges.npz", "g3_garbage.npz"):
+        z = load(name)
+        t = to_dev(states(z, "s"))
+        x = v0.states_to_model_input(t[0], t[1], t[2], t[3], t[4])
+        assert x.dtype == torch.float32 and tuple(x.shape[1:]) == (11, 6, 6)
+        assert np.array_equal(x.cpu().numpy(), z["model_input"].astype(np.float32)), name
+
+
+def test_project_policy_logits(v0):
+    z = load("g4_project.npz")
+    mask = torch.from_numpy(unpack_mask(z["mask"], 220)).to(DEV)
+    probs, ml = v0.project_policy_logits_fast(*(torch.from_numpy(z[k]).to(DEV) for k in ("lp1", "lp2", "lpmc")),
+                                              mask, 36, 144, 36, 4)
+    np.testing.assert_allclose(probs.cpu().numpy(), z["probs"], atol=1e-6, rtol=0)   # tolerance: <= 1e-5 required
+    got, want = ml.cpu().numpy(), z["masked_logits"]
+    assert np.array_equal(np.isneginf(got), np.isneginf(want))
+    fin = np.isfinite(want)
+    np.testing.assert_allclose(got[fin], want[fin], atol=1e-6, rtol=0)
+    # larger random batch against the oracle
+    rng = np.random.default_rng(3)
+    B = 4096
+    lp = [torch.log_softmax(torch.from_numpy(rng.normal(size=(B, 36)).astype(np.float32)) * 2, 1) for _ in range(3)]
+    m = rng.random((B, 220)) < 0.12
+    m[:, 217:] = False
+    wp, wl = O.project_policy(lp[0].numpy(), lp[1].numpy(), lp[2].numpy(), m)
+    probs, ml = v0.project_policy_logits_fast(*(x.to(DEV) for x in lp), torch.from_numpy(m).to(DEV), 36, 144, 36, 4)
+    np.testing.assert_allclose(probs.cpu().numpy(), wp, atol=1e-6, rtol=0)
+
+
+def test_root_pack_sparse_actions(v0):
+    z = load("g7_ops.npz")
+    mask = torch.from_numpy(unpack_mask(z["mask"], 220)).to(DEV)
+    probs = torch.from_numpy(z["probs"]).to(DEV)
+    meta = torch.from_numpy(z["meta"].astype(np.int32)).to(DEV)
+    pack = v0.root_pack_sparse_actions(mask, probs, meta)
+    names = ["terminal_mask", "valid_root_indices", "counts", "valid_mask", "legal_index_mat", "priors_mat",
+             "action_code_mat", "pack_flat_idx", "action_codes_all", "parent_indices_all"]
+    for n, got in zip(names, pack):
+        want = z[f"pack_{n}"]
+        g = got.cpu().numpy()
+        assert g.dtype == want.dtype, (n, g.dtype, want.dtype)
+        if g.dtype == np.float32:
+            np.testing.assert_allclose(g, want, atol=1e-6, rtol=0, err_msg=n)
+        else:
+            assert np.array_equal(g, want), n
+
+
+def test_root_puct_visit_counts_bit_exact(v0):
+    z = load("g6_root_puct.npz")
+    p, lv, vm = (torch.from_numpy(z[k]).to(DEV) for k in ("priors", "leaf", "valid"))
+    for sims in (1, 16, 200, 1024):
+        v, vs, rv = v0.root_puct_allocate_visits(p, lv, vm, sims, 1.0)
+        assert np.array_equal(v.cpu().numpy(), z[f"visits_{sims}"]), sims
+        np.testing.assert_allclose(vs.cpu().numpy(), z[f"value_sum_{sims}"], atol=1e-4, rtol=1e-5)
+        np.testing.assert_allclose(rv.cpu().numpy(), z[f"root_{sims}"], atol=1e-5, rtol=0)
+    v, _, _ = v0.root_puct_allocate_visits(p, lv, vm, 64, 2.5)
+    assert np.array_equal(v.cpu().numpy(), z["visits_64_c25"])
+
+
+@pytest.mark.parametrize("A", [5, 64, 72, 130])
+def test_root_puct_random_vs_oracle(v0, A):
+    rng = np.random.default_rng(A)
+    R = 512
+    valid = rng.random((R, A)) < 0.5
+    valid[:, rng.integers(0, A)] = True
+    pri = (rng.random((R, A)) * valid).astype(np.float32)
+    pri /= np.maximum(pri.sum(1, keepdims=True), 1e-8)
+    leaf = ((rng.random((R, A)) * 2 - 1) * valid).astype(np.float32)
+    want_v, want_vs, want_rv = O.root_puct(pri, leaf, valid, 200, 1.25)
+    v, vs, rv = v0.root_puct_allocate_visits(torch.from_numpy(pri).to(DEV), torch.from_numpy(leaf).to(DEV),
+                                             torch.from_numpy(valid).to(DEV), 200, 1.25)
+    assert np.array_equal(v.cpu().numpy(), want_v)
+    np.testing.assert_allclose(vs.cpu().numpy(), want_vs, atol=1e-4, rtol=1e-5)
+    np.testing.assert_allclose(rv.cpu().numpy(), want_rv, atol=1e-5, rtol=0)
+
+
+def test_root_finalize_from_visits(v0):
+    z = load("g7_ops.npz")
+    g = lambda k: torch.from_numpy(z[k]).to(DEV)
+    B = z["s_board"].shape[0]
+    out = v0.root_finalize_from_visits(g("pack_legal_index_mat"), g("pack_action_code_mat"), g("pack_valid_mask"),
+                                       g("fin_visits"), g("fin_value_sum"), g("pack_valid_root_indices"), B, 220,
+                                       g("fin_temps"), False)
+    np.testing.assert_allclose(out[0].cpu().numpy(), z["fin_policy_dense"], atol=1e-5, rtol=0)
+    assert np.array_equal(out[1].cpu().numpy(), z["fin_chosen_idx"])
+    assert np.array_equal(out[2].cpu().numpy(), z["fin_chosen_codes"])
+    assert np.array_equal(out[3].cpu().numpy(), z["fin_chosen_valid"])
+    np.testing.assert_allclose(out[4].cpu().numpy(), z["fin_root_value"], atol=1e-6, rtol=0)
+    # sampled picks with injected uniforms: must be legal, and follow the inverse CDF of the stable policy
+    R, M = z["fin_visits"].shape
+    u = torch.linspace(0.01, 0.99, R).to(DEV)
+    out_s = v0.root_finalize_from_visits(g("pack_legal_index_mat"), g("pack_action_code_mat"), g("pack_valid_mask"),
+                                         g("fin_visits"), g("fin_value_sum"), g("pack_valid_root_indices"), B, 220,
+                                         g("fin_temps"), True, uniforms=u)
+    picks = out_s[1].cpu().numpy()
+    vis = z["fin_visits"]; valid = z["pack_valid_mask"]; temps = z["fin_temps"]
+    for r in range(R):
+        b = int(z["pack_valid_root_indices"][r])
+        logits = np.where(valid[r], np.log(np.maximum(vis[r], 1e-8)) / max(temps[r], 1e-6), -np.inf)
+        e = np.where(valid[r], np.exp(logits - logits.max()), 0.0)
+        cdf = np.cumsum(e)
+        target = float(u[r].item()) * cdf[-1]
+        k = int(np.searchsorted(cdf, target, side="right"))
+        k = min(k, int(np.nonzero(e > 0)[0].max()))
+        cand = {int(z["pack_legal_index_mat"][r, k])}
+        if k > 0 and abs(cdf[k - 1] - target) < 1e-5 * cdf[-1]:
+            cand.add(int(z["pack_legal_index_mat"][r, k - 1]))
+        if k + 1 < M and abs(cdf[k] - target) < 1e-5 * cdf[-1]:
+            cand.add(int(z["pack_legal_index_mat"][r, k + 1]))
+        assert int(picks[b]) in cand, (r, picks[b], cand)
+    np.testing.assert_allclose(out_s[0].cpu().numpy(), z["fin_policy_dense"], atol=1e-5, rtol=0)
+
+
+def test_self_play_step_inplace(v0):
+    z = load("g7_ops.npz")
+    t = to_dev(states(z, "s"))
+    plies = torch.from_numpy(z["step_plies_in"].copy()).to(DEV)
+    done = torch.zeros(plies.shape[0], dtype=torch.bool, device=DEV)
+    g = lambda k: torch.from_numpy(z[k]).to(DEV)
+    slots, res, soft = v0.self_play_step_inplace(*t, plies, done, g("step_active"), g("step_codes"), g("step_term"),
+                                                 g("step_valid"), 96, 2.0)
+    assert np.array_equal(slots.cpu().numpy(), z["step_slots"])
+    assert np.array_equal(res.cpu().numpy(), z["step_result"])
+    np.testing.assert_allclose(soft.cpu().numpy(), z["step_soft"], atol=1e-6, rtol=0)
+    assert np.array_equal(plies.cpu().numpy(), z["step_plies_out"])
+    assert np.array_equal(done.cpu().numpy(), z["step_done_out"])
+    ok, field = states_equal(from_dev(t), {f: z[f"step_after_{f}"] for f in FIELDS})
+    assert ok, field
+
+
+def test_finalize_trajectory_inplace(v0):
+    z = load("g7_ops.npz")
+    g = lambda k: torch.from_numpy(z[k]).to(DEV)
+    S = z["traj_value_out"].shape[0]
+    vt = torch.full((S,), float("nan"), device=DEV); svt = torch.full((S,), float("nan"), device=DEV)
+    fs, fc, co = v0.finalize_trajectory_inplace(vt, svt, g("traj_signs"), g("traj_step_index"), g("traj_counts"),
+                                                g("traj_slots"), g("traj_result"), g("traj_soft"))
+    np.testing.assert_array_equal(vt.cpu().numpy(), z["traj_value_out"])
+    np.testing.assert_allclose(svt.cpu().numpy(), z["traj_soft_out"], atol=1e-7, rtol=0, equal_nan=True)
+    assert np.array_equal(fs.cpu().numpy(), z["traj_final_slots"])
+    assert np.array_equal(fc.cpu().numpy(), z["traj_final_counts"])
+    assert np.array_equal(co.cpu().numpy(), z["traj_counts_out"])
+
+
+def test_cpu_tensors_fail_loudly(v0):
+    t = [torch.from_numpy(np.asarray(v)) for v in O.initial_states(2).values()]
+    with pytest.raises(RuntimeError, match="CUDA kernels were not built"):
+        v0.encode_actions_fast(*t[:10], 36, 144, 36, 4)
+
+
+def test_model_fp32_matches_reference_outputs(v0):
+    """<= 1e-5 on policy / value tensors (fp32 path), weights regenerated from the seed on the box."""
+    import json, os
+    from liuzhou_amd.net import ChessNet, MODEL_CONFIGS
+    from tests.golden_utils import GOLDEN
+    z = load("g9_net.npz")
+    keys = json.load(open(os.path.join(GOLDEN, "g9_net_keys.json")))
+    x = torch.from_numpy(z["inputs"].astype(np.float32)).to(DEV)
+    for name, seed in (("tiny", 7), ("b6c64", 20260314), ("b10c128", 20260314)):
+        torch.manual_seed(seed)
+        m = ChessNet(**MODEL_CONFIGS[name])
+        gen = torch.Generator().manual_seed(seed + 1)
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                mod.running_mean.copy_(torch.randn(mod.running_mean.shape, generator=gen) * 0.1)
+                mod.running_var.copy_(torch.rand(mod.running_var.shape, generator=gen) * 0.5 + 0.75)
+                mod.weight.data.copy_(torch.rand(mod.weight.shape, generator=gen) * 0.5 + 0.75)
+                mod.bias.data.copy_(torch.randn(mod.bias.shape, generator=gen) * 0.1)
+        assert [(k, list(v.shape)) for k, v in m.state_dict().items()] == [(k, s) for k, s in keys[name]]
+        m = m.to(DEV).eval()
+        with torch.inference_mode():
+            out = m(x)
+        for got, k in zip(out, ("lp1", "lp2", "lpmc", "value_logits")):
+            np.testing.assert_allclose(got.cpu().numpy(), z[f"{name}_{k}"], atol=1e-5, rtol=0, err_msg=f"{name}/{k}")

@@ -1,0 +1,24 @@
+"""CPU: the oracle's variant-R self-play loop reproduces the reference v1 runner's trace (g8)."""
+import numpy as np
+import torch
+
+from oracle import selfplay_oracle as SO
+from liuzhou_amd.net import ChessNet, MODEL_CONFIGS
+from tests.golden_utils import load
+
+
+def test_oracle_root_selfplay_matches_reference_trace():
+    z = load("g8_selfplay.npz")
+    torch.manual_seed(7)
+    model = ChessNet(**MODEL_CONFIGS["tiny"]).eval()
+    tensors, stats = SO.self_play_root(model, num_games=4, sims=32, temperature_init=1.0, temperature_final=0.1,
+                                       temperature_threshold=10, c=1.0, soft_k=2.0, max_game_plies=512)
+    n = int(z["num_positions"])
+    assert stats["num_positions"] == n
+    want_states = np.unpackbits(z["state_tensors"], axis=1)[:, :11 * 36].reshape(n, 11, 6, 6).astype(np.float32)
+    assert np.array_equal(tensors["state_tensors"], want_states)
+    assert np.array_equal(tensors["legal_masks"], np.unpackbits(z["legal_masks"], axis=1)[:, :220].astype(bool))
+    np.testing.assert_allclose(tensors["policy_targets"], z["policy_targets"], atol=1e-5, rtol=0)
+    np.testing.assert_array_equal(tensors["value_targets"], z["value_targets"])
+    np.testing.assert_allclose(tensors["soft_value_targets"], z["soft_value_targets"], atol=1e-6, rtol=0)
+    assert (stats["black_wins"], stats["white_wins"], stats["draws"]) == (int(z["black_wins"]), int(z["white_wins"]), int(z["draws"]))
