@@ -742,10 +742,11 @@ const char* lz_status_string(int status) {
 
 int lz_encode_actions_fast(const LzStateSoA* s, int64_t B, int64_t pd, int64_t md, int64_t sd, int64_t ad,
                            uint8_t* mask, int32_t* meta, void* stream) {
-    if (!soa_ok(s) || B < 0 || !mask || !meta || ad < 0) return LZ_ERR_ARG;
+    if (B < 0 || ad < 0) return LZ_ERR_ARG;
     if (pd != 36 || md != 144 || sd != 36 || ad > 40) return LZ_ERR_UNSUPPORTED;
+    if (B == 0) return LZ_OK;                          /* empty batch: pointers may be null */
+    if (!soa_ok(s) || !mask || !meta) return LZ_ERR_ARG;
     if (!aligned(meta, 16)) return LZ_ERR_ALIGN;
-    if (B == 0) return LZ_OK;
     const int T = (int)(pd + md + sd + ad);
     if ((T % 4) == 0 && aligned(mask, 4))
         hipLaunchKernelGGL(encode_actions_kernel<true>, dim3(grid_waves(B)), dim3(kBlock), 0, as_stream(stream), *s, B, T, mask, meta);
@@ -756,9 +757,10 @@ int lz_encode_actions_fast(const LzStateSoA* s, int64_t B, int64_t pd, int64_t m
 
 int lz_batch_apply_moves(const LzStateSoA* s, int64_t B, const int32_t* codes, const int64_t* parents,
                          int64_t N, const LzStateSoA* out, void* stream) {
-    if (!soa_ok(s) || !soa_ok(out) || B < 0 || N < 0 || (N > 0 && (!codes || !parents))) return LZ_ERR_ARG;
-    if (!soa_aligned(s) || !soa_aligned(out) || !aligned(codes, 16)) return LZ_ERR_ALIGN;
+    if (B < 0 || N < 0) return LZ_ERR_ARG;
     if (N == 0) return LZ_OK;
+    if (!s || !out || !soa_ok(s) || !soa_ok(out) || !codes || !parents) return LZ_ERR_ARG;
+    if (!soa_aligned(s) || !soa_aligned(out) || !aligned(codes, 16)) return LZ_ERR_ALIGN;
     hipLaunchKernelGGL(apply_moves_kernel, dim3(grid_threads(N)), dim3(kBlock), 0, as_stream(stream), *s, B,
                        reinterpret_cast<const int4*>(codes), parents, N, *out);
     return launch_status();
@@ -766,9 +768,10 @@ int lz_batch_apply_moves(const LzStateSoA* s, int64_t B, const int32_t* codes, c
 
 int lz_batch_apply_moves_inplace(const LzStateSoA* s, int64_t B, const int32_t* codes, const int64_t* slots,
                                  int64_t N, void* stream) {
-    if (!soa_ok(s) || B < 0 || N < 0 || (N > 0 && (!codes || !slots))) return LZ_ERR_ARG;
-    if (!soa_aligned(s) || !aligned(codes, 16)) return LZ_ERR_ALIGN;
+    if (B < 0 || N < 0) return LZ_ERR_ARG;
     if (N == 0) return LZ_OK;
+    if (!soa_ok(s) || !codes || !slots) return LZ_ERR_ARG;
+    if (!soa_aligned(s) || !aligned(codes, 16)) return LZ_ERR_ALIGN;
     hipLaunchKernelGGL(apply_moves_inplace_kernel, dim3(grid_threads(N)), dim3(kBlock), 0, as_stream(stream), *s, B,
                        reinterpret_cast<const int4*>(codes), slots, N);
     return launch_status();
@@ -776,9 +779,10 @@ int lz_batch_apply_moves_inplace(const LzStateSoA* s, int64_t B, const int32_t* 
 
 int lz_states_to_model_input(const int8_t* board, const uint8_t* mb, const uint8_t* mw, const int64_t* phase,
                              const int64_t* player, int64_t B, float* out, void* stream) {
-    if (!board || !mb || !mw || !phase || !player || !out || B < 0) return LZ_ERR_ARG;
-    if (!aligned(out, 16)) return LZ_ERR_ALIGN;
+    if (B < 0) return LZ_ERR_ARG;
     if (B == 0) return LZ_OK;
+    if (!board || !mb || !mw || !phase || !player || !out) return LZ_ERR_ARG;
+    if (!aligned(out, 16)) return LZ_ERR_ALIGN;
     hipLaunchKernelGGL(model_input_kernel, dim3(grid_waves(B)), dim3(kBlock), 0, as_stream(stream), board, mb, mw,
                        phase, player, B, out);
     return launch_status();
@@ -787,9 +791,10 @@ int lz_states_to_model_input(const int8_t* board, const uint8_t* mb, const uint8
 int lz_project_policy_logits_fast(const float* lp1, const float* lp2, const float* lpmc, const uint8_t* mask,
                                   int64_t B, int64_t pd, int64_t md, int64_t sd, int64_t ad, float* probs,
                                   float* masked_logits, void* stream) {
-    if (!lp1 || !lp2 || !lpmc || !mask || !probs || !masked_logits || B < 0 || ad < 0) return LZ_ERR_ARG;
+    if (B < 0 || ad < 0) return LZ_ERR_ARG;
     if (pd != 36 || md != 144 || sd != 36 || ad > 40) return LZ_ERR_UNSUPPORTED;
     if (B == 0) return LZ_OK;
+    if (!lp1 || !lp2 || !lpmc || !mask || !probs || !masked_logits) return LZ_ERR_ARG;
     const int T = (int)(pd + md + sd + ad);
     hipLaunchKernelGGL(project_policy_kernel, dim3(grid_waves(B)), dim3(kBlock), 0, as_stream(stream), lp1, lp2, lpmc,
                        mask, B, T, probs, masked_logits);
@@ -799,11 +804,11 @@ int lz_project_policy_logits_fast(const float* lp1, const float* lp2, const floa
 int lz_root_pack_rows(const uint8_t* mask, const float* probs, const int32_t* meta, int64_t B, int64_t T,
                       int64_t cap, int32_t* counts, int32_t* legal_index, float* priors, int32_t* codes,
                       void* stream) {
-    if (!mask || !probs || !meta || !counts || !legal_index || !priors || !codes || B < 0 || T <= 0 || cap <= 0)
-        return LZ_ERR_ARG;
+    if (B < 0 || T <= 0 || cap <= 0) return LZ_ERR_ARG;
     if (T > 4096 || cap > 4096) return LZ_ERR_UNSUPPORTED;
-    if (!aligned(meta, 16) || !aligned(codes, 16)) return LZ_ERR_ALIGN;
     if (B == 0) return LZ_OK;
+    if (!mask || !probs || !meta || !counts || !legal_index || !priors || !codes) return LZ_ERR_ARG;
+    if (!aligned(meta, 16) || !aligned(codes, 16)) return LZ_ERR_ALIGN;
     hipLaunchKernelGGL(root_pack_kernel, dim3(grid_waves(B)), dim3(kBlock), 0, as_stream(stream), mask, probs,
                        reinterpret_cast<const int4*>(meta), B, (int)T, (int)cap, counts, legal_index, priors,
                        reinterpret_cast<int4*>(codes));
@@ -813,10 +818,10 @@ int lz_root_pack_rows(const uint8_t* mask, const float* probs, const int32_t* me
 int lz_root_puct_allocate_visits(const float* priors, const float* leaf, const uint8_t* valid, int64_t R,
                                  int64_t A, int64_t sims, float c, float* visits, float* value_sum,
                                  float* root_values, void* stream) {
-    if (!priors || !leaf || !valid || !visits || !value_sum || !root_values || R < 0 || A < 0 || sims <= 0)
-        return LZ_ERR_ARG;
+    if (R < 0 || A < 0 || sims <= 0) return LZ_ERR_ARG;
     if (A > 256) return LZ_ERR_UNSUPPORTED;
     if (R == 0 || A == 0) return LZ_OK;
+    if (!priors || !leaf || !valid || !visits || !value_sum || !root_values) return LZ_ERR_ARG;
     const dim3 grid(grid_waves(R)), block(kBlock);
     hipStream_t st = as_stream(stream);
     if (A <= 64) hipLaunchKernelGGL(root_puct_kernel<1>, grid, block, 0, st, priors, leaf, valid, R, (int)A, sims, c, visits, value_sum, root_values);
@@ -830,7 +835,9 @@ int lz_root_finalize_from_visits(const int64_t* lidx, const int32_t* codes, cons
                                  int64_t M, int64_t B, int64_t T, const float* temps, const float* uniforms,
                                  float* policy, int64_t* cidx, int32_t* ccodes, uint8_t* cvalid,
                                  float* root_value, void* stream) {
-    if (B < 0 || T <= 0 || R < 0 || M < 0 || !policy || !cidx || !ccodes || !cvalid) return LZ_ERR_ARG;
+    if (B < 0 || T <= 0 || R < 0 || M < 0) return LZ_ERR_ARG;
+    if (B == 0) return LZ_OK;
+    if (!policy || !cidx || !ccodes || !cvalid) return LZ_ERR_ARG;
     if (R > 0 && M > 0 && (!lidx || !codes || !valid || !visits || !value_sum || !roots || !temps || !root_value))
         return LZ_ERR_ARG;
     if (M > 256) return LZ_ERR_UNSUPPORTED;
@@ -857,10 +864,11 @@ int lz_self_play_step_inplace(const LzStateSoA* s, int64_t B, int64_t* plies, ui
                               const int64_t* active, int64_t n_active, const int32_t* codes,
                               const uint8_t* terminal, const uint8_t* cvalid, int64_t max_plies, float k,
                               int32_t* fin_kind, float* result, float* soft, void* stream) {
-    if (!soa_ok(s) || !plies || !done || B < 0 || n_active < 0 || max_plies <= 0) return LZ_ERR_ARG;
-    if (n_active > 0 && (!active || !codes || !terminal || !cvalid || !fin_kind || !result || !soft)) return LZ_ERR_ARG;
-    if (!soa_aligned(s) || (codes && !aligned(codes, 16))) return LZ_ERR_ALIGN;
+    if (B < 0 || n_active < 0 || max_plies <= 0) return LZ_ERR_ARG;
     if (n_active == 0) return LZ_OK;
+    if (!soa_ok(s) || !plies || !done) return LZ_ERR_ARG;
+    if (!active || !codes || !terminal || !cvalid || !fin_kind || !result || !soft) return LZ_ERR_ARG;
+    if (!soa_aligned(s) || !aligned(codes, 16)) return LZ_ERR_ALIGN;
     hipLaunchKernelGGL(self_play_step_kernel, dim3(grid_threads(n_active)), dim3(kBlock), 0, as_stream(stream), *s, B,
                        plies, done, active, n_active, reinterpret_cast<const int4*>(codes), terminal, cvalid,
                        max_plies, k, fin_kind, result, soft);
