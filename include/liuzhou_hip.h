@@ -162,6 +162,35 @@ LZ_API int lz_finalize_trajectory_inplace(float* value_targets, float* soft_valu
                                           uint8_t* keep, int64_t* final_counts, int64_t* counts_out,
                                           void* stream);
 
+
+/* ---- network forward ------------------------------------------------------------------------- */
+
+/* Packed network description (built by liuzhou_amd/net_pack.py from a ChessNet state_dict:
+ * BatchNorm folded, conv weights in v_mfma_f32_16x16x32_f16 operand order).  All offsets into
+ * `fparams` are in floats, `layer_offsets` (stem, conv1/conv2 per block, stacked head convs) in halfs. */
+typedef struct LzNetDesc {
+    int32_t channels;            /* trunk channels: 64 or 128 */
+    int32_t blocks;              /* residual blocks (<= 15) */
+    int32_t num_layers;          /* 2 + 2*blocks */
+    int32_t max_blocks;          /* persistent grid size (0 = 256, one workgroup per CU) */
+    const void* wfrag;           /* device, fp16 */
+    const float* fparams;        /* device, fp32 */
+    int32_t layer_offsets[32];
+    int32_t off_stem_bias, off_block0 /* a1|b1|bias1 per block, 3*C floats each */, off_trunk_a, off_trunk_b,
+            off_head_bias, off_p_gwT, off_p_a2, off_p_b2, off_p_out, off_v_w1T, off_v_b1, off_v_w2T, off_v_b2;
+} LzNetDesc;
+
+/* ChessNet.forward (src/neural_network.py:213-259) + bucket_logits_to_scalar (:201-210), fused:
+ * planes float32[N,11,6,6] -> log_p1 / log_p2 / log_pmc float32[N,36] (log-softmax over the board),
+ * value_logits float32[N,101] (may be NULL), value float32[N] = E[bucket centre] (may be NULL).
+ * fp16 MFMA operands with fp32 accumulation and an fp32 residual stream (the reference's autocast
+ * inference mode, v1/python/mcts_gpu.py:640-646). */
+LZ_API int lz_net_forward_f16(const LzNetDesc* net, const float* planes, int64_t batch,
+                              float* log_p1, float* log_p2, float* log_pmc,
+                              float* value_logits, float* value, void* stream);
+/* one-time kernel attribute setup (dynamic LDS size); call once per process before graph capture */
+LZ_API int lz_net_configure(void);
+
 #ifdef __cplusplus
 }
 #endif

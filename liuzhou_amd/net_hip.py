@@ -1,0 +1,99 @@
+"""Fused gfx950 network forward (csrc/lz_net.hip) behind a module-like callable.
+
+`FusedNet(model)` packs a ChessNet once (BN folding + MFMA fragment order, net_pack.py) and then
+evaluates `planes f32[N,11,6,6] -> (log_p1, log_p2, log_pmc, value_logits)` -- the same 4-tuple as
+`ChessNet.forward` (src/neural_network.py:248-259) -- plus the bucket-expectation scalar in `.last_value`.
+It is also usable as the `inference_engine` of V1RootMCTS (`.forward(inputs, n_valid)`), i.e. the seat the
+reference gives to its TorchScript/CUDA-graph InferenceEngine (v0/src/net/inference_engine.cpp:58-202).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib as L
+from .net_pack import NetPack, pack_model, BINS
+
+
+class LzNetDesc(C.Structure):
+    _fields_ = [("channels", C.c_int32), ("blocks", C.c_int32), ("num_layers", C.c_int32), ("max_blocks", C.c_int32),
+                ("wfrag", C.c_void_p), ("fparams", C.c_void_p), ("layer_offsets", C.c_int32 * 32)] + \
+               [(n, C.c_int32) for n in ("off_stem_bias", "off_block0", "off_trunk_a", "off_trunk_b", "off_head_bias",
+                                         "off_p_gwT", "off_p_a2", "off_p_b2", "off_p_out", "off_v_w1T", "off_v_b1",
+                                         "off_v_w2T", "off_v_b2")]
+
+
+_configured = False
+
+
+class FusedNet:
+    def __init__(self, model, device=None, max_blocks: int = 0) -> None:
+        global _configured
+        dev = torch.device(device) if device is not None else next(model.parameters()).device
+        if dev.type != "cuda":
+            raise RuntimeError("FusedNet needs a HIP device (no CPU path)")
+        self.device = dev
+        self.pack: NetPack = pack_model(model).to(dev)
+        if self.pack.channels not in (64, 128):
+            raise RuntimeError(f"fused kernel is built for 64 / 128 trunk channels, got {self.pack.channels}")
+        d = LzNetDesc()
+        d.channels, d.blocks = self.pack.channels, self.pack.blocks
+        d.num_layers = len(self.pack.layer_offsets)
+        d.max_blocks = int(max_blocks)
+        d.wfrag, d.fparams = self.pack.wfrag.data_ptr(), self.pack.fparams.data_ptr()
+        for i, o in enumerate(self.pack.layer_offsets):
+            d.layer_offsets[i] = int(o)
+        f = self.pack.foff
+        d.off_stem_bias, d.off_block0 = f["stem_bias"], f.get("b0_a1", 0)
+        d.off_trunk_a, d.off_trunk_b, d.off_head_bias = f["trunk_a"], f["trunk_b"], f["head_bias"]
+        d.off_p_gwT, d.off_p_a2, d.off_p_b2, d.off_p_out = f["p_gwT"], f["p_a2"], f["p_b2"], f["p_out"]
+        d.off_v_w1T, d.off_v_b1, d.off_v_w2T, d.off_v_b2 = f["v_w1T"], f["v_b1"], f["v_w2T"], f["v_b2"]
+        self.desc = d
+        self.last_value: Optional[torch.Tensor] = None
+        self.flops_per_eval = _flops(self.pack.channels, self.pack.blocks)
+        if not _configured:
+            with torch.cuda.device(dev):
+                L.check(L.lib().lz_net_configure(), "net_configure")
+            _configured = True
+
+    def eval(self):
+        return self
+
+    def forward_into(self, planes: torch.Tensor, lp1, lp2, lpm, vlogits, value) -> None:
+        N = int(planes.shape[0])
+        with torch.cuda.device(self.device):
+            st = L.lib().lz_net_forward_f16(C.byref(self.desc), L.ptr(planes), L.i64(N), L.ptr(lp1), L.ptr(lp2),
+                                            L.ptr(lpm), L.ptr(vlogits), L.ptr(value), L.stream_ptr(self.device))
+        L.check(st, "net_forward_f16")
+
+    def __call__(self, planes: torch.Tensor, want_logits: bool = True) -> Tuple[torch.Tensor, ...]:
+        L.require_hip(planes, "net_forward_f16")
+        x = planes if (planes.dtype == torch.float32 and planes.is_contiguous()) else planes.float().contiguous()
+        N = int(x.shape[0])
+        dev = x.device
+        lp1 = torch.empty((N, 36), dtype=torch.float32, device=dev)
+        lp2 = torch.empty((N, 36), dtype=torch.float32, device=dev)
+        lpm = torch.empty((N, 36), dtype=torch.float32, device=dev)
+        vl = torch.empty((N, BINS), dtype=torch.float32, device=dev) if want_logits else None
+        val = torch.empty((N,), dtype=torch.float32, device=dev)
+        self.forward_into(x, lp1, lp2, lpm, vl, val)
+        self.last_value = val
+        return lp1, lp2, lpm, vl
+
+    def forward(self, inputs: torch.Tensor, n_valid: Optional[int] = None):
+        out = self(inputs)
+        return out
+
+    def values_only(self, planes: torch.Tensor) -> torch.Tensor:
+        self(planes, want_logits=False)
+        return self.last_value
+
+
+def _flops(C: int, NB: int) -> float:
+    """Algorithmic FLOPs per evaluation: stem + trunk + heads."""
+    stem = 2 * 36 * 9 * 11 * C
+    trunk = NB * 2 * (2 * 36 * 9 * C * C)
+    heads = 2 * 36 * C * 128 + 2 * (192 * 64 + 36 * 64 * 3 + 192 * 128 + 128 * 101)
+    return float(stem + trunk + heads)

@@ -1,0 +1,54 @@
+"""GPU: fused fp16-MFMA network forward vs the fp32 PyTorch model (and the pack emulation)."""
+import numpy as np
+import pytest
+import torch
+
+from tests.golden_utils import load, states, FIELDS
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _planes(n, seed=0):
+    """n real positions: golden reachable states encoded with the HIP op."""
+    from liuzhou_amd import v0_core
+    z = load("g1_rules.npz")
+    st = states(z, "s")
+    rng = np.random.default_rng(seed)
+    idx = rng.integers(0, st["board"].shape[0], n)
+    t = lambda k, dt: torch.from_numpy(np.ascontiguousarray(st[k][idx]).astype(dt)).to(DEV)
+    return v0_core.states_to_model_input(t("board", np.int8), t("marks_black", bool), t("marks_white", bool),
+                                         t("phase", np.int64), t("current_player", np.int64))
+
+
+@pytest.mark.parametrize("name,n", [("b6c64", 16), ("b6c64", 1000), ("b6c64", 4099), ("b10c128", 8), ("b10c128", 777)])
+def test_fused_net_matches_fp32_model(name, n):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from liuzhou_amd.net import ChessNet, MODEL_CONFIGS, bucket_logits_to_scalar
+    from liuzhou_amd.net_hip import FusedNet
+    torch.manual_seed(20260314)
+    m = ChessNet(**MODEL_CONFIGS[name]).eval()
+    g = torch.Generator().manual_seed(5)
+    for mod in m.modules():                       # non-trivial BN statistics so folding is exercised
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.running_mean.copy_(torch.randn(mod.running_mean.shape, generator=g) * 0.1)
+            mod.running_var.copy_(torch.rand(mod.running_var.shape, generator=g) * 0.5 + 0.75)
+            mod.weight.data.copy_(torch.rand(mod.weight.shape, generator=g) * 0.5 + 0.75)
+            mod.bias.data.copy_(torch.randn(mod.bias.shape, generator=g) * 0.1)
+    m = m.to(DEV)
+    x = _planes(n, seed=n)
+    fused = FusedNet(m)
+    lp1, lp2, lpm, vl = fused(x)
+    val = fused.last_value
+    with torch.inference_mode():
+        r1, r2, rm, rv = m(x)
+        rval = bucket_logits_to_scalar(rv)
+    # fp16 operands / fp32 accumulate: tolerance is the reduced-precision mode's, not the 1e-5 fp32 bar
+    for got, want in ((lp1, r1), (lp2, r2), (lpm, rm)):
+        assert torch.isfinite(got).all()
+        err = (got.exp() - want.exp()).abs().max().item()
+        assert err < 3e-3, err
+        assert torch.allclose(got.exp().sum(1), torch.ones(n, device=DEV), atol=1e-4)
+    assert (vl - rv).abs().max().item() < 3e-2
+    assert (val - rval).abs().max().item() < 3e-3
