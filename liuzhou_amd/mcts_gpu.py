@@ -259,8 +259,18 @@ class V1RootMCTS:
             return torch.autocast("cuda", enabled=False)
         return torch.autocast("cuda", dtype=torch.bfloat16 if key in ("bf16", "bfloat16") else torch.float16)
 
+    def _fused(self):
+        """The fused gfx950 forward (net_hip.FusedNet) if one was given as `model` or `inference_engine`."""
+        for cand in (self.inference_engine, self.model):
+            if cand is not None and hasattr(cand, "values_only") and hasattr(cand, "last_value"):
+                return cand
+        return None
+
     def _forward_model(self, inputs: torch.Tensor):
         self._leaf_evals += int(inputs.shape[0])
+        fused = self._fused()
+        if fused is not None:
+            return fused(inputs)
         if self.inference_engine is not None:
             return self.inference_engine.forward(inputs, int(inputs.shape[0]))
         self.model.eval()
@@ -281,13 +291,19 @@ class V1RootMCTS:
     def _evaluate_batch(self, batch: GpuStateBatch):
         inputs = states_to_model_input(batch)
         lp1, lp2, lpm, raw = self._forward_model(inputs)
-        values = self._to_scalar_value(raw).float()
+        fused = self._fused()
+        values = fused.last_value if fused is not None else self._to_scalar_value(raw).float()
         legal_mask, metadata = encode_actions_fast(batch)
         probs, _ = v0_core.project_policy_logits_fast(lp1.float(), lp2.float(), lpm.float(), legal_mask,
                                                       PLACEMENT_DIM, MOVEMENT_DIM, SELECTION_DIM, AUXILIARY_DIM)
         return inputs, legal_mask, metadata, probs, values
 
     def _evaluate_values_only(self, batch: GpuStateBatch) -> torch.Tensor:
+        fused = self._fused()
+        if fused is not None:
+            inputs = states_to_model_input(batch)
+            self._leaf_evals += int(inputs.shape[0])
+            return fused.values_only(inputs)
         _, _, _, raw = self._forward_model(states_to_model_input(batch))
         return self._to_scalar_value(raw).float()
 

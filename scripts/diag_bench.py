@@ -11,17 +11,10 @@ dev = torch.device("cuda:0")
 games = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 torch.manual_seed(20260314)
 model = ChessNet(**MODEL_CONFIGS["b6c64"]).eval().to(dev)
+from liuzhou_amd.net_hip import FusedNet
+model = FusedNet(model)
 cfg = V1RootMCTSConfig(num_simulations=200, autocast_dtype=sys.argv[2] if len(sys.argv) > 2 else "float16")
 t = time.time(); pop = SteadyStateRootSelfPlay(model, games, cfg, dev); torch.cuda.synchronize(); log("init", time.time() - t)
 t = time.time(); pop.preroll(120); torch.cuda.synchronize(); log("preroll", time.time() - t)
-# NN forward timing at a few batch sizes
-x = torch.randn(games, 11, 6, 6, device=dev)
-for n in (games, 8 * games, 24 * games, 24 * games + 7, 25 * games):
-    xx = torch.randn(n, 11, 6, 6, device=dev)
-    for rep in range(3):
-        t = time.time()
-        with torch.inference_mode(), torch.autocast("cuda", dtype=torch.float16):
-            o = model(xx)
-        torch.cuda.synchronize(); log("fwd", n, rep, round(time.time() - t, 4))
-for i in range(4):
-    t = time.time(); pop.step(); torch.cuda.synchronize(); log("step", i, round(time.time() - t, 3), "evals", pop.mcts._leaf_evals)
+for i in range(8):
+    t = time.time(); pop.step(); torch.cuda.synchronize(); log("step", i, round(time.time() - t, 4), "evals", pop.mcts._leaf_evals)
