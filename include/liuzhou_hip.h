@@ -191,6 +191,72 @@ LZ_API int lz_net_forward_f16(const LzNetDesc* net, const float* planes, int64_t
 /* one-time kernel attribute setup (dynamic LDS size); call once per process before graph capture */
 LZ_API int lz_net_configure(void);
 
+/* ---- device-resident tree search (variant P) --------------------------------------------------- */
+
+/* Replaces the reference's portable full-tree search and its split-phase C++ twin:
+ *   v1/python/portable_mcts.py:264-746 (PortableMCTS.search_batch) == src/mcts.py:280-548 with batch_K=1,
+ *   v1/cpp/portable_mcts.cpp:448-979 (PrepareRoots / SelectLeaves / CompletePending / AdvanceRoots).
+ * All buffers are caller-allocated device memory; per game g the regions are
+ *   nodes  [g*node_cap  .. +node_cap)   node_cap >= sims + 2
+ *   edges  [g*edge_cap  .. +edge_cap)   edge_cap >= (sims + 1) * 72   (worst case, no overflow path)
+ *   path   [g*path_cap  .. +path_cap)   path_cap >= sims + 3
+ * States are 32-byte packed bitboard records (lz_pack_states). */
+typedef struct LzTreeDesc {
+    int64_t num_games;
+    int32_t node_cap, edge_cap, path_cap, reserved;
+    double  exploration_weight;
+    const void* root_state;        /* packed [B]: current game states (input of lz_tree_begin) */
+    void*    node_state;           /* packed [B*node_cap] */
+    int32_t* node_edge_begin;      /* [B*node_cap] */
+    int32_t* node_nedges;          /* [B*node_cap]  (-1 = not expanded) */
+    double*  edge_w;               /* [B*edge_cap] value sums (child mover's perspective) */
+    float*   edge_p;               /* priors */
+    int32_t* edge_n;               /* visit counts */
+    int32_t* edge_child;           /* node index or -1 */
+    uint8_t* edge_action;          /* 220-d action index */
+    uint8_t* edge_info;            /* bit0 child mover white, bit1 terminal, bits2-3 terminal value + 1 */
+    int32_t* n_nodes;              /* [B] */
+    int32_t* n_edges;              /* [B] */
+    int32_t* root_visits;          /* [B] */
+    double*  root_w;               /* [B] */
+    float*   root_init_value;      /* [B] */
+    int32_t* path;                 /* [B*path_cap] */
+    int32_t* path_len;             /* [B] */
+    int32_t* leaf_kind;            /* [B] 0 inactive, 1 needs evaluation, 2 terminal (value in leaf_value) */
+    void*    leaf_state;           /* packed [B]: state awaiting evaluation */
+    float*   leaf_value;           /* [B] */
+    uint8_t* root_terminal;        /* [B] */
+    const uint8_t* active;         /* [B] or NULL (all active) */
+} LzTreeDesc;
+
+/* SoA batch -> packed records; packed records -> float32[B,11,6,6] model input (src/neural_network.py:15-65) */
+LZ_API int lz_pack_states(const LzStateSoA* states, int64_t batch, void* packed_out, void* stream);
+LZ_API int lz_packed_to_model_input(const void* packed, int64_t batch, float* out, void* stream);
+
+/* PrepareRoots: fresh single-node trees from root_state; the roots become the pending evaluations. */
+LZ_API int lz_tree_begin(const LzTreeDesc* tree, void* stream);
+/* SelectLeaves: one PUCT descent per game; leaf_kind / leaf_state / path are written. */
+LZ_API int lz_tree_select(const LzTreeDesc* tree, void* stream);
+/* CompletePending: expand the pending leaf of every game and back the value up (is_root: expand only,
+ * optional noise float32[B,noise_stride] mixed with weight epsilon, `set_root_priors` semantics).
+ * Evaluator output is either the three log-prob heads float32[B,36] (priors220 == NULL) or a dense
+ * prior row float32[B,220] (injected evaluator for parity runs); values float32[B]. */
+LZ_API int lz_tree_expand(const LzTreeDesc* tree, int is_root, const float* log_p1, const float* log_p2,
+                          const float* log_pmc, const float* priors220, const float* values,
+                          const float* noise, int64_t noise_stride, float epsilon, void* stream);
+/* Root policy (visits^(1/T) in log space), move pick (uniforms != NULL: inverse-CDF sample;
+ * NULL: most visits -> Q -> prior -> lowest index), per-child statistics.  child_* are [B,out_cap]. */
+LZ_API int lz_tree_finish(const LzTreeDesc* tree, const float* temperatures, const float* uniforms,
+                          float* policy_dense /*[B,220]*/, int32_t* chosen_index, int32_t* chosen_code /*[B,4]*/,
+                          uint8_t* chosen_valid, uint8_t* terminal_mask, float* root_value,
+                          int32_t* child_count, int32_t* child_action, int32_t* child_visits,
+                          float* child_prior, int64_t out_cap, void* stream);
+/* One whole search enqueued from C++: begin, root evaluation + expansion, then `sims` x
+ * (select -> planes -> fused network -> expand + backup).  No host synchronisation; capturable. */
+LZ_API int lz_tree_search(const LzTreeDesc* tree, const LzNetDesc* net, int64_t sims, float* planes /*[B,11,36]*/,
+                          float* log_p1, float* log_p2, float* log_pmc, float* values, const float* noise,
+                          int64_t noise_stride, float epsilon, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

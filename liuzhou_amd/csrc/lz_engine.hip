@@ -1,0 +1,609 @@
+// lz_engine.hip -- device-resident full-tree PUCT search ("variant P"), one wavefront per game.
+//
+// Semantics follow v1/python/portable_mcts.py:264-746 (== src/mcts.py:280-548 with batch_K = 1, no virtual
+// loss): one leaf per tree per simulation, all trees of the wave advanced together;
+//   select : argmax_a Q + c*P*sqrt(max(1,N_parent))/(1+n_a) in double, Q = W/n flipped iff the mover
+//            changes, first (lowest action index) maximum wins          (portable_mcts.py:480-506)
+//   expand : children in ascending 220-d action index, priors renormalised over the legal set,
+//            game-over children / no-legal leaves are terminal            (portable_mcts.py:418-478)
+//   backup : leaf -> root, N += 1, W += v, v = -v iff the mover changes   (portable_mcts.py:123-138)
+//   root   : expanded without backup, optional Dirichlet mix on the priors (portable_mcts.py:451-463)
+//
+// Layout in HBM (sized for the worst case, 288 GB makes this affordable -- no overflow paths):
+//   per game g: node arena  [S+1] x { packed 32-byte state, edge_begin, n_edges }
+//               edge arena  [(S+1)*72] x { W f64, P f32, N i32, child i32, action u8, info u8 }
+//               path        [S+2] edge ids of the current simulation
+// A wave owns one game: lanes enumerate legal actions with ballots + popcount prefixes, evaluate PUCT
+// scores for up to 2 children per lane and reduce with shuffles; there is no cross-wave communication.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "lz_soa.h"
+
+using namespace lz;
+
+namespace {
+
+constexpr int kWave = 64;
+constexpr int kBlock = 256;
+constexpr int kWavesPerBlock = 4;
+constexpr int kMaxChildren = 72;
+
+enum LeafKind : int { kLeafInactive = 0, kLeafExpand = 1, kLeafTerminal = 2 };
+// edge info bits
+constexpr uint8_t kInfoWhite = 1;       // child mover is white
+constexpr uint8_t kInfoTerminal = 2;    // child is terminal (game over, or found to have no legal move)
+// bits 2..3: terminal value + 1  (0 => -1, 1 => 0, 2 => +1), from the child's mover's perspective
+
+struct Tree {
+    int B, node_cap, edge_cap, path_cap;
+    const Packed* root_state;
+    Packed* node_state; int* node_edge_begin; int* node_nedges;
+    double* eW; float* eP; int* eN; int* eChild; uint8_t* eAct; uint8_t* eInfo;
+    int* n_nodes; int* n_edges; int* root_visits; double* root_W; float* root_init_value;
+    int* path; int* path_len; int* leaf_kind; Packed* leaf_state; float* leaf_value;
+    uint8_t* root_terminal; const uint8_t* active;
+    double c_puct;
+};
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+__device__ __forceinline__ int wave_game() {
+    return blockIdx.x * kWavesPerBlock + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+}
+__device__ __forceinline__ double wave_max_f64(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const double t = __shfl_xor(v, o); v = t > v ? t : v; }
+    return v;
+}
+__device__ __forceinline__ float wave_max_f32(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+__device__ __forceinline__ double terminal_value_for_mover(const State& s) {   // portable_mcts.py:141-147
+    const int st = game_status(s);
+    if (st == 1 || st == -1) return st == s.player ? 1.0 : -1.0;
+    return 0.0;
+}
+
+// ---- SoA <-> packed -------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void pack_states_kernel(LzStateSoA s, int64_t B, Packed* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= B) return;
+    State st;
+    st.black = cells_equal(s.board + i * 36, 1);
+    st.white = cells_equal(s.board + i * 36, -1);
+    st.mb = cells_nonzero(s.marks_black + i * 36);
+    st.mw = cells_nonzero(s.marks_white + i * 36);
+    st.phase = (int)s.phase[i]; st.player = (int)s.current_player[i];
+    st.pm_req = (int)s.pending_marks_required[i]; st.pm_rem = (int)s.pending_marks_remaining[i];
+    st.pc_req = (int)s.pending_captures_required[i]; st.pc_rem = (int)s.pending_captures_remaining[i];
+    st.forced = (int)s.forced_removals_done[i]; st.move_count = (int)s.move_count[i];
+    st.msc = (int)s.moves_since_capture[i];
+    out[i] = pack(st);
+}
+
+// packed states -> float32 model input planes (one wave per state; src/neural_network.py:15-65)
+__global__ __launch_bounds__(kBlock) void packed_planes_kernel(const Packed* __restrict__ states, int64_t B,
+                                                               float* __restrict__ out) {
+    const int lane = lane_id();
+    const int64_t g = (int64_t)blockIdx.x * kWavesPerBlock + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (g >= B) return;
+    const State s = unpack(states[g]);
+    const bool blk = s.player == 1;
+    const uint64_t own = blk ? s.black : s.white, opp = blk ? s.white : s.black;
+    const uint64_t sm = blk ? s.mb : s.mw, om = blk ? s.mw : s.mb;
+    float4* orow = reinterpret_cast<float4*>(out + g * 396);
+    for (int j = lane; j < 99; j += kWave) {
+        const int plane = j / 9, cell0 = (j - plane * 9) * 4;
+        uint32_t bits;
+        if (plane < 4) {
+            const uint64_t src = plane == 0 ? own : plane == 1 ? opp : plane == 2 ? sm : om;
+            bits = (uint32_t)(src >> cell0) & 0xFu;
+        } else bits = (s.phase == plane - 3) ? 0xFu : 0u;
+        orow[j] = make_float4((bits & 1) ? 1.f : 0.f, (bits & 2) ? 1.f : 0.f, (bits & 4) ? 1.f : 0.f, (bits & 8) ? 1.f : 0.f);
+    }
+}
+
+// ---- begin a search: fresh tree per game -----------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void tree_begin_kernel(Tree t) {
+    const int g = blockIdx.x * kBlock + threadIdx.x;
+    if (g >= t.B) return;
+    const Packed rs = t.root_state[g];
+    t.node_state[(size_t)g * t.node_cap] = rs;
+    t.node_edge_begin[(size_t)g * t.node_cap] = 0;
+    t.node_nedges[(size_t)g * t.node_cap] = -1;          // unexpanded
+    t.n_nodes[g] = 1;
+    t.n_edges[g] = 0;
+    t.root_visits[g] = 0;
+    t.root_W[g] = 0.0;
+    t.root_init_value[g] = 0.f;
+    t.path_len[g] = 0;
+    const State s = unpack(rs);
+    const bool act = t.active == nullptr || t.active[g] != 0;
+    const bool term = game_status(s) != 0;                // portable_mcts.py:601-603
+    t.root_terminal[g] = (term || !act) ? 1 : 0;
+    t.leaf_kind[g] = (term || !act) ? kLeafInactive : kLeafExpand;
+    t.leaf_state[g] = rs;                                  // the root is the first pending evaluation
+    t.leaf_value[g] = 0.f;
+}
+
+// ---- select: one wave per game ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void tree_select_kernel(Tree t) {
+    const int lane = lane_id();
+    const int g = wave_game();
+    if (g >= t.B) return;
+    if (t.root_terminal[g]) { if (lane == 0) t.leaf_kind[g] = kLeafInactive; return; }
+    const size_t nb = (size_t)g * t.node_cap, eb = (size_t)g * t.edge_cap;
+    int* path = t.path + (size_t)g * t.path_cap;
+    int node = 0, depth = 0;
+    int parent_n = t.root_visits[g];
+    int kind = kLeafInactive;
+    float term_value = 0.f;
+    State leaf;
+    for (;;) {
+        const int ne = t.node_nedges[nb + node];
+        if (ne <= 0) break;                                // (cannot happen for an expanded inner node)
+        const int e0 = t.node_edge_begin[nb + node];
+        const State ns = unpack(t.node_state[nb + node]);
+        const double sq = sqrt((double)(parent_n > 1 ? parent_n : 1));
+        // up to 2 children per lane, ascending edge index
+        double best = -INFINITY;
+        int best_k = -1;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int k = r * kWave + lane;
+            if (k < ne) {
+                const size_t e = eb + e0 + k;
+                const int n = t.eN[e];
+                double q = 0.0;
+                if (n > 0) {
+                    const double mv = t.eW[e] / (double)n;
+                    const int child_player = (t.eInfo[e] & kInfoWhite) ? -1 : 1;
+                    q = child_player == ns.player ? mv : -mv;
+                }
+                const double u = t.c_puct * (double)t.eP[e] * sq / (1.0 + (double)n);
+                const double sc = q + u;
+                if (sc > best) { best = sc; best_k = k; }
+            }
+        }
+        const double mx = wave_max_f64(best);
+        // lowest edge index among the maxima
+        uint64_t lo = __ballot(best_k >= 0 && best_k < kWave && best == mx);
+        int chosen;
+        if (lo) chosen = __ffsll((unsigned long long)lo) - 1;
+        else {
+            const uint64_t hi = __ballot(best_k >= kWave && best == mx);
+            if (!hi) break;                                // all scores NaN: stop here (portable: best_child None)
+            chosen = kWave + __ffsll((unsigned long long)hi) - 1;
+        }
+        const size_t e = eb + e0 + chosen;
+        if (lane == 0) path[depth] = e0 + chosen;
+        ++depth;
+        const uint8_t info = t.eInfo[e];
+        if (info & kInfoTerminal) {
+            kind = kLeafTerminal;
+            term_value = (float)((int)((info >> 2) & 3) - 1);
+            break;
+        }
+        const int child = t.eChild[e];
+        if (child < 0) {
+            leaf = ns;
+            int kd, p, q2, ex;
+            index_to_code(ns.phase, (int)t.eAct[e], kd, p, q2, ex);
+            apply(leaf, kd, p, q2);
+            kind = kLeafExpand;
+            break;
+        }
+        parent_n = t.eN[e];
+        node = child;
+        if (depth >= t.path_cap - 1) break;
+    }
+    if (lane == 0) {
+        t.path_len[g] = depth;
+        t.leaf_kind[g] = kind;
+        t.leaf_value[g] = term_value;
+        if (kind == kLeafExpand) t.leaf_state[g] = pack(leaf);
+    }
+}
+
+// ---- expand (+ backup): one wave per game -----------------------------------------------------------------
+// priors come either from the three 36-wide log-prob heads (production) or from a dense 220-d prior row
+// (injected evaluator, parity runs).  IS_ROOT: no backup, optional noise mix.
+template <bool IS_ROOT>
+__global__ __launch_bounds__(kBlock) void tree_expand_kernel(Tree t, const float* __restrict__ lp1,
+                                                             const float* __restrict__ lp2,
+                                                             const float* __restrict__ lpm,
+                                                             const float* __restrict__ priors220,
+                                                             const float* __restrict__ values,
+                                                             const float* __restrict__ noise, int noise_stride,
+                                                             float epsilon) {
+    __shared__ float s_pr[kWavesPerBlock][kMaxChildren + 8];
+    const int lane = lane_id();
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int g = blockIdx.x * kWavesPerBlock + w;
+    if (g >= t.B) return;
+    const int kind = t.leaf_kind[g];
+    if (kind == kLeafInactive) return;
+    const size_t nb = (size_t)g * t.node_cap, eb = (size_t)g * t.edge_cap;
+    const int* path = t.path + (size_t)g * t.path_cap;
+    const int plen = IS_ROOT ? 0 : t.path_len[g];
+    double backup_value = 0.0;
+
+    if (kind == kLeafTerminal) {
+        backup_value = (double)t.leaf_value[g];
+    } else {
+        const State s = unpack(t.leaf_state[g]);
+        const Legal L = legal_actions(s, /*fallback_forced=*/0);     // python semantics (move_generator.py:24-70)
+        const int n = legal_count(L);
+        if (n == 0) {
+            // portable_mcts.py:433-441: no legal move on a non-finished state => terminal, value -1
+            backup_value = -1.0;
+            if (lane == 0) {
+                if (IS_ROOT) { t.node_nedges[nb] = 0; t.root_terminal[g] = 1; t.root_init_value[g] = -1.f; }
+                else {
+                    const size_t e = eb + path[plen - 1];
+                    t.eInfo[e] = (uint8_t)((t.eInfo[e] & kInfoWhite) | kInfoTerminal | (0u << 2));
+                }
+            }
+        } else {
+            // gather per-lane logits / priors of the legal actions in ascending index order
+            float h1 = 0.f, h2 = 0.f, hm = 0.f;
+            const bool heads = priors220 == nullptr;
+            if (heads && lane < kCells) {
+                h1 = lp1[(size_t)g * 36 + lane]; h2 = lp2[(size_t)g * 36 + lane]; hm = lpm[(size_t)g * 36 + lane];
+            }
+            float val[4]; int slot[4]; bool lg[4];
+            int base = 0;
+            float mx = -INFINITY;
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int a = it * kWave + lane;
+                lg[it] = a < 217 && legal_bit(L, a);
+                const uint64_t bal = __ballot(lg[it]);
+                slot[it] = base + __popcll(bal & ((1ull << lane) - 1ull));
+                base += __popcll(bal);
+                int from = 0, dest = 0, cell = 0;
+                if (a >= 36 && a < 180) { from = (a - 36) >> 2; dest = move_dest(from, (a - 36) & 3); dest = dest < 0 ? 0 : (dest > 35 ? 35 : dest); }
+                else if (a >= 180 && a < 216) cell = a - 180;
+                else if (a < 36) cell = a;
+                float x;
+                if (heads) {
+                    const float p1d = __shfl(h1, dest), p2f = __shfl(h2, from), p1c = __shfl(h1, cell), pmc = __shfl(hm, cell);
+                    x = a < 36 ? p1c : a < 180 ? (p2f + p1d) : a < 216 ? pmc : 0.f;
+                } else {
+                    x = lg[it] ? priors220[(size_t)g * 220 + a] : 0.f;
+                }
+                val[it] = x;
+                if (heads && lg[it]) mx = fmaxf(mx, x);
+            }
+            if (heads) {
+                // softmax over the legal set (portable_mcts.py:381-386), fp32
+                mx = wave_max_f32(mx);
+                float sum = 0.f;
+#pragma unroll
+                for (int it = 0; it < 4; ++it) { val[it] = lg[it] ? expf(val[it] - mx) : 0.f; sum += val[it]; }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+#pragma unroll
+                for (int it = 0; it < 4; ++it) val[it] = val[it] / sum;
+            }
+            // root noise mix (portable_mcts.py:451-459), then renormalise with a sequential fp32 sum
+            if (IS_ROOT && noise != nullptr && n > 1) {
+                const float keep = (float)(1.0 - (double)epsilon);
+#pragma unroll
+                for (int it = 0; it < 4; ++it)
+                    if (lg[it]) val[it] = keep * val[it] + epsilon * noise[(size_t)g * noise_stride + slot[it]];
+            }
+#pragma unroll
+            for (int it = 0; it < 4; ++it) if (lg[it]) s_pr[w][slot[it]] = val[it];
+            __builtin_amdgcn_wave_barrier();
+            __threadfence_block();
+            float psum = 0.f;
+            if (lane == 0) { for (int k = 0; k < n; ++k) psum += s_pr[w][k]; }
+            psum = __shfl(psum, 0);
+            const bool bad = !(psum > 0.f) || !isfinite(psum);
+            // node + edge allocation (per-game bump counters, worst-case sized regions)
+            int node_id = 0, e0 = 0;
+            if (lane == 0) {
+                if (IS_ROOT) { node_id = 0; e0 = t.n_edges[g]; t.n_edges[g] = e0 + n; }
+                else {
+                    node_id = t.n_nodes[g]; t.n_nodes[g] = node_id + 1;
+                    e0 = t.n_edges[g]; t.n_edges[g] = e0 + n;
+                    t.eChild[eb + path[plen - 1]] = node_id;
+                    t.node_state[nb + node_id] = t.leaf_state[g];
+                }
+                t.node_edge_begin[nb + node_id] = e0;
+                t.node_nedges[nb + node_id] = n;
+                if (IS_ROOT) t.root_init_value[g] = values[g];
+            }
+            e0 = __shfl(e0, 0);
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                if (!lg[it]) continue;
+                const int a = it * kWave + lane;
+                State c = s;
+                int kd, p, q2, ex;
+                index_to_code(s.phase, a, kd, p, q2, ex);
+                apply(c, kd, p, q2);
+                uint8_t info = c.player < 0 ? kInfoWhite : 0;
+                if (game_status(c) != 0) {
+                    const int tv = (int)terminal_value_for_mover(c);
+                    info |= kInfoTerminal | (uint8_t)((tv + 1) << 2);
+                }
+                const size_t e = eb + e0 + slot[it];
+                t.eW[e] = 0.0;
+                t.eP[e] = bad ? (1.0f / (float)n) : (val[it] / psum);
+                t.eN[e] = 0;
+                t.eChild[e] = -1;
+                t.eAct[e] = (uint8_t)a;
+                t.eInfo[e] = info;
+            }
+            backup_value = (double)values[g];
+        }
+    }
+    if (IS_ROOT) return;
+    // ---- backup along the path (portable_mcts.py:123-138) ----
+    if (lane == 0 && plen > 0) {
+        const State root = unpack(t.node_state[nb]);
+        double v = backup_value;
+        for (int off = plen - 1; off >= 0; --off) {
+            const size_t e = eb + path[off];
+            t.eN[e] += 1;
+            t.eW[e] += v;
+            const int child_player = (t.eInfo[e] & kInfoWhite) ? -1 : 1;
+            const int parent_player = off > 0 ? ((t.eInfo[eb + path[off - 1]] & kInfoWhite) ? -1 : 1) : root.player;
+            if (parent_player != child_player) v = -v;
+        }
+        t.root_visits[g] += 1;
+        t.root_W[g] += v;
+    }
+}
+
+// ---- finish: root policy / pick -----------------------------------------------------------------------------
+// policy = softmax(log(N)/T) over visited children (T <= 1e-6: one-hot argmax) (portable_mcts.py:150-205)
+// pick   = inverse-CDF sample with the given uniform, or N -> Q -> P -> index (portable_mcts.py:208-261)
+__global__ __launch_bounds__(kBlock) void tree_finish_kernel(Tree t, const float* __restrict__ temps,
+                                                             const float* __restrict__ uniforms,
+                                                             float* __restrict__ policy_dense,
+                                                             int* __restrict__ chosen_index,
+                                                             int4* __restrict__ chosen_code,
+                                                             uint8_t* __restrict__ chosen_valid,
+                                                             uint8_t* __restrict__ terminal_out,
+                                                             float* __restrict__ root_value,
+                                                             int* __restrict__ child_count,
+                                                             int* __restrict__ child_action,
+                                                             int* __restrict__ child_visits,
+                                                             float* __restrict__ child_prior, int out_cap) {
+    const int lane = lane_id();
+    const int g = wave_game();
+    if (g >= t.B) return;
+    float* prow = policy_dense + (size_t)g * 220;
+    for (int j = lane; j < 220; j += kWave) prow[j] = 0.f;
+    const size_t nb = (size_t)g * t.node_cap, eb = (size_t)g * t.edge_cap;
+    const int ne = t.node_nedges[nb];
+    const State root = unpack(t.node_state[nb]);
+    const bool term = t.root_terminal[g] != 0 || ne <= 0;
+    if (lane == 0) {
+        terminal_out[g] = term ? 1 : 0;
+        chosen_valid[g] = term ? 0 : 1;
+        chosen_index[g] = -1;
+        chosen_code[g] = make_int4(-1, -1, -1, -1);
+        child_count[g] = term ? 0 : ne;
+        const int rv = t.root_visits[g];
+        root_value[g] = term ? (t.node_nedges[nb] == 0 && game_status(root) == 0 ? -1.f : (float)terminal_value_for_mover(root))
+                             : (rv > 0 ? (float)(t.root_W[g] / (double)rv) : t.root_init_value[g]);
+    }
+    if (term) return;
+    const int e0 = t.node_edge_begin[nb];
+    const float temp = temps[g];
+    float v[2], pr[2]; int act[2]; double q[2]; bool ok[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int k = r * kWave + lane;
+        ok[r] = k < ne;
+        const size_t e = eb + e0 + (ok[r] ? k : 0);
+        const int n = ok[r] ? t.eN[e] : 0;
+        v[r] = (float)n;
+        pr[r] = ok[r] ? t.eP[e] : 0.f;
+        act[r] = ok[r] ? (int)t.eAct[e] : 0;
+        q[r] = 0.0;
+        if (ok[r] && n > 0) {
+            const double mv = t.eW[e] / (double)n;
+            q[r] = ((t.eInfo[e] & kInfoWhite) ? -1 : 1) == root.player ? mv : -mv;
+        }
+        if (ok[r] && k < out_cap) {
+            child_action[(size_t)g * out_cap + k] = act[r];
+            child_visits[(size_t)g * out_cap + k] = n;
+            child_prior[(size_t)g * out_cap + k] = pr[r];
+        }
+    }
+    // ---- policy ----
+    float pol[2] = {0.f, 0.f};
+    float vmax = wave_max_f32(fmaxf(ok[0] ? v[0] : -1.f, ok[1] ? v[1] : -1.f));
+    if (temp <= 1e-6f) {
+        uint64_t lo = __ballot(ok[0] && v[0] == vmax);
+        int am;
+        if (lo) am = __ffsll((unsigned long long)lo) - 1;
+        else am = kWave + __ffsll((unsigned long long)__ballot(ok[1] && v[1] == vmax)) - 1;
+        pol[0] = (lane == am) ? 1.f : 0.f;
+        pol[1] = (kWave + lane == am) ? 1.f : 0.f;
+    } else {
+        const float tt = fmaxf(temp, 1e-6f);
+        float lg0 = (ok[0] && v[0] > 0.f) ? logf(v[0]) / tt : -INFINITY;
+        float lg1 = (ok[1] && v[1] > 0.f) ? logf(v[1]) / tt : -INFINITY;
+        const float mx = wave_max_f32(fmaxf(lg0, lg1));
+        float e0f = lg0 == -INFINITY ? 0.f : expf(lg0 - mx), e1f = lg1 == -INFINITY ? 0.f : expf(lg1 - mx);
+        float sum = e0f + e1f;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+        pol[0] = e0f / sum; pol[1] = e1f / sum;
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r) if (ok[r]) prow[act[r]] = pol[r];
+    // ---- pick ----
+    int pick = -1;
+    if (uniforms != nullptr) {
+        const float target = uniforms[g];
+        float run = 0.f;
+        int last = -1;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            float incl = pol[r];
+#pragma unroll
+            for (int o = 1; o < kWave; o <<= 1) { const float tt = __shfl_up(incl, o); if (lane >= o) incl += tt; }
+            const uint64_t hb = __ballot(ok[r] && pol[r] > 0.f && run + incl > target);
+            if (pick < 0 && hb) pick = r * kWave + __ffsll((unsigned long long)hb) - 1;
+            const uint64_t vb = __ballot(ok[r] && pol[r] > 0.f);
+            if (vb) last = r * kWave + 63 - __clzll((unsigned long long)vb);
+            run += __shfl(incl, kWave - 1);
+        }
+        if (pick < 0) pick = last;
+    } else {
+        // most visits, then Q (atol 1e-6), then prior (atol 1e-8), then lowest index
+        bool c0 = ok[0] && v[0] == vmax, c1 = ok[1] && v[1] == vmax;
+        float qf0 = (float)q[0], qf1 = (float)q[1];
+        const float qmax = wave_max_f32(fmaxf(c0 ? qf0 : -INFINITY, c1 ? qf1 : -INFINITY));
+        c0 = c0 && fabsf(qf0 - qmax) <= 1e-6f; c1 = c1 && fabsf(qf1 - qmax) <= 1e-6f;
+        const float pmax = wave_max_f32(fmaxf(c0 ? pr[0] : -INFINITY, c1 ? pr[1] : -INFINITY));
+        c0 = c0 && fabsf(pr[0] - pmax) <= 1e-8f; c1 = c1 && fabsf(pr[1] - pmax) <= 1e-8f;
+        const uint64_t lo = __ballot(c0);
+        if (lo) pick = __ffsll((unsigned long long)lo) - 1;
+        else { const uint64_t hi = __ballot(c1); if (hi) pick = kWave + __ffsll((unsigned long long)hi) - 1; }
+    }
+    if (pick >= 0 && lane == (pick & 63)) {
+        const int r = pick >> 6;
+        const int a = r == 0 ? act[0] : act[1];
+        int kd, p, q2, ex;
+        index_to_code(root.phase, a, kd, p, q2, ex);
+        chosen_index[g] = a;
+        chosen_code[g] = make_int4(kd, p, q2, ex);
+    }
+}
+
+inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+inline int st() { return hipGetLastError() == hipSuccess ? LZ_OK : LZ_ERR_LAUNCH; }
+
+Tree make_tree(const LzTreeDesc* d) {
+    Tree t;
+    t.B = (int)d->num_games; t.node_cap = d->node_cap; t.edge_cap = d->edge_cap; t.path_cap = d->path_cap;
+    t.root_state = reinterpret_cast<const Packed*>(d->root_state);
+    t.node_state = reinterpret_cast<Packed*>(d->node_state);
+    t.node_edge_begin = d->node_edge_begin; t.node_nedges = d->node_nedges;
+    t.eW = d->edge_w; t.eP = d->edge_p; t.eN = d->edge_n; t.eChild = d->edge_child; t.eAct = d->edge_action;
+    t.eInfo = d->edge_info;
+    t.n_nodes = d->n_nodes; t.n_edges = d->n_edges; t.root_visits = d->root_visits; t.root_W = d->root_w;
+    t.root_init_value = d->root_init_value;
+    t.path = d->path; t.path_len = d->path_len; t.leaf_kind = d->leaf_kind;
+    t.leaf_state = reinterpret_cast<Packed*>(d->leaf_state); t.leaf_value = d->leaf_value;
+    t.root_terminal = d->root_terminal; t.active = d->active;
+    t.c_puct = d->exploration_weight;
+    return t;
+}
+bool tree_ok(const LzTreeDesc* d) {
+    return d && d->num_games >= 0 && d->node_cap >= 2 && d->edge_cap >= kMaxChildren && d->path_cap >= 3 &&
+           d->root_state && d->node_state && d->node_edge_begin && d->node_nedges && d->edge_w && d->edge_p &&
+           d->edge_n && d->edge_child && d->edge_action && d->edge_info && d->n_nodes && d->n_edges &&
+           d->root_visits && d->root_w && d->root_init_value && d->path && d->path_len && d->leaf_kind &&
+           d->leaf_state && d->leaf_value && d->root_terminal;
+}
+inline unsigned gw(int64_t n) { return (unsigned)((n + kWavesPerBlock - 1) / kWavesPerBlock); }
+inline unsigned gt(int64_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
+
+}  // namespace
+
+extern "C" {
+
+int lz_pack_states(const LzStateSoA* s, int64_t B, void* packed_out, void* stream) {
+    if (B < 0) return LZ_ERR_ARG;
+    if (B == 0) return LZ_OK;
+    if (!s || !s->board || !s->marks_black || !s->marks_white || !s->phase || !s->current_player ||
+        !s->pending_marks_required || !s->pending_marks_remaining || !s->pending_captures_required ||
+        !s->pending_captures_remaining || !s->forced_removals_done || !s->move_count || !s->moves_since_capture ||
+        !packed_out)
+        return LZ_ERR_ARG;
+    hipLaunchKernelGGL(pack_states_kernel, dim3(gt(B)), dim3(kBlock), 0, as_stream(stream), *s, B,
+                       reinterpret_cast<Packed*>(packed_out));
+    return st();
+}
+
+int lz_packed_to_model_input(const void* packed, int64_t B, float* out, void* stream) {
+    if (B < 0) return LZ_ERR_ARG;
+    if (B == 0) return LZ_OK;
+    if (!packed || !out) return LZ_ERR_ARG;
+    hipLaunchKernelGGL(packed_planes_kernel, dim3(gw(B)), dim3(kBlock), 0, as_stream(stream),
+                       reinterpret_cast<const Packed*>(packed), B, out);
+    return st();
+}
+
+int lz_tree_begin(const LzTreeDesc* d, void* stream) {
+    if (!tree_ok(d)) return LZ_ERR_ARG;
+    if (d->num_games == 0) return LZ_OK;
+    hipLaunchKernelGGL(tree_begin_kernel, dim3(gt(d->num_games)), dim3(kBlock), 0, as_stream(stream), make_tree(d));
+    return st();
+}
+
+int lz_tree_select(const LzTreeDesc* d, void* stream) {
+    if (!tree_ok(d)) return LZ_ERR_ARG;
+    if (d->num_games == 0) return LZ_OK;
+    hipLaunchKernelGGL(tree_select_kernel, dim3(gw(d->num_games)), dim3(kBlock), 0, as_stream(stream), make_tree(d));
+    return st();
+}
+
+int lz_tree_expand(const LzTreeDesc* d, int is_root, const float* lp1, const float* lp2, const float* lpmc,
+                   const float* priors220, const float* values, const float* noise, int64_t noise_stride,
+                   float epsilon, void* stream) {
+    if (!tree_ok(d) || !values) return LZ_ERR_ARG;
+    if (!priors220 && (!lp1 || !lp2 || !lpmc)) return LZ_ERR_ARG;
+    if (d->num_games == 0) return LZ_OK;
+    const Tree t = make_tree(d);
+    if (is_root)
+        hipLaunchKernelGGL(tree_expand_kernel<true>, dim3(gw(t.B)), dim3(kBlock), 0, as_stream(stream), t, lp1, lp2,
+                           lpmc, priors220, values, noise, (int)noise_stride, epsilon);
+    else
+        hipLaunchKernelGGL(tree_expand_kernel<false>, dim3(gw(t.B)), dim3(kBlock), 0, as_stream(stream), t, lp1, lp2,
+                           lpmc, priors220, values, nullptr, 0, 0.f);
+    return st();
+}
+
+int lz_tree_finish(const LzTreeDesc* d, const float* temperatures, const float* uniforms, float* policy_dense,
+                   int32_t* chosen_index, int32_t* chosen_code, uint8_t* chosen_valid, uint8_t* terminal_mask,
+                   float* root_value, int32_t* child_count, int32_t* child_action, int32_t* child_visits,
+                   float* child_prior, int64_t out_cap, void* stream) {
+    if (!tree_ok(d) || !temperatures || !policy_dense || !chosen_index || !chosen_code || !chosen_valid ||
+        !terminal_mask || !root_value || !child_count || !child_action || !child_visits || !child_prior || out_cap < 1)
+        return LZ_ERR_ARG;
+    if (d->num_games == 0) return LZ_OK;
+    hipLaunchKernelGGL(tree_finish_kernel, dim3(gw(d->num_games)), dim3(kBlock), 0, as_stream(stream), make_tree(d),
+                       temperatures, uniforms, policy_dense, chosen_index, reinterpret_cast<int4*>(chosen_code),
+                       chosen_valid, terminal_mask, root_value, child_count, child_action, child_visits, child_prior,
+                       (int)out_cap);
+    return st();
+}
+
+// Whole search of one move, enqueued from C++ (no Python in the simulation loop, hipGraph-capturable):
+//   begin -> [planes -> net -> expand_root] -> sims x [select -> planes -> net -> expand+backup]
+int lz_tree_search(const LzTreeDesc* d, const LzNetDesc* net, int64_t sims, float* planes, float* lp1, float* lp2,
+                   float* lpmc, float* values, const float* noise, int64_t noise_stride, float epsilon,
+                   void* stream) {
+    if (!tree_ok(d) || !net || sims < 0 || !planes || !lp1 || !lp2 || !lpmc || !values) return LZ_ERR_ARG;
+    const int64_t B = d->num_games;
+    if (B == 0) return LZ_OK;
+    int rc = lz_tree_begin(d, stream);
+    if (rc) return rc;
+    for (int64_t s = 0; s <= sims; ++s) {
+        if (s > 0) { rc = lz_tree_select(d, stream); if (rc) return rc; }
+        rc = lz_packed_to_model_input(d->leaf_state, B, planes, stream);
+        if (rc) return rc;
+        rc = lz_net_forward_f16(net, planes, B, lp1, lp2, lpmc, nullptr, values, stream);
+        if (rc) return rc;
+        rc = lz_tree_expand(d, s == 0 ? 1 : 0, lp1, lp2, lpmc, nullptr, values, s == 0 ? noise : nullptr, noise_stride,
+                            epsilon, stream);
+        if (rc) return rc;
+    }
+    return LZ_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,296 @@
+"""Device-resident full-tree PUCT search (variant P) -- host side.
+
+`TreeEngine` owns the HBM arenas of B concurrent search trees (csrc/lz_engine.hip) and exposes the same
+split-phase protocol as the reference's C++ tree batch (`v1/python/portable_cpp_mcts.py:270-282`:
+prepare roots -> evaluate -> complete, then sims x (select -> evaluate -> complete)), plus
+`search()` which enqueues a whole move's search from C++ with the fused network kernel in the loop.
+
+`PortableTreeMCTS.search_batch(state, ...)` gives it the `V1RootMCTS`-style interface (same
+`RootSearchBatchOutput`), `self_play_tree_gpu` is the tree-search twin of `self_play_v1_gpu`, and
+`SteadyStateTreeSelfPlay` is the fixed-population driver used by bench.py.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import time
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from . import _lib as L
+from . import v0_core
+from .mcts_gpu import GpuStateBatch, RootSearchBatchOutput, TOTAL_ACTION_DIM, states_to_model_input, \
+    encode_actions_fast
+from .net_hip import FusedNet, LzNetDesc
+from .self_play_types import SelfPlayV1Stats
+from .trajectory_buffer import TensorSelfPlayBatch, TensorTrajectoryBuffer
+
+MAX_CHILDREN = 72
+OUT_CAP = 80
+
+
+class LzTreeDesc(C.Structure):
+    _fields_ = [("num_games", C.c_int64), ("node_cap", C.c_int32), ("edge_cap", C.c_int32), ("path_cap", C.c_int32),
+                ("reserved", C.c_int32), ("exploration_weight", C.c_double)] + \
+               [(n, C.c_void_p) for n in (
+                   "root_state", "node_state", "node_edge_begin", "node_nedges", "edge_w", "edge_p", "edge_n",
+                   "edge_child", "edge_action", "edge_info", "n_nodes", "n_edges", "root_visits", "root_w",
+                   "root_init_value", "path", "path_len", "leaf_kind", "leaf_state", "leaf_value", "root_terminal",
+                   "active")]
+
+
+class TreeEngine:
+    def __init__(self, num_games: int, max_sims: int, device, exploration_weight: float = 1.0) -> None:
+        dev = torch.device(device)
+        if dev.type != "cuda":
+            raise RuntimeError("TreeEngine needs a HIP device (no CPU path)")
+        self.device, self.B, self.max_sims = dev, int(num_games), int(max_sims)
+        B = self.B
+        self.node_cap = self.max_sims + 2
+        self.edge_cap = (self.max_sims + 1) * MAX_CHILDREN
+        self.path_cap = self.max_sims + 3
+        z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)
+        self.buf: Dict[str, torch.Tensor] = {
+            "root_state": z((B, 4), torch.int64), "node_state": z((B * self.node_cap, 4), torch.int64),
+            "node_edge_begin": z((B * self.node_cap,), torch.int32), "node_nedges": z((B * self.node_cap,), torch.int32),
+            "edge_w": z((B * self.edge_cap,), torch.float64), "edge_p": z((B * self.edge_cap,), torch.float32),
+            "edge_n": z((B * self.edge_cap,), torch.int32), "edge_child": z((B * self.edge_cap,), torch.int32),
+            "edge_action": z((B * self.edge_cap,), torch.uint8), "edge_info": z((B * self.edge_cap,), torch.uint8),
+            "n_nodes": z((B,), torch.int32), "n_edges": z((B,), torch.int32), "root_visits": z((B,), torch.int32),
+            "root_w": z((B,), torch.float64), "root_init_value": z((B,), torch.float32),
+            "path": z((B * self.path_cap,), torch.int32), "path_len": z((B,), torch.int32),
+            "leaf_kind": z((B,), torch.int32), "leaf_state": z((B, 4), torch.int64), "leaf_value": z((B,), torch.float32),
+            "root_terminal": z((B,), torch.uint8), "active": torch.ones((B,), dtype=torch.uint8, device=dev),
+        }
+        d = LzTreeDesc()
+        d.num_games, d.node_cap, d.edge_cap, d.path_cap = B, self.node_cap, self.edge_cap, self.path_cap
+        d.exploration_weight = float(exploration_weight)
+        for name, t in self.buf.items():
+            setattr(d, name, t.data_ptr())
+        self.desc = d
+        # evaluator scratch (fused network inputs / outputs)
+        self.planes = z((B, 11, 6, 6), torch.float32)
+        self.lp1, self.lp2, self.lpm = (z((B, 36), torch.float32) for _ in range(3))
+        self.values = z((B,), torch.float32)
+        # finish outputs
+        self.policy_dense = z((B, TOTAL_ACTION_DIM), torch.float32)
+        self.chosen_index = z((B,), torch.int32)
+        self.chosen_code = z((B, 4), torch.int32)
+        self.chosen_valid = z((B,), torch.bool)
+        self.terminal_mask = z((B,), torch.bool)
+        self.root_value = z((B,), torch.float32)
+        self.child_count = z((B,), torch.int32)
+        self.child_action = z((B, OUT_CAP), torch.int32)
+        self.child_visits = z((B, OUT_CAP), torch.int32)
+        self.child_prior = z((B, OUT_CAP), torch.float32)
+
+    def hbm_bytes(self) -> int:
+        return sum(t.numel() * t.element_size() for t in self.buf.values())
+
+    def _stream(self):
+        return L.stream_ptr(self.device)
+
+    # ---- state plumbing ----
+    def set_roots(self, state: GpuStateBatch, active: Optional[torch.Tensor] = None) -> None:
+        ts = [t if t.is_contiguous() else t.contiguous() for t in state.tensors()]
+        s = L.soa(ts)
+        with torch.cuda.device(self.device):
+            L.check(L.lib().lz_pack_states(C.byref(s), L.i64(self.B), L.ptr(self.buf["root_state"]), self._stream()),
+                    "pack_states")
+        if active is not None:
+            self.buf["active"].copy_(active.to(torch.uint8))
+        else:
+            self.buf["active"].fill_(1)
+
+    def begin(self) -> None:
+        with torch.cuda.device(self.device):
+            L.check(L.lib().lz_tree_begin(C.byref(self.desc), self._stream()), "tree_begin")
+
+    def select(self) -> None:
+        with torch.cuda.device(self.device):
+            L.check(L.lib().lz_tree_select(C.byref(self.desc), self._stream()), "tree_select")
+
+    def leaf_planes(self) -> torch.Tensor:
+        with torch.cuda.device(self.device):
+            L.check(L.lib().lz_packed_to_model_input(L.ptr(self.buf["leaf_state"]), L.i64(self.B), L.ptr(self.planes),
+                                                     self._stream()), "packed_to_model_input")
+        return self.planes
+
+    def expand(self, *, is_root: bool, values: torch.Tensor, heads=None, priors220: Optional[torch.Tensor] = None,
+               noise: Optional[torch.Tensor] = None, epsilon: float = 0.25) -> None:
+        lp1 = lp2 = lpm = None
+        if priors220 is None:
+            lp1, lp2, lpm = heads
+        nz_stride = int(noise.shape[1]) if noise is not None else 0
+        with torch.cuda.device(self.device):
+            L.check(L.lib().lz_tree_expand(C.byref(self.desc), C.c_int(1 if is_root else 0), L.ptr(lp1), L.ptr(lp2),
+                                           L.ptr(lpm), L.ptr(priors220), L.ptr(values), L.ptr(noise), L.i64(nz_stride),
+                                           C.c_float(float(epsilon)), self._stream()), "tree_expand")
+
+    def finish(self, temperatures: torch.Tensor, uniforms: Optional[torch.Tensor]) -> None:
+        with torch.cuda.device(self.device):
+            L.check(L.lib().lz_tree_finish(C.byref(self.desc), L.ptr(temperatures), L.ptr(uniforms),
+                                           L.ptr(self.policy_dense), L.ptr(self.chosen_index), L.ptr(self.chosen_code),
+                                           L.ptr(self.chosen_valid), L.ptr(self.terminal_mask), L.ptr(self.root_value),
+                                           L.ptr(self.child_count), L.ptr(self.child_action), L.ptr(self.child_visits),
+                                           L.ptr(self.child_prior), L.i64(OUT_CAP), self._stream()), "tree_finish")
+
+    def search(self, net: FusedNet, sims: int, noise: Optional[torch.Tensor] = None, epsilon: float = 0.25) -> None:
+        """Whole search of one move (C++ loop: begin, root, sims x select/eval/expand)."""
+        if int(sims) > self.max_sims:
+            raise ValueError(f"sims={sims} exceeds the arena capacity max_sims={self.max_sims}")
+        nz_stride = int(noise.shape[1]) if noise is not None else 0
+        with torch.cuda.device(self.device):
+            L.check(L.lib().lz_tree_search(C.byref(self.desc), C.byref(net.desc), L.i64(sims), L.ptr(self.planes),
+                                           L.ptr(self.lp1), L.ptr(self.lp2), L.ptr(self.lpm), L.ptr(self.values),
+                                           L.ptr(noise), L.i64(nz_stride), C.c_float(float(epsilon)), self._stream()),
+                    "tree_search")
+
+
+def dirichlet_noise(shape, alpha: float, device, generator=None) -> torch.Tensor:
+    """Gamma(alpha) draws; the expand kernel mixes them with weight epsilon and renormalises the priors
+    (the same distribution as Dirichlet noise after normalisation over the legal children)."""
+    a = torch.full(shape, float(alpha), dtype=torch.float32, device=device)
+    g = torch._standard_gamma(a) if generator is None else torch._standard_gamma(a, generator=generator)
+    return g
+
+
+class PortableTreeMCTS:
+    """Full-tree search with the V1RootMCTS calling convention (search_batch -> RootSearchBatchOutput)."""
+
+    def __init__(self, net: FusedNet, num_games: int, num_simulations: int, device, exploration_weight: float = 1.0,
+                 add_dirichlet_noise: bool = True, dirichlet_alpha: float = 0.3, dirichlet_epsilon: float = 0.25,
+                 sample_moves: bool = True) -> None:
+        self.net, self.sims = net, int(num_simulations)
+        self.engine = TreeEngine(num_games, num_simulations, device, exploration_weight)
+        self.add_noise, self.alpha, self.eps = bool(add_dirichlet_noise), float(dirichlet_alpha), float(dirichlet_epsilon)
+        self.sample_moves = bool(sample_moves)
+        self.leaf_evals = 0
+
+    def search_batch(self, state: GpuStateBatch, *, temperatures: torch.Tensor, active: Optional[torch.Tensor] = None,
+                     add_dirichlet_noise: Optional[bool] = None) -> RootSearchBatchOutput:
+        e = self.engine
+        dev = e.device
+        add_noise = self.add_noise if add_dirichlet_noise is None else bool(add_dirichlet_noise)
+        e.set_roots(state, active)
+        noise = dirichlet_noise((e.B, OUT_CAP), self.alpha, dev) if add_noise else None
+        e.search(self.net, self.sims, noise, self.eps)
+        self.leaf_evals += e.B * (self.sims + 1)
+        uniforms = torch.rand((e.B,), dtype=torch.float32, device=dev) if self.sample_moves else None
+        e.finish(temperatures.to(torch.float32).contiguous(), uniforms)
+        model_input = states_to_model_input(state)
+        legal_mask, _ = encode_actions_fast(state)
+        return RootSearchBatchOutput(
+            model_input=model_input, legal_mask=legal_mask, policy_dense=e.policy_dense, root_value=e.root_value,
+            terminal_mask=e.terminal_mask, chosen_action_indices=e.chosen_index.to(torch.int64),
+            chosen_action_codes=e.chosen_code, chosen_valid_mask=e.chosen_valid)
+
+
+class SteadyStateTreeSelfPlay:
+    """B games, always full (finished games are re-seated); one step = one searched move for every game."""
+
+    def __init__(self, model, num_games: int, sims: int, device, dtype: str = "float16", seed: int = 12345,
+                 temperature_init: float = 1.0, temperature_final: float = 0.1, temperature_threshold: int = 10,
+                 max_game_plies: int = 512, exploration_weight: float = 1.0) -> None:
+        from .steady_state import SteadyStateRootSelfPlay
+        from .mcts_gpu import V1RootMCTSConfig
+        dev = torch.device(device)
+        self.net = model if isinstance(model, FusedNet) else FusedNet(model, dev)
+        self.dev, self.B, self.sims = dev, int(num_games), int(sims)
+        # reuse the population bookkeeping (states, plies, trajectory arena, preroll, reset)
+        self.pop = SteadyStateRootSelfPlay(self.net, num_games, V1RootMCTSConfig(num_simulations=1), dev, seed=seed,
+                                           temperature_init=temperature_init, temperature_final=temperature_final,
+                                           temperature_threshold=temperature_threshold, max_game_plies=max_game_plies)
+        self.mcts = PortableTreeMCTS(self.net, num_games, sims, dev, exploration_weight)
+        self.positions = 0
+        self._nn_events = []
+
+    @property
+    def leaf_evals(self) -> int:
+        return self.mcts.leaf_evals
+
+    def preroll(self, n: int = 120) -> None:
+        self.pop.preroll(n)
+
+    def step(self) -> None:
+        p = self.pop
+        temps = torch.where(p.plies < p.t_thr, p.t_init, p.t_final).to(torch.float32)
+        search = self.mcts.search_batch(p.states, temperatures=temps)
+        rows = p.buffer.append_steps(search.model_input, search.legal_mask, search.policy_dense, p.states.current_player)
+        p.step_index[p.all_idx, p.step_counts] = rows
+        p.step_counts.add_(p.ones)
+        fin, result, soft = v0_core.self_play_step_inplace(*p.states.tensors(), p.plies, p.done, p.all_idx,
+                                                           search.chosen_action_codes, search.terminal_mask,
+                                                           search.chosen_valid_mask, p.max_plies, 2.0)
+        self.positions += self.B
+        if int(fin.numel()) > 0:
+            _, _, out = p.buffer.finalize_games_inplace(step_index_matrix=p.step_index, step_counts=p.step_counts,
+                                                        slots=fin, result_from_black=result, soft_value_from_black=soft)
+            p.outcome.add_(out)
+            p.games_finished += int(fin.numel())
+            p._reset_slots(fin)
+
+
+def self_play_tree_gpu(model, num_games: int, mcts_simulations: int, temperature_init: float, temperature_final: float,
+                       temperature_threshold: int, exploration_weight: float, device: str,
+                       add_dirichlet_noise: bool = True, dirichlet_alpha: float = 0.3, dirichlet_epsilon: float = 0.25,
+                       soft_value_k: float = 2.0, max_game_plies: int = 512, sample_moves: bool = True,
+                       concurrent_games: int = 8, verbose: bool = False) -> Tuple[TensorSelfPlayBatch, SelfPlayV1Stats]:
+    """Tree-search twin of self_play_v1_gpu (same outputs); mirrors v1/python/portable_self_play.py:82-284."""
+    dev = torch.device(device)
+    net = model if isinstance(model, FusedNet) else FusedNet(model, dev)
+    wave = max(1, min(int(concurrent_games), int(num_games)))
+    mcts = PortableTreeMCTS(net, wave, mcts_simulations, dev, exploration_weight, add_dirichlet_noise, dirichlet_alpha,
+                            dirichlet_epsilon, sample_moves)
+    buffer = TensorTrajectoryBuffer(dev, TOTAL_ACTION_DIM, max_steps_hint=max_game_plies, concurrent_games_hint=wave)
+    outcome = torch.zeros((3,), dtype=torch.int64, device=dev)
+    lengths = torch.zeros((int(num_games),), dtype=torch.int64, device=dev)
+    started = time.perf_counter()
+    for base in range(0, int(num_games), wave):
+        g = min(wave, int(num_games) - base)
+        states = GpuStateBatch.initial(dev, wave)
+        step_index = torch.full((wave, max_game_plies), -1, dtype=torch.int64, device=dev)
+        step_counts = torch.zeros((wave,), dtype=torch.int64, device=dev)
+        plies = torch.zeros((wave,), dtype=torch.int64, device=dev)
+        done = torch.zeros((wave,), dtype=torch.bool, device=dev)
+        if g < wave:
+            done[g:] = True
+        while True:
+            active = torch.nonzero(~done).view(-1)
+            if int(active.numel()) == 0:
+                break
+            temps = torch.where(plies < int(temperature_threshold), float(temperature_init),
+                                float(temperature_final)).to(torch.float32)
+            out = mcts.search_batch(states, temperatures=temps, active=~done)
+            rows = buffer.append_steps(out.model_input.index_select(0, active), out.legal_mask.index_select(0, active),
+                                       out.policy_dense.index_select(0, active),
+                                       states.current_player.index_select(0, active))
+            step_index[active, step_counts.index_select(0, active)] = rows
+            step_counts.index_add_(0, active, torch.ones_like(active))
+            fin, result, _ = v0_core.self_play_step_inplace(
+                *states.tensors(), plies, done, active, out.chosen_action_codes.index_select(0, active),
+                out.terminal_mask.index_select(0, active), out.chosen_valid_mask.index_select(0, active),
+                int(max_game_plies), float(soft_value_k))
+            if int(fin.numel()) > 0:
+                boards = states.board.index_select(0, fin)
+                delta = (boards.eq(1).sum(dim=(1, 2)) - boards.eq(-1).sum(dim=(1, 2))).to(torch.float32)
+                soft = torch.tanh(delta / 18.0 * float(soft_value_k))
+                f_slots, f_len, f_out = buffer.finalize_games_inplace(
+                    step_index_matrix=step_index, step_counts=step_counts, slots=fin, result_from_black=result,
+                    soft_value_from_black=soft)
+                if int(f_slots.numel()) > 0:
+                    lengths.index_copy_(0, f_slots + base, f_len)
+                outcome.add_(f_out)
+    torch.cuda.synchronize(dev)
+    elapsed = max(1e-9, time.perf_counter() - started)
+    batch = buffer.build()
+    o = outcome.tolist()
+    keys = ("root_puct_ms", "pack_writeback_ms", "self_play_step_ms", "finalize_ms")
+    stats = SelfPlayV1Stats(
+        num_games=num_games, num_positions=batch.num_samples, black_wins=int(o[0]), white_wins=int(o[1]), draws=int(o[2]),
+        avg_game_length=float(lengths.to(torch.float32).mean().item()), elapsed_sec=elapsed,
+        positions_per_sec=float(batch.num_samples / elapsed), games_per_sec=float(num_games / elapsed),
+        step_timing_ms={k: 0.0 for k in keys}, step_timing_ratio={k: 0.0 for k in keys},
+        step_timing_calls={k: 0 for k in keys}, mcts_counters={"leaf_eval_count": int(mcts.leaf_evals)},
+        piece_delta_buckets={}, device=str(dev))
+    return batch, stats

@@ -1,0 +1,147 @@
+"""Shared helpers for the tree-engine parity tests (GPU engine vs oracle/lz_oracle.c)."""
+import numpy as np
+import torch
+
+from oracle import lz_oracle as O
+from tests.golden_utils import FIELDS
+
+FULL = (1 << 36) - 1
+
+
+def unpack_packed(packed: np.ndarray):
+    """int64[B,4] packed records (liuzhou_amd/csrc/lz_rules.h:pack) -> state dict of numpy arrays."""
+    p = packed.astype(np.uint64)
+    B = p.shape[0]
+    w0, w1, w2, w3 = p[:, 0], p[:, 1], p[:, 2], p[:, 3]
+    bits = lambda w: ((w[:, None] >> np.arange(36, dtype=np.uint64)[None, :]) & np.uint64(1)).astype(np.int64)
+    black, white = bits(w0), bits(w1)
+    st = O.empty_states(B)
+    st["board"] = (black - white).astype(np.int8).reshape(B, 6, 6)
+    st["marks_black"] = bits(w2).astype(bool).reshape(B, 6, 6)
+    st["marks_white"] = bits(w3).astype(bool).reshape(B, 6, 6)
+    f = lambda sh, m: ((w0 >> np.uint64(sh)) & np.uint64(m)).astype(np.int64)
+    st["move_count"] = f(36, 0xFF); st["moves_since_capture"] = f(44, 0x3F); st["phase"] = f(50, 7)
+    st["current_player"] = np.where(f(53, 1) == 1, -1, 1).astype(np.int64)
+    st["forced_removals_done"] = f(54, 3); st["pending_marks_required"] = f(56, 3)
+    st["pending_marks_remaining"] = f(58, 3); st["pending_captures_required"] = f(60, 3)
+    st["pending_captures_remaining"] = f(62, 3)
+    return st
+
+
+def hash_evaluator(states):
+    """Deterministic pseudo-network: priors220 (strictly positive on every index) + value in (-1,1),
+    a pure function of the state bytes -> bit-identical on both sides."""
+    B = states["board"].shape[0]
+    key = np.zeros(B, np.uint64)
+    flat = np.concatenate([np.asarray(states["board"]).reshape(B, 36).astype(np.int64) + 1,
+                           np.asarray(states["marks_black"]).reshape(B, 36).astype(np.int64),
+                           np.asarray(states["marks_white"]).reshape(B, 36).astype(np.int64),
+                           np.stack([np.asarray(states[f]).astype(np.int64) for f in FIELDS[3:]], axis=1) + 2], axis=1)
+    for j in range(flat.shape[1]):
+        key = (key * np.uint64(6364136223846793005) + flat[:, j].astype(np.uint64) + np.uint64(1442695040888963407))
+    a = np.arange(220, dtype=np.uint64)[None, :]
+    h = (key[:, None] ^ (a * np.uint64(0x9E3779B97F4A7C15)))
+    h = (h ^ (h >> np.uint64(31))) * np.uint64(0xBF58476D1CE4E5B9)
+    h = h ^ (h >> np.uint64(29))
+    pri = ((h >> np.uint64(40)).astype(np.float64) / float(1 << 24) + 0.01).astype(np.float32)
+    pri = (pri / pri.sum(1, keepdims=True, dtype=np.float32)).astype(np.float32)
+    hv = (key ^ (key >> np.uint64(33))) * np.uint64(0xFF51AFD7ED558CCD)
+    val = (((hv >> np.uint64(40)).astype(np.float64) / float(1 << 24)) * 1.8 - 0.9).astype(np.float32)
+    return pri, val
+
+
+def to_gpu_batch(st, device):
+    from liuzhou_amd.mcts_gpu import GpuStateBatch
+    ts = []
+    for f in FIELDS:
+        a = np.ascontiguousarray(st[f])
+        dt = np.int8 if f == "board" else (bool if f.startswith("marks") else np.int64)
+        ts.append(torch.from_numpy(a.astype(dt)).to(device))
+    return GpuStateBatch(*ts)
+
+
+def engine_visits(engine):
+    cnt = engine.child_count.cpu().numpy()
+    act = engine.child_action.cpu().numpy(); vis = engine.child_visits.cpu().numpy(); pri = engine.child_prior.cpu().numpy()
+    out_v = np.zeros((engine.B, 220), np.int32); out_p = np.zeros((engine.B, 220), np.float32)
+    for g in range(engine.B):
+        k = int(cnt[g])
+        out_v[g, act[g, :k]] = vis[g, :k]; out_p[g, act[g, :k]] = pri[g, :k]
+    return out_v, out_p
+
+
+def run_injected_parity(device, num_games=64, sims=64, seed=0, states=None, c=1.0, noise=None, eps=0.25,
+                        temperature=1.0):
+    """GPU tree engine vs oracle tree, both driven by `hash_evaluator`; returns the engine for inspection.
+    Asserts bit-exact visit counts, priors, picks, and close policy / root value."""
+    from liuzhou_amd.tree_engine import TreeEngine
+    from tests.golden_utils import load, states as gstates
+    if states is None:
+        z = load("g1_rules.npz")
+        st_all = gstates(z, "s")
+        rng = np.random.default_rng(seed)
+        idx = rng.integers(0, st_all["board"].shape[0], num_games)
+        states = {f: np.ascontiguousarray(np.asarray(st_all[f])[idx]) for f in FIELDS}
+    B = states["board"].shape[0]
+    eng = TreeEngine(B, sims, device, c)
+    eng.set_roots(to_gpu_batch(states, device))
+    eng.begin()
+    trees = [O.OracleTree(O.state_from_batch(states, i), c) for i in range(B)]
+    nz_dev = None if noise is None else torch.from_numpy(noise.astype(np.float32)).to(device)
+
+    def complete(is_root):
+        kind = eng.buf["leaf_kind"].cpu().numpy()
+        leaf = unpack_packed(eng.buf["leaf_state"].cpu().numpy())
+        pend = [t.prepare_root() if is_root else t.select() for t in trees]
+        want_kind = np.array([1 if p else 0 for p in pend])
+        got_kind = (kind == 1).astype(int)
+        assert np.array_equal(got_kind, want_kind), "GPU and oracle disagree on which games need an evaluation"
+        need = np.nonzero(want_kind)[0]
+        if need.size:
+            o_states = O.batch_from_states([trees[i].pending_state() for i in need])
+            for f in FIELDS:
+                a = np.asarray(leaf[f])[need].reshape(need.size, -1).astype(np.int64)
+                b = np.asarray(o_states[f]).reshape(need.size, -1).astype(np.int64)
+                assert np.array_equal(a, b), f"leaf state field {f} differs"
+        pri, val = hash_evaluator(leaf)
+        for k, i in enumerate(need):
+            nz = None
+            if is_root and noise is not None:
+                nz = noise[i]
+            trees[i].complete(pri[i], float(val[i]), nz, eps)
+        eng.expand(is_root=is_root, values=torch.from_numpy(val).to(device),
+                   priors220=torch.from_numpy(pri).to(device), noise=nz_dev if is_root else None, epsilon=eps)
+
+    complete(True)
+    for _ in range(sims):
+        eng.select()
+        complete(False)
+    temps = torch.full((B,), float(temperature), dtype=torch.float32, device=device)
+    eng.finish(temps, None)
+    got_v, got_p = engine_visits(eng)
+    chosen = eng.chosen_index.cpu().numpy()
+    pol = eng.policy_dense.cpu().numpy()
+    rv = eng.root_value.cpu().numpy()
+    term = eng.terminal_mask.cpu().numpy()
+    for i, t in enumerate(trees):
+        if t.root_terminal():
+            assert term[i], i
+            continue
+        idx, vis, vs, pr, pl = t.root_children()
+        want = np.zeros(220, np.int32); want[idx] = vis
+        assert np.array_equal(got_v[i], want), (i, np.abs(got_v[i] - want).sum())
+        wp = np.zeros(220, np.float32); wp[idx] = pr
+        assert np.array_equal(got_p[i], wp), i
+        assert int(vis.sum()) == sims
+        p = np.zeros(220, np.float32); p[idx] = O.policy_from_visits(vis, temperature)
+        np.testing.assert_allclose(pol[i], p, atol=1e-6, rtol=0)
+        want_rv = t.root_value_sum() / max(1, t.root_visits())
+        assert abs(float(rv[i]) - want_rv) < 1e-6
+        # deterministic pick: most visits -> Q -> prior -> lowest index
+        rp = t.root_player()
+        q = np.where(vis > 0, np.where(pl == rp, vs, -vs) / np.maximum(vis, 1), 0.0).astype(np.float32)
+        cand = np.nonzero(vis == vis.max())[0]
+        cand = cand[np.abs(q[cand] - q[cand].max()) <= 1e-6]
+        cand = cand[np.abs(pr[cand] - pr[cand].max()) <= 1e-8]
+        assert int(chosen[i]) == int(idx[cand.min()]), i
+    return eng
