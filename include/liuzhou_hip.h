@@ -176,6 +176,7 @@ typedef struct LzNetDesc {
     const void* wfrag;           /* device, fp16 */
     const float* fparams;        /* device, fp32 */
     int32_t layer_offsets[32];
+    int32_t head_frag_offsets[4]; /* halfs: gpool_linear [64x192], fc1 [128x192], fc2 [112x128], out convs [16x64] */
     int32_t off_stem_bias, off_block0 /* a1|b1|bias1 per block, 3*C floats each */, off_trunk_a, off_trunk_b,
             off_head_bias, off_p_gwT, off_p_a2, off_p_b2, off_p_out, off_v_w1T, off_v_b1, off_v_w2T, off_v_b2;
 } LzNetDesc;

@@ -1,9 +1,10 @@
 // lz_net.hip -- fused policy + bucketed-value ResNet forward for 6x6 Liuzhou boards on gfx950.
 //
-// One persistent workgroup (4 waves, one per SIMD) owns S samples (S*36 board cells) and runs the WHOLE
+// One persistent workgroup (8 waves, two per SIMD) owns S samples (S*36 board cells) and runs the WHOLE
 // network on them without touching HBM in between:
 //   * the fp32 residual stream lives in MFMA accumulator registers for the whole trunk
-//     (each wave owns 9 tiles of 16 cells x 4 tiles of 16 channels = 144 VGPRs);
+//     (each wave owns 9 tiles of 16 cells x 2 tiles of 16 channels = 72 registers, plus 72 for the
+//     conv1 output: 144 accumulators fit the AGPR half of the 256-register budget of 2 waves/SIMD);
 //   * conv inputs are staged as fp16 [cell][channel] rows in LDS (one buffer, rewritten per layer);
 //   * every 3x3 conv is 9 shifted GEMMs on v_mfma_f32_16x16x32_f16 with the WEIGHTS as the A operand
 //     (pre-packed in fragment order, streamed from L2 with one 16-byte load per lane) and the
@@ -35,6 +36,7 @@ struct NetParams {
     const _Float16* wfrag;
     const float* fp;
     int layer_off[32];          // offsets in halfs: stem, (conv1, conv2) x blocks, heads
+    int hf_gw, hf_w1, hf_w2, hf_out;   // offsets in halfs of the head FC fragments (gpool_linear, fc1, fc2, 3 out convs)
     int blocks;
     // float-parameter offsets
     int stem_bias, blk0, trunk_a, trunk_b, head_bias, p_gwT, p_a2, p_b2, p_out, v_w1T, v_b1, v_w2T, v_b2;
@@ -44,22 +46,31 @@ template <int C, int S>
 struct Cfg {
     static constexpr int NPOS = S * 36;
     static constexpr int NT = NPOS / 16;
+    static constexpr int WAVES = 8;
+    static constexpr int THREADS = WAVES * 64;
+    static constexpr int CTW = 2;                   // 16-channel output tiles per wave
     static constexpr int PG = NT / 9;               // cell groups (4 or 2)
-    static constexpr int CG = 4 / PG;               // channel groups (1 or 2)
+    static constexpr int CG = WAVES / PG;           // channel groups (2 or 4)
     static constexpr int CT = C / 16;               // 16-channel output tiles
     static constexpr int KB = C / 32;               // 32-channel K blocks
     static constexpr int KBLOG = (KB == 1) ? 0 : (KB == 2) ? 1 : 2;
     static constexpr int STRIDE = C * 2 + 16;       // bytes per cell row (16-byte aligned, bank-skewed)
     static constexpr int ACT_OFF = 0;
     static constexpr int ZERO_OFF = NPOS * STRIDE;
+    // head scratch: fp16 rows for the MFMA B operand (16 sample columns), fp32 for scalar epilogues
+    static constexpr int POOL_STRIDE = kPool * 2 + 16;              // 400 B per sample row
+    static constexpr int HID_STRIDE = kMlp * 2 + 16;                // 272 B per sample row
+    static constexpr int VL_STRIDE = 112;                           // floats per sample (101 bins padded)
     static constexpr int POOL_OFF = ZERO_OFF + STRIDE;
-    static constexpr int G_OFF = POOL_OFF + S * kPool * 4;
-    static constexpr int HID_OFF = G_OFF + S * kHead * 4;
-    static constexpr int PLOG_OFF = HID_OFF + S * kMlp * 4;
-    static constexpr int PAR_OFF = PLOG_OFF + S * 432;
+    static constexpr int G_OFF = POOL_OFF + 16 * POOL_STRIDE;
+    static constexpr int HID_OFF = G_OFF + 16 * kHead * 4;
+    static constexpr int PLOG_OFF = HID_OFF + 16 * HID_STRIDE;
+    static constexpr int PLOG_BYTES = (S * 432 > 16 * VL_STRIDE * 4) ? S * 432 : 16 * VL_STRIDE * 4;
+    static constexpr int PAR_OFF = PLOG_OFF + PLOG_BYTES;
     static constexpr int LDS_BYTES = PAR_OFF + 5 * kHead * 4;
-    static_assert(CT / CG == 4, "each wave owns 4 output-channel tiles");
-    static_assert(NT % 9 == 0 && PG * CG == 4, "4 waves per workgroup");
+    static constexpr int HP = 8 / (CG * CTW);       // passes over the 8 head output tiles (2 or 1)
+    static_assert(CT == CG * CTW, "each wave owns 2 output-channel tiles");
+    static_assert(NT % 9 == 0 && PG * CG == WAVES, "8 waves per workgroup");
 };
 
 // ---- the GEMM core: acc[9 cell tiles][4 channel tiles] += W(layer) * act --------------------------------
@@ -78,42 +89,46 @@ __device__ __forceinline__ void step_geometry(int step, int& tap, int& off, int&
     zoff = kb * 64;
 }
 
+typedef f4 Acc[9][2];
+
 template <int C, int S, bool TAPS9, bool STEM>
-__device__ __forceinline__ void gemm_step(f4 (&acc)[9][4], const h8 (&A)[4], int step, const unsigned char* lds,
+__device__ __forceinline__ void gemm_step(Acc& acc, const h8 (&A)[2], int step, const unsigned char* lds,
                                           const int (&base)[9], const int (&valid)[9], int zero_addr) {
     int tap, off, zoff;
     step_geometry<C, S, TAPS9, STEM>(step, tap, off, zoff);
     const int za = zero_addr + zoff;
-    h8 b0 = *reinterpret_cast<const h8*>(lds + (((valid[0] >> tap) & 1) ? (base[0] + off) : za));
+    h8 B[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) B[i] = *reinterpret_cast<const h8*>(lds + (((valid[i] >> tap) & 1) ? (base[i] + off) : za));
+    __builtin_amdgcn_sched_barrier(0);                   // all 9 reads in flight before the first MFMA
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
-        h8 b1 = b0;
-        if (i + 1 < 9) b1 = *reinterpret_cast<const h8*>(lds + (((valid[i + 1] >> tap) & 1) ? (base[i + 1] + off) : za));
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[j], b0, acc[i][j], 0, 0, 0);
-        b0 = b1;
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[j], B[i], acc[i][j], 0, 0, 0);
     }
 }
 
+// Two waves per SIMD hide each other's LDS latency; the weight fragments (L2) are prefetched one K step
+// ahead in registers.
 template <int C, int S, bool TAPS9, bool STEM>
-__device__ __forceinline__ void conv_gemm(f4 (&acc)[9][4], const h8* __restrict__ wl, int ctn, int ct0,
+__device__ __forceinline__ void conv_gemm(Acc& acc, const h8* __restrict__ wl, int ctn, int ct0,
                                           const unsigned char* lds, const int (&base)[9], const int (&valid)[9],
                                           int zero_addr, int lane) {
     using K = Cfg<C, S>;
     constexpr int nsteps = TAPS9 ? (STEM ? 9 : 9 * K::KB) : K::KB;
     const h8* wp = wl + (size_t)ct0 * 64 + lane;
     const int wstride = ctn * 64;                        // h8 elements per K step
-    h8 A0[4], A1[4];
+    h8 A0[2], A1[2];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) A0[j] = wp[j * 64];
+    for (int j = 0; j < 2; ++j) A0[j] = wp[j * 64];
 #pragma unroll 1
     for (int step = 0; step + 1 < nsteps; step += 2) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) A1[j] = wp[(size_t)(step + 1) * wstride + j * 64];
+        for (int j = 0; j < 2; ++j) A1[j] = wp[(size_t)(step + 1) * wstride + j * 64];
         gemm_step<C, S, TAPS9, STEM>(acc, A0, step, lds, base, valid, zero_addr);
         if (step + 2 < nsteps) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) A0[j] = wp[(size_t)(step + 2) * wstride + j * 64];
+            for (int j = 0; j < 2; ++j) A0[j] = wp[(size_t)(step + 2) * wstride + j * 64];
         }
         gemm_step<C, S, TAPS9, STEM>(acc, A1, step + 1, lds, base, valid, zero_addr);
     }
@@ -128,13 +143,13 @@ __device__ __forceinline__ h4 to_h4(float a, float b, float c, float d) {
 
 // write relu(scale*acc + shift) (per channel) as fp16 rows; `chan_base` = first channel of co tile 0
 template <int C, int S, bool HAS_SCALE>
-__device__ __forceinline__ void store_act(const f4 (&acc)[9][4], unsigned char* lds, int tile0, int chan_base,
+__device__ __forceinline__ void store_act(const Acc& acc, unsigned char* lds, int tile0, int chan_base,
                                           const float* __restrict__ scale, const float* __restrict__ shift, int lane) {
     using K = Cfg<C, S>;
     const int sub = (lane >> 4) * 4;
-    f4 sc[4], sh[4];
+    f4 sc[2], sh[2];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < 2; ++j) {
         const int ch = chan_base + j * 16 + sub;
         sh[j] = *reinterpret_cast<const f4*>(shift + ch);
         if (HAS_SCALE) sc[j] = *reinterpret_cast<const f4*>(scale + ch);
@@ -143,7 +158,7 @@ __device__ __forceinline__ void store_act(const f4 (&acc)[9][4], unsigned char* 
     for (int i = 0; i < 9; ++i) {
         const int n = (tile0 + i) * 16 + (lane & 15);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < 2; ++j) {
             f4 v = acc[i][j];
             if (HAS_SCALE) v = v * sc[j] + sh[j]; else v = v + sh[j];
             const h4 o = to_h4(fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f));
@@ -152,13 +167,14 @@ __device__ __forceinline__ void store_act(const f4 (&acc)[9][4], unsigned char* 
     }
 }
 
-// global pooling of a [cell][64] fp16 map in LDS -> pooled[s][192] = mean | max | sqrt(var + 1e-6)
+// global pooling of a [cell][64] fp16 map in LDS -> fp16 row pooled[s][192] = mean | max | sqrt(var + 1e-6)
 template <int C, int S>
-__device__ __forceinline__ void gpool64(const unsigned char* lds, float* pooled, int tid) {
+__device__ __forceinline__ void gpool64(unsigned char* lds, int tid) {
     using K = Cfg<C, S>;
     if (tid < S * 16) {
         const int s = tid >> 4, cq = tid & 15;
         float sum[4] = {0.f, 0.f, 0.f, 0.f}, mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll 6
         for (int p = 0; p < 36; ++p) {
             const h4 v = *reinterpret_cast<const h4*>(lds + K::ACT_OFF + (s * 36 + p) * K::STRIDE + cq * 8);
 #pragma unroll
@@ -167,33 +183,68 @@ __device__ __forceinline__ void gpool64(const unsigned char* lds, float* pooled,
         float mean[4], var[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int k = 0; k < 4; ++k) mean[k] = sum[k] * (1.0f / 36.0f);
+#pragma unroll 6
         for (int p = 0; p < 36; ++p) {
             const h4 v = *reinterpret_cast<const h4*>(lds + K::ACT_OFF + (s * 36 + p) * K::STRIDE + cq * 8);
 #pragma unroll
             for (int k = 0; k < 4; ++k) { const float d = (float)v[k] - mean[k]; var[k] += d * d; }
         }
+        unsigned char* row = lds + K::POOL_OFF + s * K::POOL_STRIDE;
+        *reinterpret_cast<h4*>(row + (cq * 4) * 2) = to_h4(mean[0], mean[1], mean[2], mean[3]);
+        *reinterpret_cast<h4*>(row + (kHead + cq * 4) * 2) = to_h4(mx[0], mx[1], mx[2], mx[3]);
+        *reinterpret_cast<h4*>(row + (2 * kHead + cq * 4) * 2) =
+            to_h4(sqrtf(var[0] * (1.0f / 36.0f) + 1e-6f), sqrtf(var[1] * (1.0f / 36.0f) + 1e-6f),
+                  sqrtf(var[2] * (1.0f / 36.0f) + 1e-6f), sqrtf(var[3] * (1.0f / 36.0f) + 1e-6f));
+    }
+}
+
+// small dense layer on the matrix cores: D[16 outputs of tile ct][16 samples] = W(ct) * rows, K = 32*kbn
+__device__ __forceinline__ f4 fc_tile(const h8* __restrict__ wfrag, int ctn, int ct, int kbn,
+                                      const unsigned char* rows, int row_stride, int lane) {
+    f4 d = (f4){0.f, 0.f, 0.f, 0.f};
+    const unsigned char* bp = rows + (lane & 15) * row_stride + (lane >> 4) * 16;
+    for (int kb = 0; kb < kbn; ++kb) {
+        const h8 a = wfrag[(size_t)(kb * ctn + ct) * 64 + lane];
+        const h8 b = *reinterpret_cast<const h8*>(bp + kb * 64);
+        d = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, d, 0, 0, 0);
+    }
+    return d;
+}
+
+// write one head map (64 channels wide) from a wave's 2 output tiles: channel = (tile_in_map*16) + ...
+template <int C, int S>
+__device__ __forceinline__ void store_head(const Acc& acc, unsigned char* lds, int tile0, int map_tile0,
+                                           const float* __restrict__ bias, int lane) {
+    using K = Cfg<C, S>;
+    const int sub = (lane >> 4) * 4;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            pooled[s * kPool + cq * 4 + k] = mean[k];
-            pooled[s * kPool + kHead + cq * 4 + k] = mx[k];
-            pooled[s * kPool + 2 * kHead + cq * 4 + k] = sqrtf(var[k] * (1.0f / 36.0f) + 1e-6f);
+    for (int i = 0; i < 9; ++i) {
+        const int n = (tile0 + i) * 16 + (lane & 15);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int ch = (map_tile0 + j) * 16 + sub;
+            const f4 b = *reinterpret_cast<const f4*>(bias + ch);
+            const f4 v = acc[i][j] + b;
+            *reinterpret_cast<h4*>(lds + K::ACT_OFF + n * K::STRIDE + ch * 2) =
+                to_h4(fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f));
         }
     }
 }
 
 template <int C, int S>
-__global__ __launch_bounds__(256, 1) void net_forward_kernel(NetParams P, const float* __restrict__ planes,
+__global__ __launch_bounds__(512, 2) void net_forward_kernel(NetParams P, const float* __restrict__ planes,
                                                             int64_t N, float* __restrict__ lp1,
                                                             float* __restrict__ lp2, float* __restrict__ lpm,
                                                             float* __restrict__ vlogits, float* __restrict__ value) {
     using K = Cfg<C, S>;
+    constexpr int NTHR = K::THREADS;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int pg = wave % K::PG, cg = wave / K::PG;
     const int tile0 = pg * 9;
-    const int ct0 = cg * 4;                     // first output-channel tile of this wave
+    const int ct0 = cg * K::CTW;                 // first output-channel tile of this wave
     const int chan0 = ct0 * 16;
     const float* fp = P.fp;
 
@@ -214,13 +265,12 @@ __global__ __launch_bounds__(256, 1) void net_forward_kernel(NetParams P, const 
         valid[i] = m;
     }
     const int zero_addr = K::ZERO_OFF + (lane >> 4) * 16;
-    for (int i = tid; i < K::STRIDE / 4; i += 256) reinterpret_cast<uint32_t*>(lds + K::ZERO_OFF)[i] = 0u;
-    float* pooled = reinterpret_cast<float*>(lds + K::POOL_OFF);
+    for (int i = tid; i < K::STRIDE / 4; i += NTHR) reinterpret_cast<uint32_t*>(lds + K::ZERO_OFF)[i] = 0u;
     float* gvec = reinterpret_cast<float*>(lds + K::G_OFF);
-    float* hidden = reinterpret_cast<float*>(lds + K::HID_OFF);
     float* plog = reinterpret_cast<float*>(lds + K::PLOG_OFF);
     float* par = reinterpret_cast<float*>(lds + K::PAR_OFF);
-    for (int i = tid; i < 5 * kHead; i += 256) {
+    for (int i = tid; i < (K::PLOG_OFF - K::POOL_OFF) / 4; i += NTHR) reinterpret_cast<uint32_t*>(lds + K::POOL_OFF)[i] = 0u;
+    for (int i = tid; i < 5 * kHead; i += NTHR) {
         float v;
         if (i < kHead) v = fp[P.p_a2 + i];
         else if (i < 2 * kHead) v = fp[P.p_b2 + i - kHead];
@@ -234,7 +284,7 @@ __global__ __launch_bounds__(256, 1) void net_forward_kernel(NetParams P, const 
         const int nvalid = (int)((N - n0) < S ? (N - n0) : S);
         __syncthreads();
         // ---- stage the 11 input planes as fp16 rows [cell][32 ch] (ch >= 11 zero) ----
-        for (int n = tid; n < K::NPOS; n += 256) {
+        for (int n = tid; n < K::NPOS; n += NTHR) {
             const int s = n / 36, p = n - s * 36;
             _Float16 row[32];
 #pragma unroll
@@ -255,18 +305,18 @@ __global__ __launch_bounds__(256, 1) void net_forward_kernel(NetParams P, const 
         }
         __syncthreads();
 
-        f4 x[9][4], acc[9][4];
+        Acc x, acc;
 #pragma unroll
         for (int i = 0; i < 9; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) x[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < 2; ++j) x[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
         // ---- stem: x = relu(conv(planes) + bias) ----
         conv_gemm<C, S, true, true>(x, reinterpret_cast<const h8*>(P.wfrag + P.layer_off[0]), K::CT, ct0, lds, base,
                                     valid, zero_addr, lane);
         {
             const int sub = (lane >> 4) * 4;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < 2; ++j) {
                 const f4 b = *reinterpret_cast<const f4*>(fp + P.stem_bias + chan0 + j * 16 + sub);
 #pragma unroll
                 for (int i = 0; i < 9; ++i) {
@@ -284,7 +334,7 @@ __global__ __launch_bounds__(256, 1) void net_forward_kernel(NetParams P, const 
 #pragma unroll
             for (int i = 0; i < 9; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
+                for (int j = 0; j < 2; ++j) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
             conv_gemm<C, S, true, false>(acc, reinterpret_cast<const h8*>(P.wfrag + P.layer_off[1 + 2 * blk]), K::CT,
                                          ct0, lds, base, valid, zero_addr, lane);
             __syncthreads();
@@ -293,7 +343,7 @@ __global__ __launch_bounds__(256, 1) void net_forward_kernel(NetParams P, const 
             conv_gemm<C, S, true, false>(x, reinterpret_cast<const h8*>(P.wfrag + P.layer_off[2 + 2 * blk]), K::CT,
                                          ct0, lds, base, valid, zero_addr, lane);       // x += conv2(u)
         }
-        // ---- trunk output h = relu(a*x + b) -> LDS; head 1x1 convs (policy 0..63 | value 64..127) ----
+        // ---- trunk output h = relu(a*x + b) -> LDS; head 1x1 convs (8 output tiles: policy 0..3 | value 4..7) ----
         __syncthreads();
         store_act<C, S, true>(x, lds, tile0, chan0, fp + P.trunk_a, fp + P.trunk_b, lane);
         __syncthreads();
@@ -301,122 +351,109 @@ __global__ __launch_bounds__(256, 1) void net_forward_kernel(NetParams P, const 
 #pragma unroll
         for (int i = 0; i < 9; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f}; x[i][j] = (f4){0.f, 0.f, 0.f, 0.f}; }
-        if (K::CG == 1) {
-            conv_gemm<C, S, false, false>(acc, wh, 8, 0, lds, base, valid, zero_addr, lane);   // policy map
-            conv_gemm<C, S, false, false>(x, wh, 8, 4, lds, base, valid, zero_addr, lane);     // value map
-        } else {
-            conv_gemm<C, S, false, false>(acc, wh, 8, cg * 4, lds, base, valid, zero_addr, lane);
-        }
+            for (int j = 0; j < 2; ++j) { acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f}; x[i][j] = (f4){0.f, 0.f, 0.f, 0.f}; }
+        // pass 0 -> acc, pass 1 (only when 4 waves' worth of tiles cover half of the 8 head tiles) -> x
+        const int ht0 = cg * K::CTW;                               // head tile of acc   (0..7)
+        const int ht1 = K::CG * K::CTW + cg * K::CTW;              // head tile of x     (HP == 2 only)
+        conv_gemm<C, S, false, false>(acc, wh, 8, ht0, lds, base, valid, zero_addr, lane);
+        if (K::HP == 2) conv_gemm<C, S, false, false>(x, wh, 8, ht1, lds, base, valid, zero_addr, lane);
         __syncthreads();
         // ---- policy head ----
-        if (K::CG == 1 || cg == 0) {
-            // rows are only 64 channels wide here: reuse the act buffer with the same stride
-            const int sub = (lane >> 4) * 4;
+        if (ht0 < 4) store_head<C, S>(acc, lds, tile0, ht0, fp + P.head_bias, lane);
+        __syncthreads();
+        gpool64<C, S>(lds, tid);
+        __syncthreads();
+        if (wave < 4) {                                            // g = gpool_linear(pooled): 4 tiles x K=192
+            const f4 d = fc_tile(reinterpret_cast<const h8*>(P.wfrag + P.hf_gw), 4, wave, 6, lds + K::POOL_OFF,
+                                 K::POOL_STRIDE, lane);
+            const int s = lane & 15, ch = wave * 16 + (lane >> 4) * 4;
+            *reinterpret_cast<f4*>(gvec + s * kHead + ch) = d;
+        }
+        __syncthreads();
+        for (int it = tid; it < K::NPOS * 8; it += NTHR) {          // p2 = relu(bn2(p + g)) in place
+            const int n = it >> 3, c8 = it & 7;
+            const int s = n / 36;
+            h8* ptr = reinterpret_cast<h8*>(lds + K::ACT_OFF + n * K::STRIDE + c8 * 16);
+            h8 v = *ptr;
 #pragma unroll
-            for (int i = 0; i < 9; ++i) {
-                const int n = (tile0 + i) * 16 + (lane & 15);
+            for (int k = 0; k < 8; ++k) {
+                const int ch = c8 * 8 + k;
+                v[k] = (_Float16)fmaxf(((float)v[k] + gvec[s * kHead + ch]) * par[ch] + par[kHead + ch], 0.f);
+            }
+            *ptr = v;
+        }
+        __syncthreads();
+        for (int t = wave; t < K::NT; t += K::WAVES) {              // three 1x1 output convs: 1 tile x K=64
+            const h8* wo = reinterpret_cast<const h8*>(P.wfrag + P.hf_out);
+            f4 d = (f4){0.f, 0.f, 0.f, 0.f};
+            const int n = t * 16 + (lane & 15);
+            const unsigned char* bp = lds + K::ACT_OFF + n * K::STRIDE + (lane >> 4) * 16;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const f4 b = *reinterpret_cast<const f4*>(fp + P.head_bias + j * 16 + sub);
-                    const f4 v = acc[i][j] + b;
-                    *reinterpret_cast<h4*>(lds + K::ACT_OFF + n * K::STRIDE + (j * 16 + sub) * 2) =
-                        to_h4(fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f));
-                }
+            for (int kb = 0; kb < 2; ++kb)
+                d = __builtin_amdgcn_mfma_f32_16x16x32_f16(wo[kb * 64 + lane], *reinterpret_cast<const h8*>(bp + kb * 64), d, 0, 0, 0);
+            if (lane < 16) {
+                const int s = n / 36, p = n - s * 36;
+                plog[(s * 3 + 0) * 36 + p] = d[0];
+                plog[(s * 3 + 1) * 36 + p] = d[1];
+                plog[(s * 3 + 2) * 36 + p] = d[2];
             }
         }
         __syncthreads();
-        gpool64<C, S>(lds, pooled, tid);
-        __syncthreads();
-        for (int it = tid; it < S * kHead; it += 256) {           // g = gpool_linear(pooled)
-            const int s = it / kHead, co = it - s * kHead;
-            float a = 0.f;
-            const float* w = fp + P.p_gwT + co;
-            for (int k = 0; k < kPool; ++k) a += w[k * kHead] * pooled[s * kPool + k];
-            gvec[it] = a;
-        }
-        __syncthreads();
-        for (int n = tid; n < K::NPOS; n += 256) {                 // three 1x1 output convs on relu(bn2(p + g))
-            const int s = n / 36, p = n - s * 36;
-            float o0 = 0.f, o1 = 0.f, o2 = 0.f;
-            const unsigned char* row = lds + K::ACT_OFF + n * K::STRIDE;
-            for (int c8 = 0; c8 < 8; ++c8) {
-                const h8 v = *reinterpret_cast<const h8*>(row + c8 * 16);
+        for (int row = wave; row < S * 3; row += K::WAVES) {        // log_softmax over the 36 cells, one wave per row
+            const int s = row / 3, h = row - s * 3;
+            const float v = lane < 36 ? plog[row * 36 + lane] : -INFINITY;
+            float mx = v;
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const int ch = c8 * 8 + k;
-                    const float z = fmaxf(((float)v[k] + gvec[s * kHead + ch]) * par[ch] + par[kHead + ch], 0.f);
-                    o0 += par[2 * kHead + ch] * z;
-                    o1 += par[3 * kHead + ch] * z;
-                    o2 += par[4 * kHead + ch] * z;
-                }
-            }
-            plog[(s * 3 + 0) * 36 + p] = o0;
-            plog[(s * 3 + 1) * 36 + p] = o1;
-            plog[(s * 3 + 2) * 36 + p] = o2;
-        }
-        __syncthreads();
-        if (tid < S * 3) {                                         // log_softmax over the 36 cells
-            const int s = tid / 3, h = tid - s * 3;
-            if (s < nvalid) {
-                const float* v = plog + (s * 3 + h) * 36;
-                float mx = -INFINITY;
-                for (int p = 0; p < 36; ++p) mx = fmaxf(mx, v[p]);
-                float sum = 0.f;
-                for (int p = 0; p < 36; ++p) sum += expf(v[p] - mx);
-                const float lse = mx + logf(sum);
-                float* dst = (h == 0 ? lp1 : h == 1 ? lp2 : lpm) + (n0 + s) * 36;
-                for (int p = 0; p < 36; ++p) dst[p] = v[p] - lse;
-            }
+            for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+            float e = lane < 36 ? expf(v - mx) : 0.f;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) e += __shfl_xor(e, o);
+            const float lse = mx + logf(e);
+            if (lane < 36 && s < nvalid) (h == 0 ? lp1 : h == 1 ? lp2 : lpm)[(n0 + s) * 36 + lane] = v - lse;
         }
         __syncthreads();
         // ---- value head ----
-        if (K::CG == 1 || cg == 1) {
-            const int sub = (lane >> 4) * 4;
+        if (K::HP == 2) store_head<C, S>(x, lds, tile0, ht1 - 4, fp + P.head_bias + kHead, lane);
+        else if (ht0 >= 4) store_head<C, S>(acc, lds, tile0, ht0 - 4, fp + P.head_bias + kHead, lane);
+        __syncthreads();
+        gpool64<C, S>(lds, tid);
+        __syncthreads();
+        {                                                           // fc1 + relu: 8 tiles x K=192, one per wave
+            const f4 d = fc_tile(reinterpret_cast<const h8*>(P.wfrag + P.hf_w1), 8, wave, 6, lds + K::POOL_OFF,
+                                 K::POOL_STRIDE, lane);
+            const int s = lane & 15, ch = wave * 16 + (lane >> 4) * 4;
+            const f4 b = *reinterpret_cast<const f4*>(fp + P.v_b1 + ch);
+            const f4 v = d + b;
+            *reinterpret_cast<h4*>(lds + K::HID_OFF + s * K::HID_STRIDE + ch * 2) =
+                to_h4(fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f));
+        }
+        __syncthreads();
+        float* vl = plog;                                           // [16][112] value logits
+        if (wave < 7) {                                             // fc2: 7 tiles (101 bins padded to 112) x K=128
+            const f4 d = fc_tile(reinterpret_cast<const h8*>(P.wfrag + P.hf_w2), 7, wave, 4, lds + K::HID_OFF,
+                                 K::HID_STRIDE, lane);
+            const int s = lane & 15, o = wave * 16 + (lane >> 4) * 4;
 #pragma unroll
-            for (int i = 0; i < 9; ++i) {
-                const int n = (tile0 + i) * 16 + (lane & 15);
+            for (int r = 0; r < 4; ++r)
+                if (o + r < kBins) vl[s * K::VL_STRIDE + o + r] = d[r] + fp[P.v_b2 + o + r];
+        }
+        __syncthreads();
+        for (int s = wave; s < nvalid; s += K::WAVES) {              // bucket expectation, one wave per sample
+            const float v0 = vl[s * K::VL_STRIDE + lane];
+            const float v1 = lane + 64 < kBins ? vl[s * K::VL_STRIDE + lane + 64] : -INFINITY;
+            float mx = fmaxf(v0, v1);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const f4 b = *reinterpret_cast<const f4*>(fp + P.head_bias + kHead + j * 16 + sub);
-                    const f4 v = (K::CG == 1 ? x[i][j] : acc[i][j]) + b;
-                    *reinterpret_cast<h4*>(lds + K::ACT_OFF + n * K::STRIDE + (j * 16 + sub) * 2) =
-                        to_h4(fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f));
-                }
+            for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+            const float e0 = expf(v0 - mx), e1 = lane + 64 < kBins ? expf(v1 - mx) : 0.f;
+            float sum = e0 + e1;
+            float ex = e0 * (-1.0f + 0.02f * (float)lane) + e1 * (-1.0f + 0.02f * (float)(lane + 64));
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { sum += __shfl_xor(sum, o); ex += __shfl_xor(ex, o); }
+            if (lane == 0 && value != nullptr) value[n0 + s] = ex / sum;
+            if (vlogits != nullptr) {
+                vlogits[(n0 + s) * kBins + lane] = v0;
+                if (lane + 64 < kBins) vlogits[(n0 + s) * kBins + lane + 64] = v1;
             }
-        }
-        __syncthreads();
-        gpool64<C, S>(lds, pooled, tid);
-        __syncthreads();
-        for (int it = tid; it < S * kMlp; it += 256) {              // fc1 + relu
-            const int s = it / kMlp, o = it - s * kMlp;
-            float a = fp[P.v_b1 + o];
-            const float* w = fp + P.v_w1T + o;
-            for (int k = 0; k < kPool; ++k) a += w[k * kMlp] * pooled[s * kPool + k];
-            hidden[it] = fmaxf(a, 0.f);
-        }
-        __syncthreads();
-        float* vl = plog;                                           // [S][101] value logits
-        for (int it = tid; it < S * kBins; it += 256) {              // fc2
-            const int s = it / kBins, o = it - s * kBins;
-            float a = fp[P.v_b2 + o];
-            const float* w = fp + P.v_w2T + o;
-            for (int k = 0; k < kMlp; ++k) a += w[k * kBins] * hidden[s * kMlp + k];
-            vl[it] = a;
-            if (vlogits != nullptr && s < nvalid) vlogits[(n0 + s) * kBins + o] = a;
-        }
-        __syncthreads();
-        if (tid < S && tid < nvalid && value != nullptr) {           // softmax expectation over bucket centres
-            const float* v = vl + tid * kBins;
-            float mx = -INFINITY;
-            for (int k = 0; k < kBins; ++k) mx = fmaxf(mx, v[k]);
-            float sum = 0.f, ex = 0.f;
-            for (int k = 0; k < kBins; ++k) {
-                const float e = expf(v[k] - mx);
-                sum += e;
-                ex += e * (-1.0f + 0.02f * (float)k);
-            }
-            value[n0 + tid] = ex / sum;
         }
     }
 }
@@ -429,7 +466,7 @@ int launch_net(const NetParams& P, const float* planes, int64_t N, float* lp1, f
     const int64_t n_pass = (N + S - 1) / S;
     int grid = (int)(n_pass < max_blocks ? n_pass : max_blocks);
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), K::LDS_BYTES, st, P, planes, N, lp1, lp2, lpm, vlogits, value);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(K::THREADS), K::LDS_BYTES, st, P, planes, N, lp1, lp2, lpm, vlogits, value);
     return hipGetLastError() == hipSuccess ? LZ_OK : LZ_ERR_LAUNCH;
 }
 
@@ -462,6 +499,8 @@ int lz_net_forward_f16(const LzNetDesc* d, const float* planes, int64_t N, float
     P.fp = d->fparams;
     for (int i = 0; i < d->num_layers; ++i) P.layer_off[i] = d->layer_offsets[i];
     P.blocks = d->blocks;
+    P.hf_gw = d->head_frag_offsets[0]; P.hf_w1 = d->head_frag_offsets[1]; P.hf_w2 = d->head_frag_offsets[2];
+    P.hf_out = d->head_frag_offsets[3];
     P.stem_bias = d->off_stem_bias; P.blk0 = d->off_block0; P.trunk_a = d->off_trunk_a; P.trunk_b = d->off_trunk_b;
     P.head_bias = d->off_head_bias; P.p_gwT = d->off_p_gwT; P.p_a2 = d->off_p_a2; P.p_b2 = d->off_p_b2;
     P.p_out = d->off_p_out; P.v_w1T = d->off_v_w1T; P.v_b1 = d->off_v_b1; P.v_w2T = d->off_v_w2T; P.v_b2 = d->off_v_b2;

@@ -19,7 +19,8 @@ from .net_pack import NetPack, pack_model, BINS
 
 class LzNetDesc(C.Structure):
     _fields_ = [("channels", C.c_int32), ("blocks", C.c_int32), ("num_layers", C.c_int32), ("max_blocks", C.c_int32),
-                ("wfrag", C.c_void_p), ("fparams", C.c_void_p), ("layer_offsets", C.c_int32 * 32)] + \
+                ("wfrag", C.c_void_p), ("fparams", C.c_void_p), ("layer_offsets", C.c_int32 * 32),
+                ("head_frag_offsets", C.c_int32 * 4)] + \
                [(n, C.c_int32) for n in ("off_stem_bias", "off_block0", "off_trunk_a", "off_trunk_b", "off_head_bias",
                                          "off_p_gwT", "off_p_a2", "off_p_b2", "off_p_out", "off_v_w1T", "off_v_b1",
                                          "off_v_w2T", "off_v_b2")]
@@ -45,6 +46,8 @@ class FusedNet:
         d.wfrag, d.fparams = self.pack.wfrag.data_ptr(), self.pack.fparams.data_ptr()
         for i, o in enumerate(self.pack.layer_offsets):
             d.layer_offsets[i] = int(o)
+        for i, o in enumerate(self.pack.head_offsets):
+            d.head_frag_offsets[i] = int(o)
         f = self.pack.foff
         d.off_stem_bias, d.off_block0 = f["stem_bias"], f.get("b0_a1", 0)
         d.off_trunk_a, d.off_trunk_b, d.off_head_bias = f["trunk_a"], f["trunk_b"], f["head_bias"]

@@ -62,10 +62,11 @@ class NetPack:
     fparams: torch.Tensor          # fp32, flat
     layer_offsets: List[int]       # offsets (in halfs) of each conv layer in wfrag; last = heads
     foff: Dict[str, int]           # offsets (in floats) into fparams
+    head_offsets: List[int] = None  # offsets (in halfs) of gpool_linear / fc1 / fc2 / out-conv fragments
 
     def to(self, device) -> "NetPack":
         return NetPack(self.channels, self.blocks, self.wfrag.to(device), self.fparams.to(device),
-                       list(self.layer_offsets), dict(self.foff))
+                       list(self.layer_offsets), dict(self.foff), list(self.head_offsets))
 
 
 def pack_model(model) -> NetPack:
@@ -121,14 +122,28 @@ def pack_model(model) -> NetPack:
     if pad:
         fl.append(torch.zeros(pad, dtype=torch.float64))
 
+    # head dense layers as 1x1 "convs" in the same fragment format (rows padded to a multiple of 16)
+    def fc_frag(w: torch.Tensor, rows_pad: int) -> torch.Tensor:
+        wp = torch.zeros((rows_pad, w.shape[1]), dtype=torch.float64)
+        wp[: w.shape[0]] = w.detach().double()
+        return _frag_conv(wp.view(rows_pad, w.shape[1], 1, 1), int(w.shape[1]))
+
+    head_frags = [fc_frag(ph.gpool_linear.weight, 64), fc_frag(vh.fc1.weight, 128), fc_frag(vh.fc2.weight, 112),
+                  fc_frag(torch.cat([ph.out_pos1.weight.view(1, -1), ph.out_pos2.weight.view(1, -1),
+                                     ph.out_mark.weight.view(1, -1)], dim=0), 16)]
     offsets, pos = [], 0
     for f in frags:
         offsets.append(pos)
         pos += int(f.numel())
+    head_offsets = []
+    for f in head_frags:
+        head_offsets.append(pos)
+        pos += int(f.numel())
+    frags = frags + head_frags
     wfrag = torch.cat([f.reshape(-1) for f in frags]).contiguous()
     fparams = torch.cat(fl).to(torch.float32).contiguous()
     model.to(sd_dev)
-    return NetPack(C, NB, wfrag, fparams, offsets, foff)
+    return NetPack(C, NB, wfrag, fparams, offsets, foff, head_offsets)
 
 
 # ------------------------------------------------------------------------------------------------

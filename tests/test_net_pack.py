@@ -42,6 +42,7 @@ def test_pack_layout_sizes():
     pack = pack_model(m)
     C, NB = 128, 10
     want = 9 * 1 * (C // 16) * 512 + 2 * NB * 9 * (C // 32) * (C // 16) * 512 + 1 * (C // 32) * 8 * 512
+    want += (6 * 4 + 6 * 8 + 4 * 7 + 2 * 1) * 512           # head dense layers (gpool_linear, fc1, fc2, out convs)
     assert int(pack.wfrag.numel()) == want
     assert pack.wfrag.dtype == torch.float16 and pack.fparams.dtype == torch.float32
     assert len(pack.layer_offsets) == 2 + 2 * NB
