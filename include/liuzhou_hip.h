@@ -191,6 +191,10 @@ LZ_API int lz_net_forward_f16(const LzNetDesc* net, const float* planes, int64_t
                               float* value_logits, float* value, void* stream);
 /* one-time kernel attribute setup (dynamic LDS size); call once per process before graph capture */
 LZ_API int lz_net_configure(void);
+/* measurement aid (bench.py): when enabled every lz_net_forward_f16 launch is bracketed by HIP events on
+ * its own stream; after synchronising, lz_prof_net_summary returns the summed kernel time. */
+LZ_API int lz_prof_enable(int on);
+LZ_API int lz_prof_net_summary(double* total_ms, int64_t* launches, int64_t* evals);
 
 /* ---- device-resident tree search (variant P) --------------------------------------------------- */
 

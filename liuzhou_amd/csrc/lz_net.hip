@@ -479,7 +479,46 @@ int configure_net() {
 
 }  // namespace
 
+// ---- optional live timing of the network kernel (bench.py roofline): HIP events on the launch stream ----
+namespace {
+struct NetProf {
+    bool on = false;
+    int used = 0;
+    static constexpr int kMax = 8192;
+    hipEvent_t ev[2 * kMax];
+    bool created = false;
+    double flops = 0.0;
+    int64_t evals = 0;
+} g_prof;
+}  // namespace
+
 extern "C" {
+
+int lz_prof_enable(int on) {
+    if (on && !g_prof.created) {
+        for (int i = 0; i < 2 * NetProf::kMax; ++i)
+            if (hipEventCreate(&g_prof.ev[i]) != hipSuccess) return LZ_ERR_LAUNCH;
+        g_prof.created = true;
+    }
+    g_prof.on = on != 0;
+    g_prof.used = 0;
+    g_prof.evals = 0;
+    return LZ_OK;
+}
+
+/* call after the stream has been synchronised: total / count of the timed network launches */
+int lz_prof_net_summary(double* total_ms, int64_t* launches, int64_t* evals) {
+    double t = 0.0;
+    for (int i = 0; i < g_prof.used; ++i) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]) != hipSuccess) return LZ_ERR_LAUNCH;
+        t += ms;
+    }
+    if (total_ms) *total_ms = t;
+    if (launches) *launches = g_prof.used;
+    if (evals) *evals = g_prof.evals;
+    return LZ_OK;
+}
 
 int lz_net_configure(void) {
     int a = configure_net<64, 16>();
@@ -506,9 +545,14 @@ int lz_net_forward_f16(const LzNetDesc* d, const float* planes, int64_t N, float
     P.p_out = d->off_p_out; P.v_w1T = d->off_v_w1T; P.v_b1 = d->off_v_b1; P.v_w2T = d->off_v_w2T; P.v_b2 = d->off_v_b2;
     const int max_blocks = d->max_blocks > 0 ? d->max_blocks : 256;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (d->channels == 64) return launch_net<64, 16>(P, planes, N, lp1, lp2, lpmc, value_logits, value, max_blocks, st);
-    if (d->channels == 128) return launch_net<128, 8>(P, planes, N, lp1, lp2, lpmc, value_logits, value, max_blocks, st);
-    return LZ_ERR_UNSUPPORTED;
+    if (d->channels != 64 && d->channels != 128) return LZ_ERR_UNSUPPORTED;
+    const bool prof = g_prof.on && g_prof.used < NetProf::kMax;
+    if (prof) (void)hipEventRecord(g_prof.ev[2 * g_prof.used], st);
+    const int rc = d->channels == 64
+                       ? launch_net<64, 16>(P, planes, N, lp1, lp2, lpmc, value_logits, value, max_blocks, st)
+                       : launch_net<128, 8>(P, planes, N, lp1, lp2, lpmc, value_logits, value, max_blocks, st);
+    if (prof) { (void)hipEventRecord(g_prof.ev[2 * g_prof.used + 1], st); g_prof.used += 1; g_prof.evals += N; }
+    return rc;
 }
 
 }  // extern "C"

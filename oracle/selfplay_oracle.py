@@ -68,7 +68,7 @@ def root_search_batch(model, states: Dict[str, np.ndarray], temps: np.ndarray, s
 
 def self_play_root(model, num_games: int, sims: int, temperature_init: float = 1.0, temperature_final: float = 0.1,
                    temperature_threshold: int = 10, c: float = 1.0, soft_k: float = 2.0, max_game_plies: int = 512,
-                   max_total_plies: Optional[int] = None):
+                   max_total_plies: Optional[int] = None, time_budget_s: Optional[float] = None):
     """variant-R wave loop, deterministic (sample_moves=False, no noise).  Returns (tensors dict, stats dict)."""
     states = O.initial_states(num_games)
     plies = np.zeros(num_games, np.int64); done = np.zeros(num_games, bool)
@@ -82,6 +82,8 @@ def self_play_root(model, num_games: int, sims: int, temperature_init: float = 1
     while True:
         active = np.nonzero(~done)[0]
         if active.size == 0 or (max_total_plies is not None and waves >= max_total_plies):
+            break
+        if time_budget_s is not None and waves > 0 and time.perf_counter() - t0 > time_budget_s:
             break
         act = O.select_states(states, active)
         temps = np.where(plies[active] < temperature_threshold, temperature_init, temperature_final).astype(np.float32)
@@ -157,7 +159,7 @@ def make_net_evaluator(model):
 
 def self_play_tree(model, num_games: int, sims: int, temperature_init: float = 1.0, temperature_final: float = 0.1,
                    temperature_threshold: int = 10, c: float = 1.0, max_total_plies: Optional[int] = None,
-                   reuse_tree: bool = False):
+                   reuse_tree: bool = False, time_budget_s: Optional[float] = None):
     """variant-P deterministic self-play (argmax N, lowest index) used as the CPU baseline."""
     evaluate = make_net_evaluator(model)
     cur = [O.state_from_batch(O.initial_states(1), 0) for _ in range(num_games)]
@@ -167,6 +169,8 @@ def self_play_tree(model, num_games: int, sims: int, temperature_init: float = 1
     t0 = time.perf_counter()
     waves = 0
     while not all(done) and (max_total_plies is None or waves < max_total_plies):
+        if time_budget_s is not None and waves > 0 and time.perf_counter() - t0 > time_budget_s:
+            break
         act = [i for i in range(num_games) if not done[i]]
         trees = [O.OracleTree(cur[i], c) for i in act]
         evals += tree_search_batch(evaluate, trees, sims)
