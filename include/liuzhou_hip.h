@@ -189,6 +189,11 @@ typedef struct LzNetDesc {
 LZ_API int lz_net_forward_f16(const LzNetDesc* net, const float* planes, int64_t batch,
                               float* log_p1, float* log_p2, float* log_pmc,
                               float* value_logits, float* value, void* stream);
+/* same network, input staged directly from 32-byte packed bitboard states (lz_pack_states) instead of
+ * float planes: the model-input encode (v0/src/net/encoding.cpp:26-79) is fused into the kernel's prologue */
+LZ_API int lz_net_forward_packed_f16(const LzNetDesc* net, const void* packed_states, int64_t batch,
+                                     float* log_p1, float* log_p2, float* log_pmc,
+                                     float* value_logits, float* value, void* stream);
 /* one-time kernel attribute setup (dynamic LDS size); call once per process before graph capture */
 LZ_API int lz_net_configure(void);
 /* measurement aid (bench.py): when enabled every lz_net_forward_f16 launch is bracketed by HIP events on
@@ -211,15 +216,11 @@ typedef struct LzTreeDesc {
     int32_t node_cap, edge_cap, path_cap, reserved;
     double  exploration_weight;
     const void* root_state;        /* packed [B]: current game states (input of lz_tree_begin) */
-    void*    node_state;           /* packed [B*node_cap] */
-    int32_t* node_edge_begin;      /* [B*node_cap] */
-    int32_t* node_nedges;          /* [B*node_cap]  (-1 = not expanded) */
-    double*  edge_w;               /* [B*edge_cap] value sums (child mover's perspective) */
-    float*   edge_p;               /* priors */
-    int32_t* edge_n;               /* visit counts */
-    int32_t* edge_child;           /* node index or -1 */
-    uint8_t* edge_action;          /* 220-d action index */
-    uint8_t* edge_info;            /* bit0 child mover white, bit1 terminal, bits2-3 terminal value + 1 */
+    void*    nodes;                /* [B*node_cap] 48-byte records {packed state, int32 edge_begin, int32 nedges (-1 =
+                                      not expanded), 8 B pad} */
+    void*    edges;                /* [B*edge_cap] 24-byte records {double W (value sum, child mover's view), float P,
+                                      uint32 N | info<<24, int32 child node or -1, uint8 action, 3 B pad};
+                                      info: bit0 child mover white, bit1 terminal, bits2-3 terminal value + 1 */
     int32_t* n_nodes;              /* [B] */
     int32_t* n_edges;              /* [B] */
     int32_t* root_visits;          /* [B] */

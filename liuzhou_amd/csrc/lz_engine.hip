@@ -10,8 +10,8 @@
 //   root   : expanded without backup, optional Dirichlet mix on the priors (portable_mcts.py:451-463)
 //
 // Layout in HBM (sized for the worst case, 288 GB makes this affordable -- no overflow paths):
-//   per game g: node arena  [S+1] x { packed 32-byte state, edge_begin, n_edges }
-//               edge arena  [(S+1)*72] x { W f64, P f32, N i32, child i32, action u8, info u8 }
+//   per game g: node arena  [S+2] x 48 B  { packed 32-byte state, edge_begin, n_edges }
+//               edge arena  [(S+1)*72] x 24 B { W f64, P f32, N|info u32, child i32, action u8 }
 //               path        [S+2] edge ids of the current simulation
 // A wave owns one game: lanes enumerate legal actions with ballots + popcount prefixes, evaluate PUCT
 // scores for up to 2 children per lane and reduce with shuffles; there is no cross-wave communication.
@@ -36,11 +36,30 @@ constexpr uint8_t kInfoWhite = 1;       // child mover is white
 constexpr uint8_t kInfoTerminal = 2;    // child is terminal (game over, or found to have no legal move)
 // bits 2..3: terminal value + 1  (0 => -1, 1 => 0, 2 => +1), from the child's mover's perspective
 
+// 24-byte edge record: one load brings everything select needs for a child
+struct Edge {
+    double W;            // value sum, child mover's perspective
+    float P;             // prior
+    uint32_t n_info;     // visit count (low 24 bits) | info (high 8 bits)
+    int32_t child;       // node index or -1
+    uint8_t act;         // 220-d action index
+    uint8_t pad[3];
+};
+static_assert(sizeof(Edge) == 24, "edge record is 24 bytes");
+// 48-byte node record
+struct Node {
+    Packed state;
+    int32_t edge_begin, nedges;      // nedges = -1: not expanded
+    int32_t pad[2];
+};
+static_assert(sizeof(Node) == 48, "node record is 48 bytes");
+__device__ __forceinline__ int edge_n(uint32_t ni) { return (int)(ni & 0xFFFFFFu); }
+__device__ __forceinline__ uint8_t edge_info(uint32_t ni) { return (uint8_t)(ni >> 24); }
+
 struct Tree {
     int B, node_cap, edge_cap, path_cap;
     const Packed* root_state;
-    Packed* node_state; int* node_edge_begin; int* node_nedges;
-    double* eW; float* eP; int* eN; int* eChild; uint8_t* eAct; uint8_t* eInfo;
+    Node* nodes; Edge* edges;
     int* n_nodes; int* n_edges; int* root_visits; double* root_W; float* root_init_value;
     int* path; int* path_len; int* leaf_kind; Packed* leaf_state; float* leaf_value;
     uint8_t* root_terminal; const uint8_t* active;
@@ -112,9 +131,10 @@ __global__ __launch_bounds__(kBlock) void tree_begin_kernel(Tree t) {
     const int g = blockIdx.x * kBlock + threadIdx.x;
     if (g >= t.B) return;
     const Packed rs = t.root_state[g];
-    t.node_state[(size_t)g * t.node_cap] = rs;
-    t.node_edge_begin[(size_t)g * t.node_cap] = 0;
-    t.node_nedges[(size_t)g * t.node_cap] = -1;          // unexpanded
+    Node& root = t.nodes[(size_t)g * t.node_cap];
+    root.state = rs;
+    root.edge_begin = 0;
+    root.nedges = -1;                                      // unexpanded
     t.n_nodes[g] = 1;
     t.n_edges[g] = 0;
     t.root_visits[g] = 0;
@@ -131,47 +151,51 @@ __global__ __launch_bounds__(kBlock) void tree_begin_kernel(Tree t) {
 }
 
 // ---- select: one wave per game ---------------------------------------------------------------------------
+// Per level the dependent chain is {edge_begin, nedges} -> edge records -> next node; the node's packed state
+// is only needed for the leaf's parent, and the mover of every inner node is known from the chosen edge.
 __global__ __launch_bounds__(kBlock) void tree_select_kernel(Tree t) {
     const int lane = lane_id();
     const int g = wave_game();
     if (g >= t.B) return;
     if (t.root_terminal[g]) { if (lane == 0) t.leaf_kind[g] = kLeafInactive; return; }
-    const size_t nb = (size_t)g * t.node_cap, eb = (size_t)g * t.edge_cap;
+    const Node* nodes = t.nodes + (size_t)g * t.node_cap;
+    const Edge* edges = t.edges + (size_t)g * t.edge_cap;
     int* path = t.path + (size_t)g * t.path_cap;
     int node = 0, depth = 0;
     int parent_n = t.root_visits[g];
+    int node_player = ((t.root_state[g].w0 >> 53) & 1) ? -1 : 1;
     int kind = kLeafInactive;
     float term_value = 0.f;
-    State leaf;
+    int leaf_parent = -1, leaf_action = 0;
     for (;;) {
-        const int ne = t.node_nedges[nb + node];
+        const int ne = nodes[node].nedges;
         if (ne <= 0) break;                                // (cannot happen for an expanded inner node)
-        const int e0 = t.node_edge_begin[nb + node];
-        const State ns = unpack(t.node_state[nb + node]);
+        const int e0 = nodes[node].edge_begin;
         const double sq = sqrt((double)(parent_n > 1 ? parent_n : 1));
         // up to 2 children per lane, ascending edge index
         double best = -INFINITY;
         int best_k = -1;
+        Edge mine[2];
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             const int k = r * kWave + lane;
             if (k < ne) {
-                const size_t e = eb + e0 + k;
-                const int n = t.eN[e];
+                mine[r] = edges[e0 + k];
+                const int n = edge_n(mine[r].n_info);
                 double q = 0.0;
                 if (n > 0) {
-                    const double mv = t.eW[e] / (double)n;
-                    const int child_player = (t.eInfo[e] & kInfoWhite) ? -1 : 1;
-                    q = child_player == ns.player ? mv : -mv;
+                    const double mv = mine[r].W / (double)n;
+                    const int child_player = (edge_info(mine[r].n_info) & kInfoWhite) ? -1 : 1;
+                    q = child_player == node_player ? mv : -mv;
                 }
-                const double u = t.c_puct * (double)t.eP[e] * sq / (1.0 + (double)n);
+                const double u = t.c_puct * (double)mine[r].P * sq / (1.0 + (double)n);
                 const double sc = q + u;
                 if (sc > best) { best = sc; best_k = k; }
             }
         }
         const double mx = wave_max_f64(best);
         // lowest edge index among the maxima
-        uint64_t lo = __ballot(best_k >= 0 && best_k < kWave && best == mx);
+        const uint64_t lo = __ballot(best_k >= 0 && best_k < kWave && best == mx);
         int chosen;
         if (lo) chosen = __ffsll((unsigned long long)lo) - 1;
         else {
@@ -179,33 +203,36 @@ __global__ __launch_bounds__(kBlock) void tree_select_kernel(Tree t) {
             if (!hi) break;                                // all scores NaN: stop here (portable: best_child None)
             chosen = kWave + __ffsll((unsigned long long)hi) - 1;
         }
-        const size_t e = eb + e0 + chosen;
         if (lane == 0) path[depth] = e0 + chosen;
         ++depth;
-        const uint8_t info = t.eInfo[e];
+        // broadcast the chosen edge's fields from the lane that holds it
+        const int src = chosen & 63, rr = chosen >> 6;
+        const uint32_t c_ni = __shfl(rr ? mine[1].n_info : mine[0].n_info, src);
+        const int c_child = __shfl(rr ? mine[1].child : mine[0].child, src);
+        const int c_act = __shfl((int)(rr ? mine[1].act : mine[0].act), src);
+        const uint8_t info = edge_info(c_ni);
         if (info & kInfoTerminal) {
             kind = kLeafTerminal;
             term_value = (float)((int)((info >> 2) & 3) - 1);
             break;
         }
-        const int child = t.eChild[e];
-        if (child < 0) {
-            leaf = ns;
-            int kd, p, q2, ex;
-            index_to_code(ns.phase, (int)t.eAct[e], kd, p, q2, ex);
-            apply(leaf, kd, p, q2);
-            kind = kLeafExpand;
-            break;
-        }
-        parent_n = t.eN[e];
-        node = child;
+        if (c_child < 0) { kind = kLeafExpand; leaf_parent = node; leaf_action = c_act; break; }
+        parent_n = edge_n(c_ni);
+        node_player = (info & kInfoWhite) ? -1 : 1;
+        node = c_child;
         if (depth >= t.path_cap - 1) break;
     }
     if (lane == 0) {
         t.path_len[g] = depth;
         t.leaf_kind[g] = kind;
         t.leaf_value[g] = term_value;
-        if (kind == kLeafExpand) t.leaf_state[g] = pack(leaf);
+        if (kind == kLeafExpand) {
+            State leaf = unpack(nodes[leaf_parent].state);
+            int kd, p, q2, ex;
+            index_to_code(leaf.phase, leaf_action, kd, p, q2, ex);
+            apply(leaf, kd, p, q2);
+            t.leaf_state[g] = pack(leaf);
+        }
     }
 }
 
@@ -220,14 +247,14 @@ __global__ __launch_bounds__(kBlock) void tree_expand_kernel(Tree t, const float
                                                              const float* __restrict__ values,
                                                              const float* __restrict__ noise, int noise_stride,
                                                              float epsilon) {
-    __shared__ float s_pr[kWavesPerBlock][kMaxChildren + 8];
     const int lane = lane_id();
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int g = blockIdx.x * kWavesPerBlock + w;
     if (g >= t.B) return;
     const int kind = t.leaf_kind[g];
     if (kind == kLeafInactive) return;
-    const size_t nb = (size_t)g * t.node_cap, eb = (size_t)g * t.edge_cap;
+    Node* nodes = t.nodes + (size_t)g * t.node_cap;
+    Edge* edges = t.edges + (size_t)g * t.edge_cap;
     const int* path = t.path + (size_t)g * t.path_cap;
     const int plen = IS_ROOT ? 0 : t.path_len[g];
     double backup_value = 0.0;
@@ -242,10 +269,11 @@ __global__ __launch_bounds__(kBlock) void tree_expand_kernel(Tree t, const float
             // portable_mcts.py:433-441: no legal move on a non-finished state => terminal, value -1
             backup_value = -1.0;
             if (lane == 0) {
-                if (IS_ROOT) { t.node_nedges[nb] = 0; t.root_terminal[g] = 1; t.root_init_value[g] = -1.f; }
+                if (IS_ROOT) { nodes[0].nedges = 0; t.root_terminal[g] = 1; t.root_init_value[g] = -1.f; }
                 else {
-                    const size_t e = eb + path[plen - 1];
-                    t.eInfo[e] = (uint8_t)((t.eInfo[e] & kInfoWhite) | kInfoTerminal | (0u << 2));
+                    Edge& e = edges[path[plen - 1]];
+                    const uint32_t info = (edge_info(e.n_info) & kInfoWhite) | kInfoTerminal | (0u << 2);
+                    e.n_info = (e.n_info & 0xFFFFFFu) | (info << 24);
                 }
             }
         } else {
@@ -297,13 +325,18 @@ __global__ __launch_bounds__(kBlock) void tree_expand_kernel(Tree t, const float
                 for (int it = 0; it < 4; ++it)
                     if (lg[it]) val[it] = keep * val[it] + epsilon * noise[(size_t)g * noise_stride + slot[it]];
             }
-#pragma unroll
-            for (int it = 0; it < 4; ++it) if (lg[it]) s_pr[w][slot[it]] = val[it];
-            __builtin_amdgcn_wave_barrier();
-            __threadfence_block();
+            // sequential fp32 sum in ascending action order (== the oracle's order), kept in scalar control flow:
+            // readlane of each legal lane's value, no LDS round trip
             float psum = 0.f;
-            if (lane == 0) { for (int k = 0; k < n; ++k) psum += s_pr[w][k]; }
-            psum = __shfl(psum, 0);
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                uint64_t m = __ballot(lg[it]);
+                while (m) {
+                    const int l = __ffsll((unsigned long long)m) - 1;
+                    psum += __shfl(val[it], l);
+                    m &= m - 1;
+                }
+            }
             const bool bad = !(psum > 0.f) || !isfinite(psum);
             // node + edge allocation (per-game bump counters, worst-case sized regions)
             int node_id = 0, e0 = 0;
@@ -312,11 +345,11 @@ __global__ __launch_bounds__(kBlock) void tree_expand_kernel(Tree t, const float
                 else {
                     node_id = t.n_nodes[g]; t.n_nodes[g] = node_id + 1;
                     e0 = t.n_edges[g]; t.n_edges[g] = e0 + n;
-                    t.eChild[eb + path[plen - 1]] = node_id;
-                    t.node_state[nb + node_id] = t.leaf_state[g];
+                    edges[path[plen - 1]].child = node_id;
+                    nodes[node_id].state = t.leaf_state[g];
                 }
-                t.node_edge_begin[nb + node_id] = e0;
-                t.node_nedges[nb + node_id] = n;
+                nodes[node_id].edge_begin = e0;
+                nodes[node_id].nedges = n;
                 if (IS_ROOT) t.root_init_value[g] = values[g];
             }
             e0 = __shfl(e0, 0);
@@ -333,32 +366,48 @@ __global__ __launch_bounds__(kBlock) void tree_expand_kernel(Tree t, const float
                     const int tv = (int)terminal_value_for_mover(c);
                     info |= kInfoTerminal | (uint8_t)((tv + 1) << 2);
                 }
-                const size_t e = eb + e0 + slot[it];
-                t.eW[e] = 0.0;
-                t.eP[e] = bad ? (1.0f / (float)n) : (val[it] / psum);
-                t.eN[e] = 0;
-                t.eChild[e] = -1;
-                t.eAct[e] = (uint8_t)a;
-                t.eInfo[e] = info;
+                Edge rec;
+                rec.W = 0.0;
+                rec.P = bad ? (1.0f / (float)n) : (val[it] / psum);
+                rec.n_info = (uint32_t)info << 24;
+                rec.child = -1;
+                rec.act = (uint8_t)a;
+                rec.pad[0] = rec.pad[1] = rec.pad[2] = 0;
+                edges[e0 + slot[it]] = rec;
             }
             backup_value = (double)values[g];
         }
     }
     if (IS_ROOT) return;
-    // ---- backup along the path (portable_mcts.py:123-138) ----
-    if (lane == 0 && plen > 0) {
-        const State root = unpack(t.node_state[nb]);
-        double v = backup_value;
-        for (int off = plen - 1; off >= 0; --off) {
-            const size_t e = eb + path[off];
-            t.eN[e] += 1;
-            t.eW[e] += v;
-            const int child_player = (t.eInfo[e] & kInfoWhite) ? -1 : 1;
-            const int parent_player = off > 0 ? ((t.eInfo[eb + path[off - 1]] & kInfoWhite) ? -1 : 1) : root.player;
-            if (parent_player != child_player) v = -v;
+    __threadfence_block();   // lane 0's edge / node stores above are visible to the other lanes' loads below
+    // ---- backup along the path (portable_mcts.py:123-138), one lane per path entry ----
+    // value added at offset j = v0 * (-1)^(#mover changes at offsets > j); the root gets the fully flipped value.
+    if (plen > 0) {
+        const int root_player = ((nodes[0].state.w0 >> 53) & 1) ? -1 : 1;
+        int flips_above = 0;                                    // mover changes at offsets above the current chunk
+        for (int hi = plen; hi > 0; hi -= kWave) {
+            const int lo = hi > kWave ? hi - kWave : 0;
+            const int j = lo + lane;
+            const bool in = j < hi;
+            Edge* e = in ? &edges[path[j]] : nullptr;
+            uint32_t ni = in ? e->n_info : 0u;
+            const int child_player = (edge_info(ni) & kInfoWhite) ? -1 : 1;
+            int parent_player = root_player;
+            if (in && j > 0) parent_player = (edge_info(edges[path[j - 1]].n_info) & kInfoWhite) ? -1 : 1;
+            const bool flip = in && parent_player != child_player;
+            const uint64_t F = __ballot(flip);
+            const int above = in ? __popcll(F >> (lane + 1)) : 0;   // flips at offsets > j inside the chunk
+            if (in) {
+                const double v = ((above + flips_above) & 1) ? -backup_value : backup_value;
+                e->n_info = ni + 1u;
+                e->W += v;
+            }
+            flips_above += __popcll(F);
         }
-        t.root_visits[g] += 1;
-        t.root_W[g] += v;
+        if (lane == 0) {
+            t.root_visits[g] += 1;
+            t.root_W[g] += (flips_above & 1) ? -backup_value : backup_value;
+        }
     }
 }
 
@@ -382,9 +431,10 @@ __global__ __launch_bounds__(kBlock) void tree_finish_kernel(Tree t, const float
     if (g >= t.B) return;
     float* prow = policy_dense + (size_t)g * 220;
     for (int j = lane; j < 220; j += kWave) prow[j] = 0.f;
-    const size_t nb = (size_t)g * t.node_cap, eb = (size_t)g * t.edge_cap;
-    const int ne = t.node_nedges[nb];
-    const State root = unpack(t.node_state[nb]);
+    const Node* nodes = t.nodes + (size_t)g * t.node_cap;
+    const Edge* edges = t.edges + (size_t)g * t.edge_cap;
+    const int ne = nodes[0].nedges;
+    const State root = unpack(nodes[0].state);
     const bool term = t.root_terminal[g] != 0 || ne <= 0;
     if (lane == 0) {
         terminal_out[g] = term ? 1 : 0;
@@ -393,26 +443,26 @@ __global__ __launch_bounds__(kBlock) void tree_finish_kernel(Tree t, const float
         chosen_code[g] = make_int4(-1, -1, -1, -1);
         child_count[g] = term ? 0 : ne;
         const int rv = t.root_visits[g];
-        root_value[g] = term ? (t.node_nedges[nb] == 0 && game_status(root) == 0 ? -1.f : (float)terminal_value_for_mover(root))
+        root_value[g] = term ? (ne == 0 && game_status(root) == 0 ? -1.f : (float)terminal_value_for_mover(root))
                              : (rv > 0 ? (float)(t.root_W[g] / (double)rv) : t.root_init_value[g]);
     }
     if (term) return;
-    const int e0 = t.node_edge_begin[nb];
+    const int e0 = nodes[0].edge_begin;
     const float temp = temps[g];
     float v[2], pr[2]; int act[2]; double q[2]; bool ok[2];
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
         const int k = r * kWave + lane;
         ok[r] = k < ne;
-        const size_t e = eb + e0 + (ok[r] ? k : 0);
-        const int n = ok[r] ? t.eN[e] : 0;
+        const Edge e = edges[e0 + (ok[r] ? k : 0)];
+        const int n = ok[r] ? edge_n(e.n_info) : 0;
         v[r] = (float)n;
-        pr[r] = ok[r] ? t.eP[e] : 0.f;
-        act[r] = ok[r] ? (int)t.eAct[e] : 0;
+        pr[r] = ok[r] ? e.P : 0.f;
+        act[r] = ok[r] ? (int)e.act : 0;
         q[r] = 0.0;
         if (ok[r] && n > 0) {
-            const double mv = t.eW[e] / (double)n;
-            q[r] = ((t.eInfo[e] & kInfoWhite) ? -1 : 1) == root.player ? mv : -mv;
+            const double mv = e.W / (double)n;
+            q[r] = ((edge_info(e.n_info) & kInfoWhite) ? -1 : 1) == root.player ? mv : -mv;
         }
         if (ok[r] && k < out_cap) {
             child_action[(size_t)g * out_cap + k] = act[r];
@@ -490,10 +540,8 @@ Tree make_tree(const LzTreeDesc* d) {
     Tree t;
     t.B = (int)d->num_games; t.node_cap = d->node_cap; t.edge_cap = d->edge_cap; t.path_cap = d->path_cap;
     t.root_state = reinterpret_cast<const Packed*>(d->root_state);
-    t.node_state = reinterpret_cast<Packed*>(d->node_state);
-    t.node_edge_begin = d->node_edge_begin; t.node_nedges = d->node_nedges;
-    t.eW = d->edge_w; t.eP = d->edge_p; t.eN = d->edge_n; t.eChild = d->edge_child; t.eAct = d->edge_action;
-    t.eInfo = d->edge_info;
+    t.nodes = reinterpret_cast<Node*>(d->nodes);
+    t.edges = reinterpret_cast<Edge*>(d->edges);
     t.n_nodes = d->n_nodes; t.n_edges = d->n_edges; t.root_visits = d->root_visits; t.root_W = d->root_w;
     t.root_init_value = d->root_init_value;
     t.path = d->path; t.path_len = d->path_len; t.leaf_kind = d->leaf_kind;
@@ -504,8 +552,7 @@ Tree make_tree(const LzTreeDesc* d) {
 }
 bool tree_ok(const LzTreeDesc* d) {
     return d && d->num_games >= 0 && d->node_cap >= 2 && d->edge_cap >= kMaxChildren && d->path_cap >= 3 &&
-           d->root_state && d->node_state && d->node_edge_begin && d->node_nedges && d->edge_w && d->edge_p &&
-           d->edge_n && d->edge_child && d->edge_action && d->edge_info && d->n_nodes && d->n_edges &&
+           d->root_state && d->nodes && d->edges && d->n_nodes && d->n_edges &&
            d->root_visits && d->root_w && d->root_init_value && d->path && d->path_len && d->leaf_kind &&
            d->leaf_state && d->leaf_value && d->root_terminal;
 }
@@ -588,16 +635,15 @@ int lz_tree_finish(const LzTreeDesc* d, const float* temperatures, const float* 
 int lz_tree_search(const LzTreeDesc* d, const LzNetDesc* net, int64_t sims, float* planes, float* lp1, float* lp2,
                    float* lpmc, float* values, const float* noise, int64_t noise_stride, float epsilon,
                    void* stream) {
-    if (!tree_ok(d) || !net || sims < 0 || !planes || !lp1 || !lp2 || !lpmc || !values) return LZ_ERR_ARG;
+    if (!tree_ok(d) || !net || sims < 0 || !lp1 || !lp2 || !lpmc || !values) return LZ_ERR_ARG;
     const int64_t B = d->num_games;
     if (B == 0) return LZ_OK;
     int rc = lz_tree_begin(d, stream);
     if (rc) return rc;
     for (int64_t s = 0; s <= sims; ++s) {
         if (s > 0) { rc = lz_tree_select(d, stream); if (rc) return rc; }
-        rc = lz_packed_to_model_input(d->leaf_state, B, planes, stream);
-        if (rc) return rc;
-        rc = lz_net_forward_f16(net, planes, B, lp1, lp2, lpmc, nullptr, values, stream);
+        (void)planes;   // the network kernel stages its input straight from the 32-byte packed leaf states
+        rc = lz_net_forward_packed_f16(net, d->leaf_state, B, lp1, lp2, lpmc, nullptr, values, stream);
         if (rc) return rc;
         rc = lz_tree_expand(d, s == 0 ? 1 : 0, lp1, lp2, lpmc, nullptr, values, s == 0 ? noise : nullptr, noise_stride,
                             epsilon, stream);

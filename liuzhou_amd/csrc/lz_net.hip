@@ -233,6 +233,7 @@ __device__ __forceinline__ void store_head(const Acc& acc, unsigned char* lds, i
 
 template <int C, int S>
 __global__ __launch_bounds__(512, 2) void net_forward_kernel(NetParams P, const float* __restrict__ planes,
+                                                            const uint64_t* __restrict__ packed,
                                                             int64_t N, float* __restrict__ lp1,
                                                             float* __restrict__ lp2, float* __restrict__ lpm,
                                                             float* __restrict__ vlogits, float* __restrict__ value) {
@@ -290,9 +291,25 @@ __global__ __launch_bounds__(512, 2) void net_forward_kernel(NetParams P, const 
 #pragma unroll
             for (int k = 0; k < 32; ++k) row[k] = (_Float16)0.f;
             if (s < nvalid) {
-                const float* src = planes + (n0 + s) * 396 + p;
+                if (packed != nullptr) {
+                    // 32-byte bitboard record (lz_rules.h: pack): planes = own, opp, own marks, opp marks, phase one-hot
+                    const uint64_t* rec = packed + (n0 + s) * 4;
+                    const uint64_t w0 = rec[0], w1 = rec[1], w2 = rec[2], w3 = rec[3];
+                    const bool white = (w0 >> 53) & 1;
+                    const int phase = (int)((w0 >> 50) & 7);
+                    const uint64_t own = white ? w1 : w0, opp = white ? w0 : w1;
+                    const uint64_t sm = white ? w3 : w2, om = white ? w2 : w3;
+                    row[0] = (_Float16)(float)((own >> p) & 1);
+                    row[1] = (_Float16)(float)((opp >> p) & 1);
+                    row[2] = (_Float16)(float)((sm >> p) & 1);
+                    row[3] = (_Float16)(float)((om >> p) & 1);
 #pragma unroll
-                for (int ch = 0; ch < 11; ++ch) row[ch] = (_Float16)src[ch * 36];
+                    for (int ph = 1; ph <= 7; ++ph) row[3 + ph] = (_Float16)(phase == ph ? 1.f : 0.f);
+                } else {
+                    const float* src = planes + (n0 + s) * 396 + p;
+#pragma unroll
+                    for (int ch = 0; ch < 11; ++ch) row[ch] = (_Float16)src[ch * 36];
+                }
             }
             h8* dst = reinterpret_cast<h8*>(lds + K::ACT_OFF + n * K::STRIDE);
 #pragma unroll
@@ -459,14 +476,14 @@ __global__ __launch_bounds__(512, 2) void net_forward_kernel(NetParams P, const 
 }
 
 template <int C, int S>
-int launch_net(const NetParams& P, const float* planes, int64_t N, float* lp1, float* lp2, float* lpm,
-               float* vlogits, float* value, int max_blocks, hipStream_t st) {
+int launch_net(const NetParams& P, const float* planes, const uint64_t* packed, int64_t N, float* lp1, float* lp2,
+               float* lpm, float* vlogits, float* value, int max_blocks, hipStream_t st) {
     using K = Cfg<C, S>;
     auto kern = net_forward_kernel<C, S>;
     const int64_t n_pass = (N + S - 1) / S;
     int grid = (int)(n_pass < max_blocks ? n_pass : max_blocks);
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(K::THREADS), K::LDS_BYTES, st, P, planes, N, lp1, lp2, lpm, vlogits, value);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(K::THREADS), K::LDS_BYTES, st, P, planes, packed, N, lp1, lp2, lpm, vlogits, value);
     return hipGetLastError() == hipSuccess ? LZ_OK : LZ_ERR_LAUNCH;
 }
 
@@ -526,11 +543,11 @@ int lz_net_configure(void) {
     return a != LZ_OK ? a : b;
 }
 
-int lz_net_forward_f16(const LzNetDesc* d, const float* planes, int64_t N, float* lp1, float* lp2, float* lpmc,
-                       float* value_logits, float* value, void* stream) {
+static int net_forward_impl(const LzNetDesc* d, const float* planes, const uint64_t* packed, int64_t N, float* lp1,
+                            float* lp2, float* lpmc, float* value_logits, float* value, void* stream) {
     if (!d || N < 0) return LZ_ERR_ARG;
     if (N == 0) return LZ_OK;
-    if (!d->wfrag || !d->fparams || !planes || !lp1 || !lp2 || !lpmc) return LZ_ERR_ARG;
+    if (!d->wfrag || !d->fparams || (!planes && !packed) || !lp1 || !lp2 || !lpmc) return LZ_ERR_ARG;
     if (d->blocks < 0 || d->blocks > 15 || d->num_layers != 2 + 2 * d->blocks) return LZ_ERR_ARG;
     if ((reinterpret_cast<uintptr_t>(d->wfrag) & 15) || (reinterpret_cast<uintptr_t>(d->fparams) & 15)) return LZ_ERR_ALIGN;
     NetParams P;
@@ -549,10 +566,21 @@ int lz_net_forward_f16(const LzNetDesc* d, const float* planes, int64_t N, float
     const bool prof = g_prof.on && g_prof.used < NetProf::kMax;
     if (prof) (void)hipEventRecord(g_prof.ev[2 * g_prof.used], st);
     const int rc = d->channels == 64
-                       ? launch_net<64, 16>(P, planes, N, lp1, lp2, lpmc, value_logits, value, max_blocks, st)
-                       : launch_net<128, 8>(P, planes, N, lp1, lp2, lpmc, value_logits, value, max_blocks, st);
+                       ? launch_net<64, 16>(P, planes, packed, N, lp1, lp2, lpmc, value_logits, value, max_blocks, st)
+                       : launch_net<128, 8>(P, planes, packed, N, lp1, lp2, lpmc, value_logits, value, max_blocks, st);
     if (prof) { (void)hipEventRecord(g_prof.ev[2 * g_prof.used + 1], st); g_prof.used += 1; g_prof.evals += N; }
     return rc;
+}
+
+int lz_net_forward_f16(const LzNetDesc* d, const float* planes, int64_t N, float* lp1, float* lp2, float* lpmc,
+                       float* value_logits, float* value, void* stream) {
+    return net_forward_impl(d, planes, nullptr, N, lp1, lp2, lpmc, value_logits, value, stream);
+}
+
+int lz_net_forward_packed_f16(const LzNetDesc* d, const void* packed_states, int64_t N, float* lp1, float* lp2,
+                              float* lpmc, float* value_logits, float* value, void* stream) {
+    return net_forward_impl(d, nullptr, reinterpret_cast<const uint64_t*>(packed_states), N, lp1, lp2, lpmc,
+                            value_logits, value, stream);
 }
 
 }  // extern "C"

@@ -33,8 +33,7 @@ class LzTreeDesc(C.Structure):
     _fields_ = [("num_games", C.c_int64), ("node_cap", C.c_int32), ("edge_cap", C.c_int32), ("path_cap", C.c_int32),
                 ("reserved", C.c_int32), ("exploration_weight", C.c_double)] + \
                [(n, C.c_void_p) for n in (
-                   "root_state", "node_state", "node_edge_begin", "node_nedges", "edge_w", "edge_p", "edge_n",
-                   "edge_child", "edge_action", "edge_info", "n_nodes", "n_edges", "root_visits", "root_w",
+                   "root_state", "nodes", "edges", "n_nodes", "n_edges", "root_visits", "root_w",
                    "root_init_value", "path", "path_len", "leaf_kind", "leaf_state", "leaf_value", "root_terminal",
                    "active")]
 
@@ -51,11 +50,9 @@ class TreeEngine:
         self.path_cap = self.max_sims + 3
         z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)
         self.buf: Dict[str, torch.Tensor] = {
-            "root_state": z((B, 4), torch.int64), "node_state": z((B * self.node_cap, 4), torch.int64),
-            "node_edge_begin": z((B * self.node_cap,), torch.int32), "node_nedges": z((B * self.node_cap,), torch.int32),
-            "edge_w": z((B * self.edge_cap,), torch.float64), "edge_p": z((B * self.edge_cap,), torch.float32),
-            "edge_n": z((B * self.edge_cap,), torch.int32), "edge_child": z((B * self.edge_cap,), torch.int32),
-            "edge_action": z((B * self.edge_cap,), torch.uint8), "edge_info": z((B * self.edge_cap,), torch.uint8),
+            "root_state": z((B, 4), torch.int64),
+            "nodes": z((B * self.node_cap, 6), torch.int64),            # 48-byte node records
+            "edges": z((B * self.edge_cap, 3), torch.int64),            # 24-byte edge records
             "n_nodes": z((B,), torch.int32), "n_edges": z((B,), torch.int32), "root_visits": z((B,), torch.int32),
             "root_w": z((B,), torch.float64), "root_init_value": z((B,), torch.float32),
             "path": z((B * self.path_cap,), torch.int32), "path_len": z((B,), torch.int32),
