@@ -175,6 +175,8 @@ typedef struct LzNetDesc {
     int32_t max_blocks;          /* persistent grid size (0 = 256, one workgroup per CU) */
     const void* wfrag;           /* device, fp16 */
     const float* fparams;        /* device, fp32 */
+    int64_t wfrag_bytes;         /* sizes of the two buffers (bounds of the kernel's buffer descriptors) */
+    int64_t fparams_bytes;
     int32_t layer_offsets[32];
     int32_t head_frag_offsets[4]; /* halfs: gpool_linear [64x192], fc1 [128x192], fc2 [112x128], out convs [16x64] */
     int32_t off_stem_bias, off_block0 /* a1|b1|bias1 per block, 3*C floats each */, off_trunk_a, off_trunk_b,

@@ -26,6 +26,21 @@ namespace {
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef float f4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+
+// Weights and per-channel parameters are read through buffer resources: the address is
+// {SGPR descriptor, SGPR byte offset (wave-uniform: layer / K step / tile), one VGPR lane offset}, so the
+// unrolled K loops need no 64-bit per-lane pointer arithmetic and nothing loop-invariant to hoist and spill.
+struct Rsrc { __amdgpu_buffer_rsrc_t w, f; };
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, int bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ h8 load_wfrag(__amdgpu_buffer_rsrc_t r, int lane_off, int byte_off) {
+    return __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(r, lane_off, byte_off, 0));
+}
+__device__ __forceinline__ f4 load_f4(__amdgpu_buffer_rsrc_t r, int lane_float_off, int float_off) {
+    return __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(r, lane_float_off * 4, float_off * 4, 0));
+}
 
 constexpr int kHead = 64;      // policy / value head channels
 constexpr int kMlp = 128;
@@ -37,6 +52,7 @@ struct NetParams {
     const float* fp;
     int layer_off[32];          // offsets in halfs: stem, (conv1, conv2) x blocks, heads
     int hf_gw, hf_w1, hf_w2, hf_out;   // offsets in halfs of the head FC fragments (gpool_linear, fc1, fc2, 3 out convs)
+    int wfrag_bytes, fparams_bytes;
     int blocks;
     // float-parameter offsets
     int stem_bias, blk0, trunk_a, trunk_b, head_bias, p_gwT, p_a2, p_b2, p_out, v_w1T, v_b1, v_w2T, v_b2;
@@ -55,8 +71,12 @@ struct Cfg {
     static constexpr int KB = C / 32;               // 32-channel K blocks
     static constexpr int KBLOG = (KB == 1) ? 0 : (KB == 2) ? 1 : 2;
     static constexpr int STRIDE = C * 2 + 16;       // bytes per cell row (16-byte aligned, bank-skewed)
+    // Zero-bordered board: cell (r,c) of sample s sits at row 58*s + 1 + 7*(r+1) + c; one shared zero column
+    // between board rows and zero rows above/below make every 3x3 tap an in-bounds read at a CONSTANT byte
+    // offset from the top-left neighbour -> the tap offset is folded into the ds_read immediate, no VALU.
+    static constexpr int CELLS = 58;
     static constexpr int ACT_OFF = 0;
-    static constexpr int ZERO_OFF = NPOS * STRIDE;
+    static constexpr int ZERO_OFF = S * CELLS * STRIDE;
     // head scratch: fp16 rows for the MFMA B operand (16 sample columns), fp32 for scalar epilogues
     static constexpr int POOL_STRIDE = kPool * 2 + 16;              // 400 B per sample row
     static constexpr int HID_STRIDE = kMlp * 2 + 16;                // 272 B per sample row
@@ -73,33 +93,37 @@ struct Cfg {
     static_assert(NT % 9 == 0 && PG * CG == WAVES, "8 waves per workgroup");
 };
 
+// byte address of 16-byte chunk `chunk` of board cell n (n = 36*sample + 6*r + c)
+template <int C, int S>
+__device__ __forceinline__ int act_addr(int n, int chunk) {
+    using K = Cfg<C, S>;
+    const int s = n / 36, p = n - s * 36;
+    const int r = p / 6, c = p - r * 6;
+    return K::ACT_OFF + (s * K::CELLS + 1 + 7 * (r + 1) + c) * K::STRIDE + (chunk << 4);
+}
+
 // ---- the GEMM core: acc[9 cell tiles][4 channel tiles] += W(layer) * act --------------------------------
 // Register budget (one wave per SIMD, 512 registers): 288 accumulators (residual stream + conv1 output),
 // weight fragments double-buffered across K steps (2 x 4 x 4), activation fragments in a 2-deep ring
 // that runs one cell tile ahead of the MFMAs.
-template <int C, int S, bool TAPS9, bool STEM>
-__device__ __forceinline__ void step_geometry(int step, int& tap, int& off, int& zoff) {
-    using K = Cfg<C, S>;
-    int kb;
-    if (!TAPS9) { tap = 4; kb = step; }
-    else if (STEM) { tap = step; kb = 0; }
-    else { tap = step >> K::KBLOG; kb = step & (K::KB - 1); }
-    const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
-    off = (dy * 6 + dx) * K::STRIDE + kb * 64;
-    zoff = kb * 64;
-}
-
 typedef f4 Acc[9][2];
 
+// byte offset of K step `step` relative to the top-left neighbour's row (compile-time after unrolling)
 template <int C, int S, bool TAPS9, bool STEM>
-__device__ __forceinline__ void gemm_step(Acc& acc, const h8 (&A)[2], int step, const unsigned char* lds,
-                                          const int (&base)[9], const int (&valid)[9], int zero_addr) {
-    int tap, off, zoff;
-    step_geometry<C, S, TAPS9, STEM>(step, tap, off, zoff);
-    const int za = zero_addr + zoff;
+__device__ __forceinline__ constexpr int step_offset(int step) {
+    using K = Cfg<C, S>;
+    const int tap = !TAPS9 ? 4 : (STEM ? step : step / K::KB);
+    const int kb = !TAPS9 ? step : (STEM ? 0 : step % K::KB);
+    return ((tap / 3) * 7 + (tap % 3)) * K::STRIDE + kb * 64;
+}
+
+// One K step: 9 activation fragments (ds_read_b128 at base[i] + immediate) x 2 weight fragments -> 18 MFMAs.
+template <int C, int S, bool TAPS9, bool STEM, int STEP>
+__device__ __forceinline__ void gemm_step(Acc& acc, const h8 (&A)[2], const unsigned char* lds, const int (&base)[9]) {
+    constexpr int off = step_offset<C, S, TAPS9, STEM>(STEP);
     h8 B[9];
 #pragma unroll
-    for (int i = 0; i < 9; ++i) B[i] = *reinterpret_cast<const h8*>(lds + (((valid[i] >> tap) & 1) ? (base[i] + off) : za));
+    for (int i = 0; i < 9; ++i) B[i] = *reinterpret_cast<const h8*>(lds + base[i] + off);
     __builtin_amdgcn_sched_barrier(0);                   // all 9 reads in flight before the first MFMA
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
@@ -108,31 +132,40 @@ __device__ __forceinline__ void gemm_step(Acc& acc, const h8 (&A)[2], int step, 
     }
 }
 
-// Two waves per SIMD hide each other's LDS latency; the weight fragments (L2) are prefetched one K step
-// ahead in registers.
-template <int C, int S, bool TAPS9, bool STEM>
-__device__ __forceinline__ void conv_gemm(Acc& acc, const h8* __restrict__ wl, int ctn, int ct0,
-                                          const unsigned char* lds, const int (&base)[9], const int (&valid)[9],
-                                          int zero_addr, int lane) {
+template <int C, int S, bool TAPS9, bool STEM, int CTN, int STEP, int NSTEPS>
+struct GemmSteps {
+    static __device__ __forceinline__ void run(Acc& acc, h8 (&A0)[2], h8 (&A1)[2], __amdgpu_buffer_rsrc_t rw, int wbyte,
+                                               int lane16, const unsigned char* lds, const int (&base)[9]) {
+        // weight fragments (L2) are prefetched one K step ahead into the other register pair
+        if (STEP + 1 < NSTEPS) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) A1[j] = load_wfrag(rw, lane16, wbyte + ((STEP + 1) * CTN + j) * 1024);
+        }
+        gemm_step<C, S, TAPS9, STEM, STEP>(acc, A0, lds, base);
+        GemmSteps<C, S, TAPS9, STEM, CTN, STEP + 1, NSTEPS>::run(acc, A1, A0, rw, wbyte, lane16, lds, base);
+    }
+};
+template <int C, int S, bool TAPS9, bool STEM, int CTN, int NSTEPS>
+struct GemmSteps<C, S, TAPS9, STEM, CTN, NSTEPS, NSTEPS> {
+    static __device__ __forceinline__ void run(Acc&, h8 (&)[2], h8 (&)[2], __amdgpu_buffer_rsrc_t, int, int,
+                                               const unsigned char*, const int (&)[9]) {}
+};
+
+// Fully unrolled over the K steps (9 taps x C/32 blocks): every LDS read offset is an immediate and every
+// weight address is {descriptor, scalar offset, lane offset}, so a step is 9 ds_read + 2 buffer_load +
+// 18 MFMA and nothing else.  Two waves per SIMD hide each other's LDS latency.
+// `layer_half_off` = offset of the layer in halfs, ct0 = first output tile of this wave (both wave-uniform).
+template <int C, int S, bool TAPS9, bool STEM, int CTN>
+__device__ __forceinline__ void conv_gemm(Acc& acc, __amdgpu_buffer_rsrc_t rw, int layer_half_off, int ct0,
+                                          const unsigned char* lds, const int (&base)[9], int lane) {
     using K = Cfg<C, S>;
     constexpr int nsteps = TAPS9 ? (STEM ? 9 : 9 * K::KB) : K::KB;
-    const h8* wp = wl + (size_t)ct0 * 64 + lane;
-    const int wstride = ctn * 64;                        // h8 elements per K step
+    const int wbyte = __builtin_amdgcn_readfirstlane(layer_half_off * 2 + ct0 * 1024);
+    const int lane16 = lane * 16;
     h8 A0[2], A1[2];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) A0[j] = wp[j * 64];
-#pragma unroll 1
-    for (int step = 0; step + 1 < nsteps; step += 2) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) A1[j] = wp[(size_t)(step + 1) * wstride + j * 64];
-        gemm_step<C, S, TAPS9, STEM>(acc, A0, step, lds, base, valid, zero_addr);
-        if (step + 2 < nsteps) {
-#pragma unroll
-            for (int j = 0; j < 2; ++j) A0[j] = wp[(size_t)(step + 2) * wstride + j * 64];
-        }
-        gemm_step<C, S, TAPS9, STEM>(acc, A1, step + 1, lds, base, valid, zero_addr);
-    }
-    if (nsteps & 1) gemm_step<C, S, TAPS9, STEM>(acc, A0, nsteps - 1, lds, base, valid, zero_addr);
+    for (int j = 0; j < 2; ++j) A0[j] = load_wfrag(rw, lane16, wbyte + j * 1024);
+    GemmSteps<C, S, TAPS9, STEM, CTN, 0, nsteps>::run(acc, A0, A1, rw, wbyte, lane16, lds, base);
 }
 
 __device__ __forceinline__ h4 to_h4(float a, float b, float c, float d) {
@@ -144,15 +177,14 @@ __device__ __forceinline__ h4 to_h4(float a, float b, float c, float d) {
 // write relu(scale*acc + shift) (per channel) as fp16 rows; `chan_base` = first channel of co tile 0
 template <int C, int S, bool HAS_SCALE>
 __device__ __forceinline__ void store_act(const Acc& acc, unsigned char* lds, int tile0, int chan_base,
-                                          const float* __restrict__ scale, const float* __restrict__ shift, int lane) {
+                                          __amdgpu_buffer_rsrc_t rf, int scale_off, int shift_off, int lane) {
     using K = Cfg<C, S>;
     const int sub = (lane >> 4) * 4;
     f4 sc[2], sh[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        const int ch = chan_base + j * 16 + sub;
-        sh[j] = *reinterpret_cast<const f4*>(shift + ch);
-        if (HAS_SCALE) sc[j] = *reinterpret_cast<const f4*>(scale + ch);
+        sh[j] = load_f4(rf, sub, shift_off + chan_base + j * 16);
+        if (HAS_SCALE) sc[j] = load_f4(rf, sub, scale_off + chan_base + j * 16);
     }
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
@@ -162,7 +194,8 @@ __device__ __forceinline__ void store_act(const Acc& acc, unsigned char* lds, in
             f4 v = acc[i][j];
             if (HAS_SCALE) v = v * sc[j] + sh[j]; else v = v + sh[j];
             const h4 o = to_h4(fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f));
-            *reinterpret_cast<h4*>(lds + K::ACT_OFF + n * K::STRIDE + (chan_base + j * 16 + sub) * 2) = o;
+            const int ch = chan_base + j * 16 + sub;
+            *reinterpret_cast<h4*>(lds + act_addr<C, S>(n, ch >> 3) + (ch & 7) * 2) = o;
         }
     }
 }
@@ -176,7 +209,7 @@ __device__ __forceinline__ void gpool64(unsigned char* lds, int tid) {
         float sum[4] = {0.f, 0.f, 0.f, 0.f}, mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
 #pragma unroll 6
         for (int p = 0; p < 36; ++p) {
-            const h4 v = *reinterpret_cast<const h4*>(lds + K::ACT_OFF + (s * 36 + p) * K::STRIDE + cq * 8);
+            const h4 v = *reinterpret_cast<const h4*>(lds + act_addr<C, S>(s * 36 + p, cq >> 1) + (cq & 1) * 8);
 #pragma unroll
             for (int k = 0; k < 4; ++k) { const float f = (float)v[k]; sum[k] += f; mx[k] = fmaxf(mx[k], f); }
         }
@@ -185,7 +218,7 @@ __device__ __forceinline__ void gpool64(unsigned char* lds, int tid) {
         for (int k = 0; k < 4; ++k) mean[k] = sum[k] * (1.0f / 36.0f);
 #pragma unroll 6
         for (int p = 0; p < 36; ++p) {
-            const h4 v = *reinterpret_cast<const h4*>(lds + K::ACT_OFF + (s * 36 + p) * K::STRIDE + cq * 8);
+            const h4 v = *reinterpret_cast<const h4*>(lds + act_addr<C, S>(s * 36 + p, cq >> 1) + (cq & 1) * 8);
 #pragma unroll
             for (int k = 0; k < 4; ++k) { const float d = (float)v[k] - mean[k]; var[k] += d * d; }
         }
@@ -199,22 +232,25 @@ __device__ __forceinline__ void gpool64(unsigned char* lds, int tid) {
 }
 
 // small dense layer on the matrix cores: D[16 outputs of tile ct][16 samples] = W(ct) * rows, K = 32*kbn
-__device__ __forceinline__ f4 fc_tile(const h8* __restrict__ wfrag, int ctn, int ct, int kbn,
+template <int CTN, int KBN>
+__device__ __forceinline__ f4 fc_tile(__amdgpu_buffer_rsrc_t rw, int half_off, int ct,
                                       const unsigned char* rows, int row_stride, int lane) {
     f4 d = (f4){0.f, 0.f, 0.f, 0.f};
     const unsigned char* bp = rows + (lane & 15) * row_stride + (lane >> 4) * 16;
-    for (int kb = 0; kb < kbn; ++kb) {
-        const h8 a = wfrag[(size_t)(kb * ctn + ct) * 64 + lane];
-        const h8 b = *reinterpret_cast<const h8*>(bp + kb * 64);
-        d = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, d, 0, 0, 0);
-    }
+    const int wbyte = __builtin_amdgcn_readfirstlane(half_off * 2 + ct * 1024);
+    h8 a[KBN];
+#pragma unroll
+    for (int kb = 0; kb < KBN; ++kb) a[kb] = load_wfrag(rw, lane * 16, wbyte + kb * CTN * 1024);
+#pragma unroll
+    for (int kb = 0; kb < KBN; ++kb)
+        d = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[kb], *reinterpret_cast<const h8*>(bp + kb * 64), d, 0, 0, 0);
     return d;
 }
 
 // write one head map (64 channels wide) from a wave's 2 output tiles: channel = (tile_in_map*16) + ...
 template <int C, int S>
 __device__ __forceinline__ void store_head(const Acc& acc, unsigned char* lds, int tile0, int map_tile0,
-                                           const float* __restrict__ bias, int lane) {
+                                           __amdgpu_buffer_rsrc_t rf, int bias_off, int lane) {
     using K = Cfg<C, S>;
     const int sub = (lane >> 4) * 4;
 #pragma unroll
@@ -223,9 +259,9 @@ __device__ __forceinline__ void store_head(const Acc& acc, unsigned char* lds, i
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int ch = (map_tile0 + j) * 16 + sub;
-            const f4 b = *reinterpret_cast<const f4*>(bias + ch);
+            const f4 b = load_f4(rf, sub, bias_off + (map_tile0 + j) * 16);
             const f4 v = acc[i][j] + b;
-            *reinterpret_cast<h4*>(lds + K::ACT_OFF + n * K::STRIDE + ch * 2) =
+            *reinterpret_cast<h4*>(lds + act_addr<C, S>(n, ch >> 3) + (ch & 7) * 2) =
                 to_h4(fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f));
         }
     }
@@ -248,25 +284,18 @@ __global__ __launch_bounds__(512, 2) void net_forward_kernel(NetParams P, const 
     const int ct0 = cg * K::CTW;                 // first output-channel tile of this wave
     const int chan0 = ct0 * 16;
     const float* fp = P.fp;
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc(P.wfrag, P.wfrag_bytes);
+    const __amdgpu_buffer_rsrc_t rf = make_rsrc(P.fp, P.fparams_bytes);
 
     // per-lane cell geometry of the 9 tiles
-    int base[9], valid[9];
+    int base[9];                                         // top-left neighbour of the lane's cell, + the lane's K chunk
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
         const int n = (tile0 + i) * 16 + (lane & 15);
-        const int p = n % 36;
-        const int r = p / 6, c = p - r * 6;
-        base[i] = K::ACT_OFF + n * K::STRIDE + (lane >> 4) * 16;
-        int m = 0;
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const int rr = r + t / 3 - 1, cc = c + t % 3 - 1;
-            m |= (rr >= 0 && rr < 6 && cc >= 0 && cc < 6) ? (1 << t) : 0;
-        }
-        valid[i] = m;
+        base[i] = act_addr<C, S>(n, lane >> 4) - 8 * K::STRIDE;
     }
-    const int zero_addr = K::ZERO_OFF + (lane >> 4) * 16;
-    for (int i = tid; i < K::STRIDE / 4; i += NTHR) reinterpret_cast<uint32_t*>(lds + K::ZERO_OFF)[i] = 0u;
+    // zero the whole activation buffer once: the board borders stay zero for every layer / pass
+    for (int i = tid; i < K::ZERO_OFF / 16; i += NTHR) reinterpret_cast<uint4*>(lds + K::ACT_OFF)[i] = make_uint4(0, 0, 0, 0);
     float* gvec = reinterpret_cast<float*>(lds + K::G_OFF);
     float* plog = reinterpret_cast<float*>(lds + K::PLOG_OFF);
     float* par = reinterpret_cast<float*>(lds + K::PAR_OFF);
@@ -311,13 +340,12 @@ __global__ __launch_bounds__(512, 2) void net_forward_kernel(NetParams P, const 
                     for (int ch = 0; ch < 11; ++ch) row[ch] = (_Float16)src[ch * 36];
                 }
             }
-            h8* dst = reinterpret_cast<h8*>(lds + K::ACT_OFF + n * K::STRIDE);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 h8 v;
 #pragma unroll
                 for (int k = 0; k < 8; ++k) v[k] = row[q * 8 + k];
-                dst[q] = v;
+                *reinterpret_cast<h8*>(lds + act_addr<C, S>(n, q)) = v;
             }
         }
         __syncthreads();
@@ -328,13 +356,12 @@ __global__ __launch_bounds__(512, 2) void net_forward_kernel(NetParams P, const 
 #pragma unroll
             for (int j = 0; j < 2; ++j) x[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
         // ---- stem: x = relu(conv(planes) + bias) ----
-        conv_gemm<C, S, true, true>(x, reinterpret_cast<const h8*>(P.wfrag + P.layer_off[0]), K::CT, ct0, lds, base,
-                                    valid, zero_addr, lane);
+        conv_gemm<C, S, true, true, K::CT>(x, rw, P.layer_off[0], ct0, lds, base, lane);
         {
             const int sub = (lane >> 4) * 4;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const f4 b = *reinterpret_cast<const f4*>(fp + P.stem_bias + chan0 + j * 16 + sub);
+                const f4 b = load_f4(rf, sub, P.stem_bias + chan0 + j * 16);
 #pragma unroll
                 for (int i = 0; i < 9; ++i) {
                     f4 v = x[i][j] + b;
@@ -344,27 +371,25 @@ __global__ __launch_bounds__(512, 2) void net_forward_kernel(NetParams P, const 
         }
         // ---- residual blocks ----
         for (int blk = 0; blk < P.blocks; ++blk) {
-            const float* bp = fp + P.blk0 + blk * 3 * C;
+            const int bp = P.blk0 + blk * 3 * C;               // float offsets: a1 | b1 | bias1
             __syncthreads();                                   // everyone finished reading the act buffer
-            store_act<C, S, true>(x, lds, tile0, chan0, bp, bp + C, lane);             // t = relu(a1*x + b1)
+            store_act<C, S, true>(x, lds, tile0, chan0, rf, bp, bp + C, lane);         // t = relu(a1*x + b1)
             __syncthreads();
 #pragma unroll
             for (int i = 0; i < 9; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
-            conv_gemm<C, S, true, false>(acc, reinterpret_cast<const h8*>(P.wfrag + P.layer_off[1 + 2 * blk]), K::CT,
-                                         ct0, lds, base, valid, zero_addr, lane);
+            conv_gemm<C, S, true, false, K::CT>(acc, rw, P.layer_off[1 + 2 * blk], ct0, lds, base, lane);
             __syncthreads();
-            store_act<C, S, false>(acc, lds, tile0, chan0, nullptr, bp + 2 * C, lane);  // u = relu(conv1 + bias1)
+            store_act<C, S, false>(acc, lds, tile0, chan0, rf, 0, bp + 2 * C, lane);   // u = relu(conv1 + bias1)
             __syncthreads();
-            conv_gemm<C, S, true, false>(x, reinterpret_cast<const h8*>(P.wfrag + P.layer_off[2 + 2 * blk]), K::CT,
-                                         ct0, lds, base, valid, zero_addr, lane);       // x += conv2(u)
+            conv_gemm<C, S, true, false, K::CT>(x, rw, P.layer_off[2 + 2 * blk], ct0, lds, base, lane);  // x += conv2(u)
         }
         // ---- trunk output h = relu(a*x + b) -> LDS; head 1x1 convs (8 output tiles: policy 0..3 | value 4..7) ----
         __syncthreads();
-        store_act<C, S, true>(x, lds, tile0, chan0, fp + P.trunk_a, fp + P.trunk_b, lane);
+        store_act<C, S, true>(x, lds, tile0, chan0, rf, P.trunk_a, P.trunk_b, lane);
         __syncthreads();
-        const h8* wh = reinterpret_cast<const h8*>(P.wfrag + P.layer_off[1 + 2 * P.blocks]);
+        const int wh = P.layer_off[1 + 2 * P.blocks];
 #pragma unroll
         for (int i = 0; i < 9; ++i)
 #pragma unroll
@@ -372,17 +397,16 @@ __global__ __launch_bounds__(512, 2) void net_forward_kernel(NetParams P, const 
         // pass 0 -> acc, pass 1 (only when 4 waves' worth of tiles cover half of the 8 head tiles) -> x
         const int ht0 = cg * K::CTW;                               // head tile of acc   (0..7)
         const int ht1 = K::CG * K::CTW + cg * K::CTW;              // head tile of x     (HP == 2 only)
-        conv_gemm<C, S, false, false>(acc, wh, 8, ht0, lds, base, valid, zero_addr, lane);
-        if (K::HP == 2) conv_gemm<C, S, false, false>(x, wh, 8, ht1, lds, base, valid, zero_addr, lane);
+        conv_gemm<C, S, false, false, 8>(acc, rw, wh, ht0, lds, base, lane);
+        if (K::HP == 2) conv_gemm<C, S, false, false, 8>(x, rw, wh, ht1, lds, base, lane);
         __syncthreads();
         // ---- policy head ----
-        if (ht0 < 4) store_head<C, S>(acc, lds, tile0, ht0, fp + P.head_bias, lane);
+        if (ht0 < 4) store_head<C, S>(acc, lds, tile0, ht0, rf, P.head_bias, lane);
         __syncthreads();
         gpool64<C, S>(lds, tid);
         __syncthreads();
         if (wave < 4) {                                            // g = gpool_linear(pooled): 4 tiles x K=192
-            const f4 d = fc_tile(reinterpret_cast<const h8*>(P.wfrag + P.hf_gw), 4, wave, 6, lds + K::POOL_OFF,
-                                 K::POOL_STRIDE, lane);
+            const f4 d = fc_tile<4, 6>(rw, P.hf_gw, wave, lds + K::POOL_OFF, K::POOL_STRIDE, lane);
             const int s = lane & 15, ch = wave * 16 + (lane >> 4) * 4;
             *reinterpret_cast<f4*>(gvec + s * kHead + ch) = d;
         }
@@ -390,7 +414,7 @@ __global__ __launch_bounds__(512, 2) void net_forward_kernel(NetParams P, const 
         for (int it = tid; it < K::NPOS * 8; it += NTHR) {          // p2 = relu(bn2(p + g)) in place
             const int n = it >> 3, c8 = it & 7;
             const int s = n / 36;
-            h8* ptr = reinterpret_cast<h8*>(lds + K::ACT_OFF + n * K::STRIDE + c8 * 16);
+            h8* ptr = reinterpret_cast<h8*>(lds + act_addr<C, S>(n, c8));
             h8 v = *ptr;
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
@@ -401,13 +425,13 @@ __global__ __launch_bounds__(512, 2) void net_forward_kernel(NetParams P, const 
         }
         __syncthreads();
         for (int t = wave; t < K::NT; t += K::WAVES) {              // three 1x1 output convs: 1 tile x K=64
-            const h8* wo = reinterpret_cast<const h8*>(P.wfrag + P.hf_out);
             f4 d = (f4){0.f, 0.f, 0.f, 0.f};
             const int n = t * 16 + (lane & 15);
-            const unsigned char* bp = lds + K::ACT_OFF + n * K::STRIDE + (lane >> 4) * 16;
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
-                d = __builtin_amdgcn_mfma_f32_16x16x32_f16(wo[kb * 64 + lane], *reinterpret_cast<const h8*>(bp + kb * 64), d, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_16x16x32_f16(
+                    load_wfrag(rw, lane * 16, P.hf_out * 2 + kb * 1024),
+                    *reinterpret_cast<const h8*>(lds + act_addr<C, S>(n, kb * 4 + (lane >> 4))), d, 0, 0, 0);
             if (lane < 16) {
                 const int s = n / 36, p = n - s * 36;
                 plog[(s * 3 + 0) * 36 + p] = d[0];
@@ -430,16 +454,15 @@ __global__ __launch_bounds__(512, 2) void net_forward_kernel(NetParams P, const 
         }
         __syncthreads();
         // ---- value head ----
-        if (K::HP == 2) store_head<C, S>(x, lds, tile0, ht1 - 4, fp + P.head_bias + kHead, lane);
-        else if (ht0 >= 4) store_head<C, S>(acc, lds, tile0, ht0 - 4, fp + P.head_bias + kHead, lane);
+        if (K::HP == 2) store_head<C, S>(x, lds, tile0, ht1 - 4, rf, P.head_bias + kHead, lane);
+        else if (ht0 >= 4) store_head<C, S>(acc, lds, tile0, ht0 - 4, rf, P.head_bias + kHead, lane);
         __syncthreads();
         gpool64<C, S>(lds, tid);
         __syncthreads();
         {                                                           // fc1 + relu: 8 tiles x K=192, one per wave
-            const f4 d = fc_tile(reinterpret_cast<const h8*>(P.wfrag + P.hf_w1), 8, wave, 6, lds + K::POOL_OFF,
-                                 K::POOL_STRIDE, lane);
+            const f4 d = fc_tile<8, 6>(rw, P.hf_w1, wave, lds + K::POOL_OFF, K::POOL_STRIDE, lane);
             const int s = lane & 15, ch = wave * 16 + (lane >> 4) * 4;
-            const f4 b = *reinterpret_cast<const f4*>(fp + P.v_b1 + ch);
+            const f4 b = load_f4(rf, (lane >> 4) * 4, P.v_b1 + wave * 16);
             const f4 v = d + b;
             *reinterpret_cast<h4*>(lds + K::HID_OFF + s * K::HID_STRIDE + ch * 2) =
                 to_h4(fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f));
@@ -447,8 +470,7 @@ __global__ __launch_bounds__(512, 2) void net_forward_kernel(NetParams P, const 
         __syncthreads();
         float* vl = plog;                                           // [16][112] value logits
         if (wave < 7) {                                             // fc2: 7 tiles (101 bins padded to 112) x K=128
-            const f4 d = fc_tile(reinterpret_cast<const h8*>(P.wfrag + P.hf_w2), 7, wave, 4, lds + K::HID_OFF,
-                                 K::HID_STRIDE, lane);
+            const f4 d = fc_tile<7, 4>(rw, P.hf_w2, wave, lds + K::HID_OFF, K::HID_STRIDE, lane);
             const int s = lane & 15, o = wave * 16 + (lane >> 4) * 4;
 #pragma unroll
             for (int r = 0; r < 4; ++r)
@@ -555,6 +577,7 @@ static int net_forward_impl(const LzNetDesc* d, const float* planes, const uint6
     P.fp = d->fparams;
     for (int i = 0; i < d->num_layers; ++i) P.layer_off[i] = d->layer_offsets[i];
     P.blocks = d->blocks;
+    P.wfrag_bytes = (int)d->wfrag_bytes; P.fparams_bytes = (int)d->fparams_bytes;
     P.hf_gw = d->head_frag_offsets[0]; P.hf_w1 = d->head_frag_offsets[1]; P.hf_w2 = d->head_frag_offsets[2];
     P.hf_out = d->head_frag_offsets[3];
     P.stem_bias = d->off_stem_bias; P.blk0 = d->off_block0; P.trunk_a = d->off_trunk_a; P.trunk_b = d->off_trunk_b;

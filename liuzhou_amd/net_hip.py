@@ -19,7 +19,8 @@ from .net_pack import NetPack, pack_model, BINS
 
 class LzNetDesc(C.Structure):
     _fields_ = [("channels", C.c_int32), ("blocks", C.c_int32), ("num_layers", C.c_int32), ("max_blocks", C.c_int32),
-                ("wfrag", C.c_void_p), ("fparams", C.c_void_p), ("layer_offsets", C.c_int32 * 32),
+                ("wfrag", C.c_void_p), ("fparams", C.c_void_p), ("wfrag_bytes", C.c_int64), ("fparams_bytes", C.c_int64),
+                ("layer_offsets", C.c_int32 * 32),
                 ("head_frag_offsets", C.c_int32 * 4)] + \
                [(n, C.c_int32) for n in ("off_stem_bias", "off_block0", "off_trunk_a", "off_trunk_b", "off_head_bias",
                                          "off_p_gwT", "off_p_a2", "off_p_b2", "off_p_out", "off_v_w1T", "off_v_b1",
@@ -44,6 +45,8 @@ class FusedNet:
         d.num_layers = len(self.pack.layer_offsets)
         d.max_blocks = int(max_blocks)
         d.wfrag, d.fparams = self.pack.wfrag.data_ptr(), self.pack.fparams.data_ptr()
+        d.wfrag_bytes = int(self.pack.wfrag.numel()) * 2
+        d.fparams_bytes = int(self.pack.fparams.numel()) * 4
         for i, o in enumerate(self.pack.layer_offsets):
             d.layer_offsets[i] = int(o)
         for i, o in enumerate(self.pack.head_offsets):
