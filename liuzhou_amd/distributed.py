@@ -1,0 +1,87 @@
+"""Sharding self-play over the GPUs of one node + the once-per-iteration exchanges.
+
+Games are independent, so ranks never talk while playing (v1/train.py:932-1020 shards by files; here one
+process per GPU under torch.distributed).  Two collectives exist, both outside the hot loop:
+  * gather_trajectories(): variable-length trajectory batches -> rank 0 (the trainer).  Counts are
+    exchanged first, then every rank sends its rows to rank 0.  On RCCL over xGMI a gather-to-one runs
+    as direct peer writes (each sender has its own link into the destination), so it is implemented with
+    batched isend/irecv (ncclSend/ncclRecv groups) rather than a ring all-gather that would be bound by a
+    single 153 GB/s link; an `all_gather` fallback exists for backends without P2P ops.
+  * broadcast_checkpoint(): the state_dict (12 MB for 10x128) rank 0 -> all.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+import torch.distributed as dist
+
+from .trajectory_buffer import TensorSelfPlayBatch
+
+_FIELDS = ("state_tensors", "legal_masks", "policy_targets", "value_targets", "soft_value_targets")
+
+
+def split_games(total_games: int, parts: int) -> List[int]:
+    """v1/train.py:129-135: base + 1 for the first `total % parts` ranks."""
+    parts, total = max(1, int(parts)), max(0, int(total_games))
+    base, rem = divmod(total, parts)
+    return [base + (1 if i < rem else 0) for i in range(parts)]
+
+
+def worker_seed(iteration_seed: int, worker_idx: int) -> int:
+    """v1/train.py:998"""
+    return int(iteration_seed) * 10007 + (int(worker_idx) + 1) * 9973
+
+
+def gather_trajectories(batch: TensorSelfPlayBatch, dst: int = 0, group=None) -> Optional[TensorSelfPlayBatch]:
+    """Concatenate every rank's samples on `dst` (rank order).  Returns None on the other ranks."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return batch
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    dev = batch.state_tensors.device
+    n_local = torch.tensor([batch.num_samples], dtype=torch.int64, device=dev)
+    counts = [torch.zeros_like(n_local) for _ in range(world)]
+    dist.all_gather(counts, n_local, group=group)
+    counts = [int(c.item()) for c in counts]
+    fields = {f: getattr(batch, f).contiguous() for f in _FIELDS}
+    if rank == dst:
+        out: Dict[str, torch.Tensor] = {}
+        total = sum(counts)
+        ops, views = [], {}
+        for f, t in fields.items():
+            buf = torch.empty((total, *t.shape[1:]), dtype=t.dtype, device=dev)
+            start = 0
+            for r in range(world):
+                if r == dst:
+                    buf[start:start + counts[r]].copy_(t)
+                elif counts[r] > 0:
+                    tgt = buf[start:start + counts[r]]
+                    if tgt.dtype == torch.bool:                      # bool is sent as uint8
+                        tmp = torch.empty(tgt.shape, dtype=torch.uint8, device=dev)
+                        views[(f, r)] = (tmp, tgt)
+                        ops.append(dist.P2POp(dist.irecv, tmp, r, group))
+                    else:
+                        ops.append(dist.P2POp(dist.irecv, tgt, r, group))
+                start += counts[r]
+            out[f] = buf
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        for (f, r), (tmp, tgt) in views.items():
+            tgt.copy_(tmp.to(torch.bool))
+        return TensorSelfPlayBatch(*(out[f] for f in _FIELDS))
+    ops = []
+    if counts[rank] > 0:
+        for f, t in fields.items():
+            ops.append(dist.P2POp(dist.isend, t.to(torch.uint8) if t.dtype == torch.bool else t, dst, group))
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    return None
+
+
+def broadcast_checkpoint(model: torch.nn.Module, src: int = 0, group=None) -> None:
+    """Rank `src`'s parameters and buffers -> every rank (checkpoint hand-off each iteration)."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    for t in list(model.parameters()) + list(model.buffers()):
+        dist.broadcast(t.data, src=src, group=group)

@@ -12,6 +12,7 @@ prepare roots -> evaluate -> complete, then sims x (select -> evaluate -> comple
 from __future__ import annotations
 
 import ctypes as C
+import os
 import time
 from typing import Dict, Optional, Tuple
 
@@ -157,12 +158,35 @@ class PortableTreeMCTS:
 
     def __init__(self, net: FusedNet, num_games: int, num_simulations: int, device, exploration_weight: float = 1.0,
                  add_dirichlet_noise: bool = True, dirichlet_alpha: float = 0.3, dirichlet_epsilon: float = 0.25,
-                 sample_moves: bool = True) -> None:
+                 sample_moves: bool = True, use_graph: Optional[bool] = None) -> None:
         self.net, self.sims = net, int(num_simulations)
         self.engine = TreeEngine(num_games, num_simulations, device, exploration_weight)
         self.add_noise, self.alpha, self.eps = bool(add_dirichlet_noise), float(dirichlet_alpha), float(dirichlet_epsilon)
         self.sample_moves = bool(sample_moves)
         self.leaf_evals = 0
+        # hipGraph: the whole search of a move (1 + sims) x (select, fused net, expand) is captured once and
+        # replayed every move; all buffers are static, noise / roots are refreshed in place before the replay.
+        if use_graph is None:
+            use_graph = os.environ.get("LZ_TREE_GRAPH", "on").strip().lower() not in ("off", "0", "false")
+        self.use_graph = bool(use_graph)
+        self._graphs = {}
+        self._noise_buf = torch.zeros((self.engine.B, OUT_CAP), dtype=torch.float32, device=self.engine.device)
+
+    def _search(self, add_noise: bool) -> None:
+        e = self.engine
+        if not self.use_graph:
+            e.search(self.net, self.sims, self._noise_buf if add_noise else None, self.eps)
+            return
+        g = self._graphs.get(add_noise)
+        if g is None:
+            # warm-up launch outside capture, then capture on a side stream as torch requires
+            e.search(self.net, self.sims, self._noise_buf if add_noise else None, self.eps)
+            torch.cuda.synchronize(e.device)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                e.search(self.net, self.sims, self._noise_buf if add_noise else None, self.eps)
+            self._graphs[add_noise] = g
+        g.replay()
 
     def search_batch(self, state: GpuStateBatch, *, temperatures: torch.Tensor, active: Optional[torch.Tensor] = None,
                      add_dirichlet_noise: Optional[bool] = None) -> RootSearchBatchOutput:
@@ -170,8 +194,9 @@ class PortableTreeMCTS:
         dev = e.device
         add_noise = self.add_noise if add_dirichlet_noise is None else bool(add_dirichlet_noise)
         e.set_roots(state, active)
-        noise = dirichlet_noise((e.B, OUT_CAP), self.alpha, dev) if add_noise else None
-        e.search(self.net, self.sims, noise, self.eps)
+        if add_noise:
+            self._noise_buf.copy_(dirichlet_noise((e.B, OUT_CAP), self.alpha, dev))
+        self._search(add_noise)
         self.leaf_evals += e.B * (self.sims + 1)
         uniforms = torch.rand((e.B,), dtype=torch.float32, device=dev) if self.sample_moves else None
         e.finish(temperatures.to(torch.float32).contiguous(), uniforms)

@@ -1,0 +1,96 @@
+"""CPU, world_size 2 over gloo: game sharding, per-rank seeds, trajectory gather to rank 0, checkpoint broadcast."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from liuzhou_amd.distributed import broadcast_checkpoint, gather_trajectories, split_games, worker_seed
+from liuzhou_amd.net import ChessNet, MODEL_CONFIGS
+from liuzhou_amd.trajectory_buffer import TensorSelfPlayBatch
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _batch(rank, n):
+    g = torch.Generator().manual_seed(100 + rank)
+    return TensorSelfPlayBatch(
+        state_tensors=(torch.rand((n, 11, 6, 6), generator=g) < 0.3).float(),
+        legal_masks=torch.rand((n, 220), generator=g) < 0.1,
+        policy_targets=torch.rand((n, 220), generator=g),
+        value_targets=torch.full((n,), float(rank + 1)),
+        soft_value_targets=torch.rand((n,), generator=g))
+
+
+def _worker(rank, world, port, counts, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        mine = _batch(rank, counts[rank])
+        got = gather_trajectories(mine, dst=0)
+        torch.manual_seed(rank)
+        model = ChessNet(**MODEL_CONFIGS["tiny"])
+        broadcast_checkpoint(model, src=0)
+        digest = float(sum(p.double().sum() for p in model.parameters()))
+        if rank == 0:
+            want = [_batch(r, counts[r]) for r in range(world)]
+            ok = got is not None and got.num_samples == sum(counts)
+            for f in ("state_tensors", "legal_masks", "policy_targets", "value_targets", "soft_value_targets"):
+                ok = ok and torch.equal(getattr(got, f), torch.cat([getattr(w, f) for w in want]))
+            q.put(("gather", ok))
+        else:
+            q.put(("none", got is None))
+        q.put(("digest", digest))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_split_and_seeds():
+    assert split_games(10, 4) == [3, 3, 2, 2]
+    assert split_games(131072, 8) == [16384] * 8
+    assert sum(split_games(7, 8)) == 7 and split_games(0, 3) == [0, 0, 0]
+    assert worker_seed(3, 0) == 3 * 10007 + 9973 and worker_seed(0, 7) == 8 * 9973
+
+
+def test_gather_and_broadcast_world2_gloo():
+    world, counts = 2, [5, 9]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, counts, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    items = [q.get(timeout=120) for _ in range(4)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    d = {}
+    digests = []
+    for k, v in items:
+        if k == "digest":
+            digests.append(v)
+        else:
+            d[k] = v
+    assert d.get("gather") is True and d.get("none") is True
+    assert len(digests) == 2 and abs(digests[0] - digests[1]) < 1e-9     # same weights after broadcast
+
+
+def test_gather_with_empty_rank_world2_gloo():
+    world, counts = 2, [4, 0]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, counts, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    items = [q.get(timeout=120) for _ in range(4)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert dict((k, v) for k, v in items if k != "digest").get("gather") is True

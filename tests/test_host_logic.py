@@ -1,0 +1,90 @@
+"""CPU: host-side logic that needs no GPU -- C ABI exports, storage planning, stats merging, loud failure."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_c_abi_exports_every_declared_symbol():
+    """The shared library loads (no GPU needed) and exports every LZ_API function of include/liuzhou_hip.h."""
+    from liuzhou_amd.build import build_hip
+    lib = ctypes.CDLL(build_hip())
+    header = open(os.path.join(ROOT, "include", "liuzhou_hip.h")).read()
+    declared = set(re.findall(r"LZ_API\s+[\w\s\*]+?\b(lz_\w+)\s*\(", header))
+    assert len(declared) >= 20
+    for sym in sorted(declared):
+        assert hasattr(lib, sym), f"{sym} declared in liuzhou_hip.h but not exported"
+    from liuzhou_amd import _lib
+    assert set(_lib.SYMBOLS) <= declared
+    lib.lz_version.restype = ctypes.c_char_p
+    assert b"gfx950" in lib.lz_version()
+
+
+def test_ops_fail_loudly_without_gpu():
+    from liuzhou_amd import v0_core
+    from liuzhou_amd.mcts_gpu import GpuStateBatch
+    st = GpuStateBatch.initial("cpu", 2)
+    with pytest.raises(RuntimeError, match="HIP device"):
+        v0_core.encode_actions_fast(*st.tensors()[:10], 36, 144, 36, 4)
+    from liuzhou_amd.tree_engine import TreeEngine
+    with pytest.raises(RuntimeError, match="HIP device"):
+        TreeEngine(4, 8, "cpu")
+
+
+def test_storage_planning_and_payload(tmp_path):
+    from liuzhou_amd.self_play_storage import plan_sample_ranges, save_self_play_payload, split_counts, estimate_bytes_per_sample
+    from liuzhou_amd.trajectory_buffer import TensorSelfPlayBatch
+    assert split_counts(10, 3) == [4, 3, 3] and split_counts(0, 3) == [] and split_counts(2, 5) == [1, 1]
+    assert plan_sample_ranges(total_samples=10, num_shards=1) == [(0, 10)]
+    assert plan_sample_ranges(total_samples=10, num_shards=1, target_samples_per_shard=4) == [(0, 4), (4, 7), (7, 10)]
+    n = 7
+    b = TensorSelfPlayBatch(torch.zeros(n, 11, 6, 6), torch.zeros(n, 220, dtype=torch.bool), torch.zeros(n, 220),
+                            torch.zeros(n), torch.zeros(n))
+    assert estimate_bytes_per_sample(b) == 11 * 36 * 4 + 220 + 220 * 4 + 4 + 4          # 2692 B / sample
+    assert len(plan_sample_ranges(total_samples=n, num_shards=1, chunk_target_bytes=1024, bytes_per_sample=2692)) == n
+    p = tmp_path / "shard.pt"
+    save_self_play_payload(path=str(p), samples=b, stats_payload={"a": 1}, metadata={"payload_format": "v1_sharded_shard"})
+    got = torch.load(p)
+    assert set(got) == {"state_tensors", "legal_masks", "policy_targets", "value_targets", "soft_value_targets", "stats", "metadata"}
+
+
+def test_target_summary_and_stats_merge():
+    from liuzhou_amd.self_play_worker import merge_self_play_stats, merge_target_summaries, summarize_scalar_targets
+    from liuzhou_amd.self_play_types import SelfPlayV1Stats
+    s = summarize_scalar_targets(torch.tensor([1.0, -1.0, 0.0, float("nan"), 0.07]))
+    assert (s["total"], s["finite_count"], s["nonfinite_count"], s["positive_count"], s["negative_count"], s["zero_count"]) == (5, 4, 1, 2, 1, 1)
+    assert s["ge_abs_0p05_count"] == 3 and s["ge_abs_0p10_count"] == 2
+    m = merge_target_summaries([s, s])
+    assert m["total"] == 10 and abs(m["abs_mean"] - s["abs_mean"]) < 1e-12
+    mk = lambda g, p: SelfPlayV1Stats(g, p, 1, 0, g - 1, 100.0, 2.0, p / 2.0, g / 2.0, {"root_puct_ms": 5.0}, {}, {"root_puct_ms": 2},
+                                      {"leaf_eval_count": 10}, {str(d): (1 if d == 0 else 0) for d in range(-18, 19)}, device="cuda:0")
+    merged = merge_self_play_stats([mk(2, 200), mk(4, 400)], elapsed_sec=3.0)
+    assert merged.num_games == 6 and merged.num_positions == 600 and merged.positions_per_sec == 200.0
+    assert merged.mcts_counters["leaf_eval_count"] == 20 and merged.piece_delta_buckets["0"] == 2
+    d = merged.to_dict()
+    assert set(d["step_timing_ms"]) >= {"root_puct_ms", "pack_writeback_ms", "self_play_step_ms", "finalize_ms"}
+
+
+def test_v1_helper_truth_tables():
+    """tests/v1/test_v1_tensor_pipeline_smoke.py:20-70 (soft tanh, terminal mask, perspective flip) -- pure torch helpers."""
+    import math
+    from liuzhou_amd.mcts_gpu import GpuStateBatch, V1RootMCTS
+    board = torch.zeros((3, 6, 6), dtype=torch.int8)
+    board[0, :2, :] = 1
+    board[1, :2, :] = -1
+    soft = V1RootMCTS._soft_tanh_from_board_black(board, soft_value_k=2.0)
+    assert float(soft[0]) == pytest.approx(math.tanh(4.0 / 3.0)) and float(soft[0]) > float(soft[2]) > float(soft[1])
+    board = torch.zeros((3, 6, 6), dtype=torch.int8)
+    board[0, 0, 0] = 1; board[1, 0, 0] = 1; board[1, 0, 1] = -1; board[2, 0, 0] = 1; board[2, 0, 1] = -1
+    z = torch.zeros((3,), dtype=torch.int64)
+    batch = GpuStateBatch(board, torch.zeros((3, 6, 6), dtype=torch.bool), torch.zeros((3, 6, 6), dtype=torch.bool),
+                          torch.tensor([2, 4, 1]), torch.ones(3, dtype=torch.int64), z.clone(), z.clone(), z.clone(), z.clone(),
+                          z.clone(), torch.tensor([0, 144, 0]), torch.tensor([0, 0, 36]))
+    assert V1RootMCTS._terminal_mask_from_next_state(batch).tolist() == [False, True, True]
+    aligned = V1RootMCTS._child_values_to_parent_perspective(torch.tensor([0.2, -0.5, 0.8, -0.1]), torch.tensor([1, 1, -1, -1]),
+                                                             torch.tensor([1, -1, -1, 1]))
+    assert torch.allclose(aligned, torch.tensor([0.2, 0.5, 0.8, 0.1]), atol=1e-6)
