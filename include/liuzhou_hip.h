@@ -220,8 +220,9 @@ typedef struct LzTreeDesc {
     const void* root_state;        /* packed [B]: current game states (input of lz_tree_begin) */
     void*    nodes;                /* [B*node_cap] 48-byte records {packed state, int32 edge_begin, int32 nedges (-1 =
                                       not expanded), 8 B pad} */
-    void*    edges;                /* [B*edge_cap] 24-byte records {double W (value sum, child mover's view), float P,
-                                      uint32 N | info<<24, int32 child node or -1, uint8 action, 3 B pad};
+    void*    edges;                /* [B*edge_cap] 32-byte records {double W (value sum, child mover's view), float P,
+                                      uint32 N | info<<24, int32 child node or -1, int32 child edge_begin, uint8 action,
+                                      uint8 child nedges, 6 B pad};
                                       info: bit0 child mover white, bit1 terminal, bits2-3 terminal value + 1 */
     int32_t* n_nodes;              /* [B] */
     int32_t* n_edges;              /* [B] */

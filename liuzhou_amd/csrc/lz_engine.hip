@@ -11,7 +11,7 @@
 //
 // Layout in HBM (sized for the worst case, 288 GB makes this affordable -- no overflow paths):
 //   per game g: node arena  [S+2] x 48 B  { packed 32-byte state, edge_begin, n_edges }
-//               edge arena  [(S+1)*72] x 24 B { W f64, P f32, N|info u32, child i32, action u8 }
+//               edge arena  [(S+1)*72] x 32 B { W f64, P f32, N|info u32, child i32, child edges i32+u8, action u8 }
 //               path        [S+2] edge ids of the current simulation
 // A wave owns one game: lanes enumerate legal actions with ballots + popcount prefixes, evaluate PUCT
 // scores for up to 2 children per lane and reduce with shuffles; there is no cross-wave communication.
@@ -20,6 +20,7 @@
 #include <stdint.h>
 
 #include "lz_soa.h"
+#include "lz_wave.h"
 
 using namespace lz;
 
@@ -36,16 +37,19 @@ constexpr uint8_t kInfoWhite = 1;       // child mover is white
 constexpr uint8_t kInfoTerminal = 2;    // child is terminal (game over, or found to have no legal move)
 // bits 2..3: terminal value + 1  (0 => -1, 1 => 0, 2 => +1), from the child's mover's perspective
 
-// 24-byte edge record: one load brings everything select needs for a child
+// 32-byte edge record: one load brings everything the descent needs for a child, including where the child's
+// own edges live -- select never touches node records until it has found the leaf's parent.
 struct Edge {
     double W;            // value sum, child mover's perspective
     float P;             // prior
     uint32_t n_info;     // visit count (low 24 bits) | info (high 8 bits)
     int32_t child;       // node index or -1
+    int32_t cbegin;      // child's first edge (valid when child >= 0)
     uint8_t act;         // 220-d action index
-    uint8_t pad[3];
+    uint8_t cn;          // child's edge count (valid when child >= 0)
+    uint8_t pad[6];
 };
-static_assert(sizeof(Edge) == 24, "edge record is 24 bytes");
+static_assert(sizeof(Edge) == 32, "edge record is 32 bytes");
 // 48-byte node record
 struct Node {
     Packed state;
@@ -70,17 +74,6 @@ __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 __device__ __forceinline__ int wave_game() {
     return blockIdx.x * kWavesPerBlock + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 }
-__device__ __forceinline__ double wave_max_f64(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { const double t = __shfl_xor(v, o); v = t > v ? t : v; }
-    return v;
-}
-__device__ __forceinline__ float wave_max_f32(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-    return v;
-}
-
 __device__ __forceinline__ double terminal_value_for_mover(const State& s) {   // portable_mcts.py:141-147
     const int st = game_status(s);
     if (st == 1 || st == -1) return st == s.player ? 1.0 : -1.0;
@@ -151,12 +144,9 @@ __global__ __launch_bounds__(kBlock) void tree_begin_kernel(Tree t) {
 }
 
 // ---- select: one wave per game ---------------------------------------------------------------------------
-// Per level the dependent chain is {edge_begin, nedges} -> edge records -> next node; the node's packed state
-// is only needed for the leaf's parent, and the mover of every inner node is known from the chosen edge.
-__global__ __launch_bounds__(kBlock) void tree_select_kernel(Tree t) {
-    const int lane = lane_id();
-    const int g = wave_game();
-    if (g >= t.B) return;
+// Per level the only dependent load is the current node's edge run (32 B per lane, coalesced); the reduction is
+// DPP-based and the chosen edge is broadcast with v_readlane.  Node records are read once, for the leaf's parent.
+__device__ __forceinline__ void tree_select(const Tree& t, int g, int lane) {
     if (t.root_terminal[g]) { if (lane == 0) t.leaf_kind[g] = kLeafInactive; return; }
     const Node* nodes = t.nodes + (size_t)g * t.node_cap;
     const Edge* edges = t.edges + (size_t)g * t.edge_cap;
@@ -164,20 +154,17 @@ __global__ __launch_bounds__(kBlock) void tree_select_kernel(Tree t) {
     int node = 0, depth = 0;
     int parent_n = t.root_visits[g];
     int node_player = ((t.root_state[g].w0 >> 53) & 1) ? -1 : 1;
+    int ne = nodes[0].nedges, e0 = nodes[0].edge_begin;
     int kind = kLeafInactive;
     float term_value = 0.f;
-    int leaf_parent = -1, leaf_action = 0;
-    for (;;) {
-        const int ne = nodes[node].nedges;
-        if (ne <= 0) break;                                // (cannot happen for an expanded inner node)
-        const int e0 = nodes[node].edge_begin;
+    int leaf_action = 0;
+    while (ne > 0) {
         const double sq = sqrt((double)(parent_n > 1 ? parent_n : 1));
-        // up to 2 children per lane, ascending edge index
         double best = -INFINITY;
         int best_k = -1;
         Edge mine[2];
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
+        for (int r = 0; r < 2; ++r) {                          // up to 2 children per lane, ascending edge index
             const int k = r * kWave + lane;
             if (k < ne) {
                 mine[r] = edges[e0 + k];
@@ -193,33 +180,36 @@ __global__ __launch_bounds__(kBlock) void tree_select_kernel(Tree t) {
                 if (sc > best) { best = sc; best_k = k; }
             }
         }
-        const double mx = wave_max_f64(best);
-        // lowest edge index among the maxima
-        const uint64_t lo = __ballot(best_k >= 0 && best_k < kWave && best == mx);
+        const double mx = lzw::wave_max(best);
+        const uint64_t lo = __ballot(best_k >= 0 && best_k < kWave && best == mx);   // lowest index among the maxima
         int chosen;
         if (lo) chosen = __ffsll((unsigned long long)lo) - 1;
         else {
             const uint64_t hi = __ballot(best_k >= kWave && best == mx);
-            if (!hi) break;                                // all scores NaN: stop here (portable: best_child None)
+            if (!hi) break;                                    // every score NaN (portable: best_child is None)
             chosen = kWave + __ffsll((unsigned long long)hi) - 1;
         }
+        chosen = __builtin_amdgcn_readfirstlane(chosen);
         if (lane == 0) path[depth] = e0 + chosen;
         ++depth;
-        // broadcast the chosen edge's fields from the lane that holds it
-        const int src = chosen & 63, rr = chosen >> 6;
-        const uint32_t c_ni = __shfl(rr ? mine[1].n_info : mine[0].n_info, src);
-        const int c_child = __shfl(rr ? mine[1].child : mine[0].child, src);
-        const int c_act = __shfl((int)(rr ? mine[1].act : mine[0].act), src);
+        const int src = chosen & 63;
+        const bool up = chosen >= kWave;
+        const uint32_t c_ni = (uint32_t)lzw::lane_bcast((int)(up ? mine[1].n_info : mine[0].n_info), src);
+        const int c_child = lzw::lane_bcast(up ? mine[1].child : mine[0].child, src);
+        const int c_begin = lzw::lane_bcast(up ? mine[1].cbegin : mine[0].cbegin, src);
+        const int c_meta = lzw::lane_bcast((int)(up ? mine[1].act : mine[0].act) | ((int)(up ? mine[1].cn : mine[0].cn) << 8), src);
         const uint8_t info = edge_info(c_ni);
         if (info & kInfoTerminal) {
             kind = kLeafTerminal;
             term_value = (float)((int)((info >> 2) & 3) - 1);
             break;
         }
-        if (c_child < 0) { kind = kLeafExpand; leaf_parent = node; leaf_action = c_act; break; }
+        if (c_child < 0) { kind = kLeafExpand; leaf_action = c_meta & 0xFF; break; }
         parent_n = edge_n(c_ni);
         node_player = (info & kInfoWhite) ? -1 : 1;
         node = c_child;
+        e0 = c_begin;
+        ne = c_meta >> 8;
         if (depth >= t.path_cap - 1) break;
     }
     if (lane == 0) {
@@ -227,7 +217,7 @@ __global__ __launch_bounds__(kBlock) void tree_select_kernel(Tree t) {
         t.leaf_kind[g] = kind;
         t.leaf_value[g] = term_value;
         if (kind == kLeafExpand) {
-            State leaf = unpack(nodes[leaf_parent].state);
+            State leaf = unpack(nodes[node].state);
             int kd, p, q2, ex;
             index_to_code(leaf.phase, leaf_action, kd, p, q2, ex);
             apply(leaf, kd, p, q2);
@@ -236,21 +226,20 @@ __global__ __launch_bounds__(kBlock) void tree_select_kernel(Tree t) {
     }
 }
 
+__global__ __launch_bounds__(kBlock) void tree_select_kernel(Tree t) {
+    const int g = wave_game();
+    if (g >= t.B) return;
+    tree_select(t, g, lane_id());
+}
+
 // ---- expand (+ backup): one wave per game -----------------------------------------------------------------
 // priors come either from the three 36-wide log-prob heads (production) or from a dense 220-d prior row
 // (injected evaluator, parity runs).  IS_ROOT: no backup, optional noise mix.
 template <bool IS_ROOT>
-__global__ __launch_bounds__(kBlock) void tree_expand_kernel(Tree t, const float* __restrict__ lp1,
-                                                             const float* __restrict__ lp2,
-                                                             const float* __restrict__ lpm,
-                                                             const float* __restrict__ priors220,
-                                                             const float* __restrict__ values,
-                                                             const float* __restrict__ noise, int noise_stride,
-                                                             float epsilon) {
-    const int lane = lane_id();
-    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int g = blockIdx.x * kWavesPerBlock + w;
-    if (g >= t.B) return;
+__device__ __forceinline__ void tree_expand(const Tree& t, int g, int lane, const float* __restrict__ lp1,
+                                            const float* __restrict__ lp2, const float* __restrict__ lpm,
+                                            const float* __restrict__ priors220, const float* __restrict__ values,
+                                            const float* __restrict__ noise, int noise_stride, float epsilon) {
     const int kind = t.leaf_kind[g];
     if (kind == kLeafInactive) return;
     Node* nodes = t.nodes + (size_t)g * t.node_cap;
@@ -309,12 +298,11 @@ __global__ __launch_bounds__(kBlock) void tree_expand_kernel(Tree t, const float
             }
             if (heads) {
                 // softmax over the legal set (portable_mcts.py:381-386), fp32
-                mx = wave_max_f32(mx);
+                mx = lzw::wave_max(mx);
                 float sum = 0.f;
 #pragma unroll
                 for (int it = 0; it < 4; ++it) { val[it] = lg[it] ? expf(val[it] - mx) : 0.f; sum += val[it]; }
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+                sum = lzw::wave_sum(sum);
 #pragma unroll
                 for (int it = 0; it < 4; ++it) val[it] = val[it] / sum;
             }
@@ -331,9 +319,9 @@ __global__ __launch_bounds__(kBlock) void tree_expand_kernel(Tree t, const float
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 uint64_t m = __ballot(lg[it]);
-                while (m) {
-                    const int l = __ffsll((unsigned long long)m) - 1;
-                    psum += __shfl(val[it], l);
+                while (m) {                                     // scalar loop: s_ff1 + v_readlane + one add
+                    const int l = __builtin_amdgcn_readfirstlane(__ffsll((unsigned long long)m) - 1);
+                    psum += lzw::lane_bcast(val[it], l);
                     m &= m - 1;
                 }
             }
@@ -345,14 +333,15 @@ __global__ __launch_bounds__(kBlock) void tree_expand_kernel(Tree t, const float
                 else {
                     node_id = t.n_nodes[g]; t.n_nodes[g] = node_id + 1;
                     e0 = t.n_edges[g]; t.n_edges[g] = e0 + n;
-                    edges[path[plen - 1]].child = node_id;
+                    Edge& in = edges[path[plen - 1]];
+                    in.child = node_id; in.cbegin = e0; in.cn = (uint8_t)n;
                     nodes[node_id].state = t.leaf_state[g];
                 }
                 nodes[node_id].edge_begin = e0;
                 nodes[node_id].nedges = n;
                 if (IS_ROOT) t.root_init_value[g] = values[g];
             }
-            e0 = __shfl(e0, 0);
+            e0 = __builtin_amdgcn_readfirstlane(e0);
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 if (!lg[it]) continue;
@@ -371,8 +360,10 @@ __global__ __launch_bounds__(kBlock) void tree_expand_kernel(Tree t, const float
                 rec.P = bad ? (1.0f / (float)n) : (val[it] / psum);
                 rec.n_info = (uint32_t)info << 24;
                 rec.child = -1;
+                rec.cbegin = 0;
                 rec.act = (uint8_t)a;
-                rec.pad[0] = rec.pad[1] = rec.pad[2] = 0;
+                rec.cn = 0;
+                rec.pad[0] = rec.pad[1] = rec.pad[2] = rec.pad[3] = rec.pad[4] = rec.pad[5] = 0;
                 edges[e0 + slot[it]] = rec;
             }
             backup_value = (double)values[g];
@@ -409,6 +400,36 @@ __global__ __launch_bounds__(kBlock) void tree_expand_kernel(Tree t, const float
             t.root_W[g] += (flips_above & 1) ? -backup_value : backup_value;
         }
     }
+}
+
+template <bool IS_ROOT>
+__global__ __launch_bounds__(kBlock) void tree_expand_kernel(Tree t, const float* __restrict__ lp1,
+                                                             const float* __restrict__ lp2,
+                                                             const float* __restrict__ lpm,
+                                                             const float* __restrict__ priors220,
+                                                             const float* __restrict__ values,
+                                                             const float* __restrict__ noise, int noise_stride,
+                                                             float epsilon) {
+    const int g = wave_game();
+    if (g >= t.B) return;
+    tree_expand<IS_ROOT>(t, g, lane_id(), lp1, lp2, lpm, priors220, values, noise, noise_stride, epsilon);
+}
+
+// expand + backup of simulation s fused with the selection of simulation s+1 (same wave, same game: the edge
+// records it just touched are still in L1/L2) -- one launch per simulation besides the network kernel.
+template <bool IS_ROOT>
+__global__ __launch_bounds__(kBlock) void tree_expand_select_kernel(Tree t, const float* __restrict__ lp1,
+                                                                    const float* __restrict__ lp2,
+                                                                    const float* __restrict__ lpm,
+                                                                    const float* __restrict__ values,
+                                                                    const float* __restrict__ noise, int noise_stride,
+                                                                    float epsilon) {
+    const int g = wave_game();
+    if (g >= t.B) return;
+    const int lane = lane_id();
+    tree_expand<IS_ROOT>(t, g, lane, lp1, lp2, lpm, nullptr, values, noise, noise_stride, epsilon);
+    __threadfence_block();
+    tree_select(t, g, lane);
 }
 
 // ---- finish: root policy / pick -----------------------------------------------------------------------------
@@ -472,7 +493,7 @@ __global__ __launch_bounds__(kBlock) void tree_finish_kernel(Tree t, const float
     }
     // ---- policy ----
     float pol[2] = {0.f, 0.f};
-    float vmax = wave_max_f32(fmaxf(ok[0] ? v[0] : -1.f, ok[1] ? v[1] : -1.f));
+    float vmax = lzw::wave_max(fmaxf(ok[0] ? v[0] : -1.f, ok[1] ? v[1] : -1.f));
     if (temp <= 1e-6f) {
         uint64_t lo = __ballot(ok[0] && v[0] == vmax);
         int am;
@@ -484,11 +505,9 @@ __global__ __launch_bounds__(kBlock) void tree_finish_kernel(Tree t, const float
         const float tt = fmaxf(temp, 1e-6f);
         float lg0 = (ok[0] && v[0] > 0.f) ? logf(v[0]) / tt : -INFINITY;
         float lg1 = (ok[1] && v[1] > 0.f) ? logf(v[1]) / tt : -INFINITY;
-        const float mx = wave_max_f32(fmaxf(lg0, lg1));
+        const float mx = lzw::wave_max(fmaxf(lg0, lg1));
         float e0f = lg0 == -INFINITY ? 0.f : expf(lg0 - mx), e1f = lg1 == -INFINITY ? 0.f : expf(lg1 - mx);
-        float sum = e0f + e1f;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+        const float sum = lzw::wave_sum(e0f + e1f);
         pol[0] = e0f / sum; pol[1] = e1f / sum;
     }
 #pragma unroll
@@ -515,9 +534,9 @@ __global__ __launch_bounds__(kBlock) void tree_finish_kernel(Tree t, const float
         // most visits, then Q (atol 1e-6), then prior (atol 1e-8), then lowest index
         bool c0 = ok[0] && v[0] == vmax, c1 = ok[1] && v[1] == vmax;
         float qf0 = (float)q[0], qf1 = (float)q[1];
-        const float qmax = wave_max_f32(fmaxf(c0 ? qf0 : -INFINITY, c1 ? qf1 : -INFINITY));
+        const float qmax = lzw::wave_max(fmaxf(c0 ? qf0 : -INFINITY, c1 ? qf1 : -INFINITY));
         c0 = c0 && fabsf(qf0 - qmax) <= 1e-6f; c1 = c1 && fabsf(qf1 - qmax) <= 1e-6f;
-        const float pmax = wave_max_f32(fmaxf(c0 ? pr[0] : -INFINITY, c1 ? pr[1] : -INFINITY));
+        const float pmax = lzw::wave_max(fmaxf(c0 ? pr[0] : -INFINITY, c1 ? pr[1] : -INFINITY));
         c0 = c0 && fabsf(pr[0] - pmax) <= 1e-8f; c1 = c1 && fabsf(pr[1] - pmax) <= 1e-8f;
         const uint64_t lo = __ballot(c0);
         if (lo) pick = __ffsll((unsigned long long)lo) - 1;
@@ -640,16 +659,24 @@ int lz_tree_search(const LzTreeDesc* d, const LzNetDesc* net, int64_t sims, floa
     if (B == 0) return LZ_OK;
     int rc = lz_tree_begin(d, stream);
     if (rc) return rc;
+    (void)planes;   // the network kernel stages its input straight from the 32-byte packed leaf states
+    const Tree t = make_tree(d);
     for (int64_t s = 0; s <= sims; ++s) {
-        if (s > 0) { rc = lz_tree_select(d, stream); if (rc) return rc; }
-        (void)planes;   // the network kernel stages its input straight from the 32-byte packed leaf states
         rc = lz_net_forward_packed_f16(net, d->leaf_state, B, lp1, lp2, lpmc, nullptr, values, stream);
         if (rc) return rc;
-        rc = lz_tree_expand(d, s == 0 ? 1 : 0, lp1, lp2, lpmc, nullptr, values, s == 0 ? noise : nullptr, noise_stride,
-                            epsilon, stream);
-        if (rc) return rc;
+        if (s == sims) {   // last simulation: nothing left to select
+            rc = lz_tree_expand(d, s == 0 ? 1 : 0, lp1, lp2, lpmc, nullptr, values, s == 0 ? noise : nullptr,
+                                noise_stride, epsilon, stream);
+            if (rc) return rc;
+        } else if (s == 0) {
+            hipLaunchKernelGGL(tree_expand_select_kernel<true>, dim3(gw(t.B)), dim3(kBlock), 0, as_stream(stream), t, lp1,
+                               lp2, lpmc, values, noise, (int)noise_stride, epsilon);
+        } else {
+            hipLaunchKernelGGL(tree_expand_select_kernel<false>, dim3(gw(t.B)), dim3(kBlock), 0, as_stream(stream), t, lp1,
+                               lp2, lpmc, values, nullptr, 0, 0.f);
+        }
     }
-    return LZ_OK;
+    return st();
 }
 
 }  // extern "C"

@@ -53,7 +53,7 @@ class TreeEngine:
         self.buf: Dict[str, torch.Tensor] = {
             "root_state": z((B, 4), torch.int64),
             "nodes": z((B * self.node_cap, 6), torch.int64),            # 48-byte node records
-            "edges": z((B * self.edge_cap, 3), torch.int64),            # 24-byte edge records
+            "edges": z((B * self.edge_cap, 4), torch.int64),            # 32-byte edge records
             "n_nodes": z((B,), torch.int32), "n_edges": z((B,), torch.int32), "root_visits": z((B,), torch.int32),
             "root_w": z((B,), torch.float64), "root_init_value": z((B,), torch.float32),
             "path": z((B * self.path_cap,), torch.int32), "path_len": z((B,), torch.int32),
