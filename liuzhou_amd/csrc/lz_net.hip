@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/liuzhou_hip.h"
 
@@ -53,6 +54,7 @@ struct NetParams {
     int layer_off[32];          // offsets in halfs: stem, (conv1, conv2) x blocks, heads
     int hf_gw, hf_w1, hf_w2, hf_out;   // offsets in halfs of the head FC fragments (gpool_linear, fc1, fc2, 3 out convs)
     int wfrag_bytes, fparams_bytes;
+    int debug_stop;             // diagnostic builds only: leave the pass after phase k (0 = run everything)
     int blocks;
     // float-parameter offsets
     int stem_bias, blk0, trunk_a, trunk_b, head_bias, p_gwT, p_a2, p_b2, p_out, v_w1T, v_b1, v_w2T, v_b2;
@@ -117,55 +119,72 @@ __device__ __forceinline__ constexpr int step_offset(int step) {
     return ((tap / 3) * 7 + (tap % 3)) * K::STRIDE + kb * 64;
 }
 
-// One K step: 9 activation fragments (ds_read_b128 at base[i] + immediate) x 2 weight fragments -> 18 MFMAs.
-template <int C, int S, bool TAPS9, bool STEM, int STEP>
-__device__ __forceinline__ void gemm_step(Acc& acc, const h8 (&A)[2], const unsigned char* lds, const int (&base)[9]) {
-    constexpr int off = step_offset<C, S, TAPS9, STEM>(STEP);
-    h8 B[9];
-#pragma unroll
-    for (int i = 0; i < 9; ++i) B[i] = *reinterpret_cast<const h8*>(lds + base[i] + off);
-    __builtin_amdgcn_sched_barrier(0);                   // all 9 reads in flight before the first MFMA
+// One K step, software-pipelined IN PLACE: tile i's activation fragment register is reloaded for the next K step
+// right after its two MFMAs have been issued, so the LDS reads are spread over the whole step (one ds_read per
+// two MFMAs) and overlap the matrix pipe instead of forming a separate read phase.  The counted lgkmcnt waits
+// the compiler derives from this order leave 8 reads in flight.
+template <int C, int S, bool TAPS9, bool STEM, int STEP, int NSTEPS>
+__device__ __forceinline__ void gemm_step(Acc& acc, const h8 (&A)[2], h8 (&B)[9], const unsigned char* lds,
+                                          const int (&base)[9]) {
+    constexpr int next_off = (STEP + 1 < NSTEPS) ? step_offset<C, S, TAPS9, STEM>(STEP + 1) : 0;
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[j], B[i], acc[i][j], 0, 0, 0);
+        if (STEP + 1 < NSTEPS) B[i] = *reinterpret_cast<const h8*>(lds + base[i] + next_off);
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
 template <int C, int S, bool TAPS9, bool STEM, int CTN, int STEP, int NSTEPS>
 struct GemmSteps {
-    static __device__ __forceinline__ void run(Acc& acc, h8 (&A0)[2], h8 (&A1)[2], __amdgpu_buffer_rsrc_t rw, int wbyte,
-                                               int lane16, const unsigned char* lds, const int (&base)[9]) {
+    static __device__ __forceinline__ void run(Acc& acc, h8 (&A0)[2], h8 (&A1)[2], h8 (&B)[9], __amdgpu_buffer_rsrc_t rw,
+                                               int wbyte, int lane16, const unsigned char* lds, const int (&base)[9]) {
         // weight fragments (L2) are prefetched one K step ahead into the other register pair
         if (STEP + 1 < NSTEPS) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) A1[j] = load_wfrag(rw, lane16, wbyte + ((STEP + 1) * CTN + j) * 1024);
         }
-        gemm_step<C, S, TAPS9, STEM, STEP>(acc, A0, lds, base);
-        GemmSteps<C, S, TAPS9, STEM, CTN, STEP + 1, NSTEPS>::run(acc, A1, A0, rw, wbyte, lane16, lds, base);
+        gemm_step<C, S, TAPS9, STEM, STEP, NSTEPS>(acc, A0, B, lds, base);
+        GemmSteps<C, S, TAPS9, STEM, CTN, STEP + 1, NSTEPS>::run(acc, A1, A0, B, rw, wbyte, lane16, lds, base);
     }
 };
 template <int C, int S, bool TAPS9, bool STEM, int CTN, int NSTEPS>
 struct GemmSteps<C, S, TAPS9, STEM, CTN, NSTEPS, NSTEPS> {
-    static __device__ __forceinline__ void run(Acc&, h8 (&)[2], h8 (&)[2], __amdgpu_buffer_rsrc_t, int, int,
+    static __device__ __forceinline__ void run(Acc&, h8 (&)[2], h8 (&)[2], h8 (&)[9], __amdgpu_buffer_rsrc_t, int, int,
                                                const unsigned char*, const int (&)[9]) {}
 };
 
 // Fully unrolled over the K steps (9 taps x C/32 blocks): every LDS read offset is an immediate and every
 // weight address is {descriptor, scalar offset, lane offset}, so a step is 9 ds_read + 2 buffer_load +
-// 18 MFMA and nothing else.  Two waves per SIMD hide each other's LDS latency.
+// 18 MFMA and nothing else.
 // `layer_half_off` = offset of the layer in halfs, ct0 = first output tile of this wave (both wave-uniform).
+// first two weight fragments of a layer: issued a whole phase early (before the barrier / LDS store phase that
+// precedes the conv) so their L2 latency never sits on the critical path
+__device__ __forceinline__ void load_first_frags(__amdgpu_buffer_rsrc_t rw, int layer_half_off, int ct0, int lane,
+                                                 h8 (&A0)[2]) {
+    const int wbyte = __builtin_amdgcn_readfirstlane(layer_half_off * 2 + ct0 * 1024);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) A0[j] = load_wfrag(rw, lane * 16, wbyte + j * 1024);
+}
+
 template <int C, int S, bool TAPS9, bool STEM, int CTN>
 __device__ __forceinline__ void conv_gemm(Acc& acc, __amdgpu_buffer_rsrc_t rw, int layer_half_off, int ct0,
-                                          const unsigned char* lds, const int (&base)[9], int lane) {
+                                          const unsigned char* lds, const int (&base)[9], int lane, h8 (&A0)[2]) {
     using K = Cfg<C, S>;
     constexpr int nsteps = TAPS9 ? (STEM ? 9 : 9 * K::KB) : K::KB;
     const int wbyte = __builtin_amdgcn_readfirstlane(layer_half_off * 2 + ct0 * 1024);
     const int lane16 = lane * 16;
-    h8 A0[2], A1[2];
+    h8 A1[2], B[9];
+    constexpr int off0 = step_offset<C, S, TAPS9, STEM>(0);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) A0[j] = load_wfrag(rw, lane16, wbyte + j * 1024);
-    GemmSteps<C, S, TAPS9, STEM, CTN, 0, nsteps>::run(acc, A0, A1, rw, wbyte, lane16, lds, base);
+    for (int i = 0; i < 9; ++i) B[i] = *reinterpret_cast<const h8*>(lds + base[i] + off0);
+    GemmSteps<C, S, TAPS9, STEM, CTN, 0, nsteps>::run(acc, A0, A1, B, rw, wbyte, lane16, lds, base);
+}
+
+// workgroup barrier that only orders LDS traffic: prefetched global loads stay in flight across it
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
 __device__ __forceinline__ h4 to_h4(float a, float b, float c, float d) {
@@ -175,17 +194,19 @@ __device__ __forceinline__ h4 to_h4(float a, float b, float c, float d) {
 }
 
 // write relu(scale*acc + shift) (per channel) as fp16 rows; `chan_base` = first channel of co tile 0
+// per-channel parameters of this lane's 2 x 4 channels (issued early, consumed by store_act)
+__device__ __forceinline__ void load_chan_params(__amdgpu_buffer_rsrc_t rf, int float_off, int chan_base, int lane,
+                                                 f4 (&v)[2]) {
+    const int sub = (lane >> 4) * 4;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) v[j] = load_f4(rf, sub, float_off + chan_base + j * 16);
+}
+
 template <int C, int S, bool HAS_SCALE>
 __device__ __forceinline__ void store_act(const Acc& acc, unsigned char* lds, int tile0, int chan_base,
-                                          __amdgpu_buffer_rsrc_t rf, int scale_off, int shift_off, int lane) {
+                                          const f4 (&sc)[2], const f4 (&sh)[2], int lane) {
     using K = Cfg<C, S>;
     const int sub = (lane >> 4) * 4;
-    f4 sc[2], sh[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        sh[j] = load_f4(rf, sub, shift_off + chan_base + j * 16);
-        if (HAS_SCALE) sc[j] = load_f4(rf, sub, scale_off + chan_base + j * 16);
-    }
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
         const int n = (tile0 + i) * 16 + (lane & 15);
@@ -349,57 +370,72 @@ __global__ __launch_bounds__(512, 2) void net_forward_kernel(NetParams P, const 
             }
         }
         __syncthreads();
+        if (P.debug_stop == 1) continue;                       // after input staging
 
         Acc x, acc;
 #pragma unroll
         for (int i = 0; i < 9; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) x[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
+        h8 Af[2];                                              // first weight fragments of the upcoming conv
+        f4 pa[2], pb[2];                                       // per-channel parameters of the upcoming store
         // ---- stem: x = relu(conv(planes) + bias) ----
-        conv_gemm<C, S, true, true, K::CT>(x, rw, P.layer_off[0], ct0, lds, base, lane);
-        {
-            const int sub = (lane >> 4) * 4;
+        load_first_frags(rw, P.layer_off[0], ct0, lane, Af);
+        load_chan_params(rf, P.stem_bias, chan0, lane, pb);
+        conv_gemm<C, S, true, true, K::CT>(x, rw, P.layer_off[0], ct0, lds, base, lane, Af);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const f4 b = load_f4(rf, sub, P.stem_bias + chan0 + j * 16);
+        for (int j = 0; j < 2; ++j) {
 #pragma unroll
-                for (int i = 0; i < 9; ++i) {
-                    f4 v = x[i][j] + b;
-                    x[i][j] = (f4){fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
-                }
+            for (int i = 0; i < 9; ++i) {
+                f4 v = x[i][j] + pb[j];
+                x[i][j] = (f4){fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
             }
         }
-        // ---- residual blocks ----
+        if (P.debug_stop == 2) { if (lane == 0 && x[0][0][0] == 123.f) lp1[0] = 1.f; continue; }   // after the stem
+        // ---- residual blocks: every global load (weights, parameters) is issued one phase ahead ----
         for (int blk = 0; blk < P.blocks; ++blk) {
             const int bp = P.blk0 + blk * 3 * C;               // float offsets: a1 | b1 | bias1
-            __syncthreads();                                   // everyone finished reading the act buffer
-            store_act<C, S, true>(x, lds, tile0, chan0, rf, bp, bp + C, lane);         // t = relu(a1*x + b1)
-            __syncthreads();
+            load_chan_params(rf, bp, chan0, lane, pa);
+            load_chan_params(rf, bp + C, chan0, lane, pb);
+            load_first_frags(rw, P.layer_off[1 + 2 * blk], ct0, lane, Af);
+            lds_barrier();                                     // everyone finished reading the act buffer
+            store_act<C, S, true>(x, lds, tile0, chan0, pa, pb, lane);                 // t = relu(a1*x + b1)
+            load_chan_params(rf, bp + 2 * C, chan0, lane, pb);                          // bias1, used after conv1
+            lds_barrier();
 #pragma unroll
             for (int i = 0; i < 9; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
-            conv_gemm<C, S, true, false, K::CT>(acc, rw, P.layer_off[1 + 2 * blk], ct0, lds, base, lane);
-            __syncthreads();
-            store_act<C, S, false>(acc, lds, tile0, chan0, rf, 0, bp + 2 * C, lane);   // u = relu(conv1 + bias1)
-            __syncthreads();
-            conv_gemm<C, S, true, false, K::CT>(x, rw, P.layer_off[2 + 2 * blk], ct0, lds, base, lane);  // x += conv2(u)
+            conv_gemm<C, S, true, false, K::CT>(acc, rw, P.layer_off[1 + 2 * blk], ct0, lds, base, lane, Af);
+            load_first_frags(rw, P.layer_off[2 + 2 * blk], ct0, lane, Af);
+            lds_barrier();
+            store_act<C, S, false>(acc, lds, tile0, chan0, pb, pb, lane);               // u = relu(conv1 + bias1)
+            lds_barrier();
+            conv_gemm<C, S, true, false, K::CT>(x, rw, P.layer_off[2 + 2 * blk], ct0, lds, base, lane, Af);  // x += conv2(u)
         }
+        if (P.debug_stop == 3) { if (lane == 0 && x[0][0][0] == 123.f) lp1[0] = 1.f; continue; }   // after the trunk
         // ---- trunk output h = relu(a*x + b) -> LDS; head 1x1 convs (8 output tiles: policy 0..3 | value 4..7) ----
-        __syncthreads();
-        store_act<C, S, true>(x, lds, tile0, chan0, rf, P.trunk_a, P.trunk_b, lane);
-        __syncthreads();
         const int wh = P.layer_off[1 + 2 * P.blocks];
+        const int ht0 = cg * K::CTW;                               // head tile of acc   (0..7)
+        const int ht1 = K::CG * K::CTW + cg * K::CTW;              // head tile of x     (HP == 2 only)
+        load_chan_params(rf, P.trunk_a, chan0, lane, pa);
+        load_chan_params(rf, P.trunk_b, chan0, lane, pb);
+        load_first_frags(rw, wh, ht0, lane, Af);
+        lds_barrier();
+        store_act<C, S, true>(x, lds, tile0, chan0, pa, pb, lane);
+        lds_barrier();
 #pragma unroll
         for (int i = 0; i < 9; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) { acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f}; x[i][j] = (f4){0.f, 0.f, 0.f, 0.f}; }
         // pass 0 -> acc, pass 1 (only when 4 waves' worth of tiles cover half of the 8 head tiles) -> x
-        const int ht0 = cg * K::CTW;                               // head tile of acc   (0..7)
-        const int ht1 = K::CG * K::CTW + cg * K::CTW;              // head tile of x     (HP == 2 only)
-        conv_gemm<C, S, false, false, 8>(acc, rw, wh, ht0, lds, base, lane);
-        if (K::HP == 2) conv_gemm<C, S, false, false, 8>(x, rw, wh, ht1, lds, base, lane);
+        conv_gemm<C, S, false, false, 8>(acc, rw, wh, ht0, lds, base, lane, Af);
+        if (K::HP == 2) {
+            load_first_frags(rw, wh, ht1, lane, Af);
+            conv_gemm<C, S, false, false, 8>(x, rw, wh, ht1, lds, base, lane, Af);
+        }
         __syncthreads();
+        if (P.debug_stop == 4) { if (lane == 0 && (acc[0][0][0] + x[0][0][0]) == 123.f) lp1[0] = 1.f; continue; }   // after head convs
         // ---- policy head ----
         if (ht0 < 4) store_head<C, S>(acc, lds, tile0, ht0, rf, P.head_bias, lane);
         __syncthreads();
@@ -453,6 +489,7 @@ __global__ __launch_bounds__(512, 2) void net_forward_kernel(NetParams P, const 
             if (lane < 36 && s < nvalid) (h == 0 ? lp1 : h == 1 ? lp2 : lpm)[(n0 + s) * 36 + lane] = v - lse;
         }
         __syncthreads();
+        if (P.debug_stop == 5) { if (lane == 0 && x[0][0][0] == 123.f) lp1[0] = 1.f; continue; }   // after the policy head
         // ---- value head ----
         if (K::HP == 2) store_head<C, S>(x, lds, tile0, ht1 - 4, rf, P.head_bias + kHead, lane);
         else if (ht0 >= 4) store_head<C, S>(acc, lds, tile0, ht0 - 4, rf, P.head_bias + kHead, lane);
@@ -578,6 +615,7 @@ static int net_forward_impl(const LzNetDesc* d, const float* planes, const uint6
     for (int i = 0; i < d->num_layers; ++i) P.layer_off[i] = d->layer_offsets[i];
     P.blocks = d->blocks;
     P.wfrag_bytes = (int)d->wfrag_bytes; P.fparams_bytes = (int)d->fparams_bytes;
+    P.debug_stop = getenv("LZ_NET_DEBUG_STOP") ? atoi(getenv("LZ_NET_DEBUG_STOP")) : 0;
     P.hf_gw = d->head_frag_offsets[0]; P.hf_w1 = d->head_frag_offsets[1]; P.hf_w2 = d->head_frag_offsets[2];
     P.hf_out = d->head_frag_offsets[3];
     P.stem_bias = d->off_stem_bias; P.blk0 = d->off_block0; P.trunk_a = d->off_trunk_a; P.trunk_b = d->off_trunk_b;
