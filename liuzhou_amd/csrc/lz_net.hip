@@ -21,6 +21,7 @@
 #include <stdlib.h>
 
 #include "../../include/liuzhou_hip.h"
+#include "lz_wave.h"
 
 namespace {
 
@@ -222,33 +223,41 @@ __device__ __forceinline__ void store_act(const Acc& acc, unsigned char* lds, in
 }
 
 // global pooling of a [cell][64] fp16 map in LDS -> fp16 row pooled[s][192] = mean | max | sqrt(var + 1e-6)
+// (src/neural_network.py:67-80).  Two lanes per (sample, 4-channel group), 18 cells each, one pass
+// (sum, sum of squares, max in fp32), halves combined with a quad-permute DPP swap.
 template <int C, int S>
 __device__ __forceinline__ void gpool64(unsigned char* lds, int tid) {
     using K = Cfg<C, S>;
-    if (tid < S * 16) {
-        const int s = tid >> 4, cq = tid & 15;
-        float sum[4] = {0.f, 0.f, 0.f, 0.f}, mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    if (tid < S * 32) {
+        const int pair = tid >> 1, half = tid & 1;
+        const int s = pair >> 4, cq = pair & 15;
+        float sum[4] = {0.f, 0.f, 0.f, 0.f}, sq[4] = {0.f, 0.f, 0.f, 0.f};
+        float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
 #pragma unroll 6
-        for (int p = 0; p < 36; ++p) {
+        for (int p = half * 18; p < half * 18 + 18; ++p) {
             const h4 v = *reinterpret_cast<const h4*>(lds + act_addr<C, S>(s * 36 + p, cq >> 1) + (cq & 1) * 8);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { const float f = (float)v[k]; sum[k] += f; mx[k] = fmaxf(mx[k], f); }
+            for (int k = 0; k < 4; ++k) { const float f = (float)v[k]; sum[k] += f; sq[k] += f * f; mx[k] = fmaxf(mx[k], f); }
         }
-        float mean[4], var[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int k = 0; k < 4; ++k) mean[k] = sum[k] * (1.0f / 36.0f);
-#pragma unroll 6
-        for (int p = 0; p < 36; ++p) {
-            const h4 v = *reinterpret_cast<const h4*>(lds + act_addr<C, S>(s * 36 + p, cq >> 1) + (cq & 1) * 8);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { const float d = (float)v[k] - mean[k]; var[k] += d * d; }
+        for (int k = 0; k < 4; ++k) {                              // combine with the neighbouring lane (tid ^ 1)
+            sum[k] += lzw::dpp_f32<0xB1, 0xf>(0.f, sum[k]);       // quad_perm [1,0,3,2]
+            sq[k] += lzw::dpp_f32<0xB1, 0xf>(0.f, sq[k]);
+            mx[k] = fmaxf(mx[k], lzw::dpp_f32<0xB1, 0xf>(-INFINITY, mx[k]));
         }
-        unsigned char* row = lds + K::POOL_OFF + s * K::POOL_STRIDE;
-        *reinterpret_cast<h4*>(row + (cq * 4) * 2) = to_h4(mean[0], mean[1], mean[2], mean[3]);
-        *reinterpret_cast<h4*>(row + (kHead + cq * 4) * 2) = to_h4(mx[0], mx[1], mx[2], mx[3]);
-        *reinterpret_cast<h4*>(row + (2 * kHead + cq * 4) * 2) =
-            to_h4(sqrtf(var[0] * (1.0f / 36.0f) + 1e-6f), sqrtf(var[1] * (1.0f / 36.0f) + 1e-6f),
-                  sqrtf(var[2] * (1.0f / 36.0f) + 1e-6f), sqrtf(var[3] * (1.0f / 36.0f) + 1e-6f));
+        if (half == 0) {
+            float mean[4], sd[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                mean[k] = sum[k] * (1.0f / 36.0f);
+                const float var = fmaxf(sq[k] * (1.0f / 36.0f) - mean[k] * mean[k], 0.f);
+                sd[k] = sqrtf(var + 1e-6f);
+            }
+            unsigned char* row = lds + K::POOL_OFF + s * K::POOL_STRIDE;
+            *reinterpret_cast<h4*>(row + (cq * 4) * 2) = to_h4(mean[0], mean[1], mean[2], mean[3]);
+            *reinterpret_cast<h4*>(row + (kHead + cq * 4) * 2) = to_h4(mx[0], mx[1], mx[2], mx[3]);
+            *reinterpret_cast<h4*>(row + (2 * kHead + cq * 4) * 2) = to_h4(sd[0], sd[1], sd[2], sd[3]);
+        }
     }
 }
 
@@ -447,44 +456,48 @@ __global__ __launch_bounds__(512, 2) void net_forward_kernel(NetParams P, const 
             *reinterpret_cast<f4*>(gvec + s * kHead + ch) = d;
         }
         __syncthreads();
-        for (int it = tid; it < K::NPOS * 8; it += NTHR) {          // p2 = relu(bn2(p + g)) in place
-            const int n = it >> 3, c8 = it & 7;
-            const int s = n / 36;
-            h8* ptr = reinterpret_cast<h8*>(lds + act_addr<C, S>(n, c8));
-            h8 v = *ptr;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int ch = c8 * 8 + k;
-                v[k] = (_Float16)fmaxf(((float)v[k] + gvec[s * kHead + ch]) * par[ch] + par[kHead + ch], 0.f);
-            }
-            *ptr = v;
-        }
-        __syncthreads();
-        for (int t = wave; t < K::NT; t += K::WAVES) {              // three 1x1 output convs: 1 tile x K=64
-            f4 d = (f4){0.f, 0.f, 0.f, 0.f};
-            const int n = t * 16 + (lane & 15);
+        // three 1x1 output convs on p2 = relu(bn2(p + g)): p2 is formed in registers on the B fragment
+        // (every [cell][8-channel chunk] is read exactly once), 1 output tile x K=64 on the matrix cores
+        {
+            float pa2[2][8], pb2[2][8];
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
-                d = __builtin_amdgcn_mfma_f32_16x16x32_f16(
-                    load_wfrag(rw, lane * 16, P.hf_out * 2 + kb * 1024),
-                    *reinterpret_cast<const h8*>(lds + act_addr<C, S>(n, kb * 4 + (lane >> 4))), d, 0, 0, 0);
-            if (lane < 16) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int ch = (kb * 4 + (lane >> 4)) * 8 + k;
+                    pa2[kb][k] = par[ch];
+                    pb2[kb][k] = par[kHead + ch];
+                }
+            const h8 wo0 = load_wfrag(rw, lane * 16, P.hf_out * 2);
+            const h8 wo1 = load_wfrag(rw, lane * 16, P.hf_out * 2 + 1024);
+            for (int t = wave; t < K::NT; t += K::WAVES) {
+                f4 d = (f4){0.f, 0.f, 0.f, 0.f};
+                const int n = t * 16 + (lane & 15);
                 const int s = n / 36, p = n - s * 36;
-                plog[(s * 3 + 0) * 36 + p] = d[0];
-                plog[(s * 3 + 1) * 36 + p] = d[1];
-                plog[(s * 3 + 2) * 36 + p] = d[2];
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {
+                    const int chunk = kb * 4 + (lane >> 4);
+                    h8 v = *reinterpret_cast<const h8*>(lds + act_addr<C, S>(n, chunk));
+                    const f4 g0 = *reinterpret_cast<const f4*>(gvec + s * kHead + chunk * 8);
+                    const f4 g1 = *reinterpret_cast<const f4*>(gvec + s * kHead + chunk * 8 + 4);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k)
+                        v[k] = (_Float16)fmaxf(((float)v[k] + (k < 4 ? g0[k] : g1[k - 4])) * pa2[kb][k] + pb2[kb][k], 0.f);
+                    d = __builtin_amdgcn_mfma_f32_16x16x32_f16(kb == 0 ? wo0 : wo1, v, d, 0, 0, 0);
+                }
+                if (lane < 16) {
+                    plog[(s * 3 + 0) * 36 + p] = d[0];
+                    plog[(s * 3 + 1) * 36 + p] = d[1];
+                    plog[(s * 3 + 2) * 36 + p] = d[2];
+                }
             }
         }
         __syncthreads();
         for (int row = wave; row < S * 3; row += K::WAVES) {        // log_softmax over the 36 cells, one wave per row
             const int s = row / 3, h = row - s * 3;
             const float v = lane < 36 ? plog[row * 36 + lane] : -INFINITY;
-            float mx = v;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-            float e = lane < 36 ? expf(v - mx) : 0.f;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) e += __shfl_xor(e, o);
+            const float mx = lzw::wave_max(v);
+            const float e = lzw::wave_sum(lane < 36 ? expf(v - mx) : 0.f);
             const float lse = mx + logf(e);
             if (lane < 36 && s < nvalid) (h == 0 ? lp1 : h == 1 ? lp2 : lpm)[(n0 + s) * 36 + lane] = v - lse;
         }
@@ -517,14 +530,10 @@ __global__ __launch_bounds__(512, 2) void net_forward_kernel(NetParams P, const 
         for (int s = wave; s < nvalid; s += K::WAVES) {              // bucket expectation, one wave per sample
             const float v0 = vl[s * K::VL_STRIDE + lane];
             const float v1 = lane + 64 < kBins ? vl[s * K::VL_STRIDE + lane + 64] : -INFINITY;
-            float mx = fmaxf(v0, v1);
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+            const float mx = lzw::wave_max(fmaxf(v0, v1));
             const float e0 = expf(v0 - mx), e1 = lane + 64 < kBins ? expf(v1 - mx) : 0.f;
-            float sum = e0 + e1;
-            float ex = e0 * (-1.0f + 0.02f * (float)lane) + e1 * (-1.0f + 0.02f * (float)(lane + 64));
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) { sum += __shfl_xor(sum, o); ex += __shfl_xor(ex, o); }
+            const float sum = lzw::wave_sum(e0 + e1);
+            const float ex = lzw::wave_sum(e0 * (-1.0f + 0.02f * (float)lane) + e1 * (-1.0f + 0.02f * (float)(lane + 64)));
             if (lane == 0 && value != nullptr) value[n0 + s] = ex / sum;
             if (vlogits != nullptr) {
                 vlogits[(n0 + s) * kBins + lane] = v0;
