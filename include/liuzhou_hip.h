@@ -211,7 +211,10 @@ LZ_API int lz_prof_net_summary(double* total_ms, int64_t* launches, int64_t* eva
  * All buffers are caller-allocated device memory; per game g the regions are
  *   nodes  [g*node_cap  .. +node_cap)   node_cap >= sims + 2
  *   edges  [g*edge_cap  .. +edge_cap)   edge_cap >= (sims + 1) * 72   (worst case, no overflow path)
- *   path   [g*path_cap  .. +path_cap)   path_cap >= sims + 3
+ *   path   [g*path_cap  .. +path_cap)   path_cap >= node_cap + 1
+ * With subtree reuse (lz_tree_advance) the arenas additionally hold the kept subtree: size them
+ * (reuse_factor * sims + 2) nodes (<= 16384) and proportionally more edges; a kept subtree that would not leave
+ * room for the next search is dropped (fresh root) and counted.
  * States are 32-byte packed bitboard records (lz_pack_states). */
 typedef struct LzTreeDesc {
     int64_t num_games;
@@ -219,10 +222,10 @@ typedef struct LzTreeDesc {
     double  exploration_weight;
     const void* root_state;        /* packed [B]: current game states (input of lz_tree_begin) */
     void*    nodes;                /* [B*node_cap] 48-byte records {packed state, int32 edge_begin, int32 nedges (-1 =
-                                      not expanded), 8 B pad} */
+                                      not expanded), int32 parent node (-1 root), 4 B pad} */
     void*    edges;                /* [B*edge_cap] 32-byte records {double W (value sum, child mover's view), float P,
                                       uint32 N | info<<24, int32 child node or -1, int32 child edge_begin, uint8 action,
-                                      uint8 child nedges, 6 B pad};
+                                      uint8 child nedges, uint16 owner node, 4 B pad};
                                       info: bit0 child mover white, bit1 terminal, bits2-3 terminal value + 1 */
     int32_t* n_nodes;              /* [B] */
     int32_t* n_edges;              /* [B] */
@@ -231,7 +234,8 @@ typedef struct LzTreeDesc {
     float*   root_init_value;      /* [B] */
     int32_t* path;                 /* [B*path_cap] */
     int32_t* path_len;             /* [B] */
-    int32_t* leaf_kind;            /* [B] 0 inactive, 1 needs evaluation, 2 terminal (value in leaf_value) */
+    int32_t* leaf_kind;            /* [B] 0 inactive, 1 needs evaluation, 2 terminal (value in leaf_value),
+                                      3 root kept by lz_tree_advance (no evaluation, noise mix only) */
     void*    leaf_state;           /* packed [B]: state awaiting evaluation */
     float*   leaf_value;           /* [B] */
     uint8_t* root_terminal;        /* [B] */
@@ -253,9 +257,15 @@ LZ_API int lz_tree_select(const LzTreeDesc* tree, void* stream);
 LZ_API int lz_tree_expand(const LzTreeDesc* tree, int is_root, const float* log_p1, const float* log_p2,
                           const float* log_pmc, const float* priors220, const float* values,
                           const float* noise, int64_t noise_stride, float epsilon, void* stream);
-/* Root policy (visits^(1/T) in log space), move pick (uniforms != NULL: inverse-CDF sample;
- * NULL: most visits -> Q -> prior -> lowest index), per-child statistics.  child_* are [B,out_cap]. */
-LZ_API int lz_tree_finish(const LzTreeDesc* tree, const float* temperatures, const float* uniforms,
+/* Root policy and move pick (portable_mcts.py:150-261, :690-727), per-child statistics (child_* are [B,out_cap]).
+ *   selection policy = visits^(1/T) in log space with `temperatures`; it drives the move: sample_moves != 0:
+ *     inverse-CDF sample with uniforms[g]; 0: most visits -> Q -> prior -> lowest index; force_uniform[g] != 0
+ *     (opening plies): uniform over the legal children, index floor(uniforms[g] * n).
+ *   policy_dense (training target) = the same with `target_temperatures` (NULL: = temperatures) on the scores
+ *     visits + prior_pseudocount * normalised priors  (policy_target_temperature / _prior_pseudocount). */
+LZ_API int lz_tree_finish(const LzTreeDesc* tree, const float* temperatures, const float* target_temperatures,
+                          float prior_pseudocount, const uint8_t* force_uniform, int sample_moves,
+                          const float* uniforms,
                           float* policy_dense /*[B,220]*/, int32_t* chosen_index, int32_t* chosen_code /*[B,4]*/,
                           uint8_t* chosen_valid, uint8_t* terminal_mask, float* root_value,
                           int32_t* child_count, int32_t* child_action, int32_t* child_visits,
@@ -265,6 +275,19 @@ LZ_API int lz_tree_finish(const LzTreeDesc* tree, const float* temperatures, con
 LZ_API int lz_tree_search(const LzTreeDesc* tree, const LzNetDesc* net, int64_t sims, float* planes /*[B,11,36]*/,
                           float* log_p1, float* log_p2, float* log_pmc, float* values, const float* noise,
                           int64_t noise_stride, float epsilon, void* stream);
+/* AdvanceRoots (src/mcts.py:577-592, portable_mcts.py:74-87, portable_mcts.cpp:739-769): after the host has
+ * played `played_action[g]` (220-d index, -1: none) and refreshed root_state, promote that child to root and keep
+ * its subtree (compacted in place) with its statistics.  Games with reset[g] != 0, inactive games, children that
+ * were never expanded, a child state different from root_state[g], or a kept subtree that leaves no room for
+ * `next_sims` more simulations (counted in *dropped, device int32, may be NULL) start a fresh tree instead.
+ * Follow with lz_tree_search_continue (or lz_tree_expand(is_root=1) + the split-phase loop): kept roots are not
+ * re-evaluated, they only get a fresh noise mix (portable_mcts.py:617-621). */
+LZ_API int lz_tree_advance(const LzTreeDesc* tree, const int32_t* played_action, const uint8_t* reset,
+                           int64_t next_sims, int32_t* dropped, void* stream);
+/* lz_tree_search without the begin: searches the trees prepared by lz_tree_advance. */
+LZ_API int lz_tree_search_continue(const LzTreeDesc* tree, const LzNetDesc* net, int64_t sims, float* planes,
+                                   float* log_p1, float* log_p2, float* log_pmc, float* values, const float* noise,
+                                   int64_t noise_stride, float epsilon, void* stream);
 
 #ifdef __cplusplus
 }

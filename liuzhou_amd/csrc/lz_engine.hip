@@ -31,7 +31,8 @@ constexpr int kBlock = 256;
 constexpr int kWavesPerBlock = 4;
 constexpr int kMaxChildren = 72;
 
-enum LeafKind : int { kLeafInactive = 0, kLeafExpand = 1, kLeafTerminal = 2 };
+// kLeafReusedRoot: the root survived an advance (a21) -- no evaluation needed, only the fresh noise mix
+enum LeafKind : int { kLeafInactive = 0, kLeafExpand = 1, kLeafTerminal = 2, kLeafReusedRoot = 3 };
 // edge info bits
 constexpr uint8_t kInfoWhite = 1;       // child mover is white
 constexpr uint8_t kInfoTerminal = 2;    // child is terminal (game over, or found to have no legal move)
@@ -47,14 +48,16 @@ struct Edge {
     int32_t cbegin;      // child's first edge (valid when child >= 0)
     uint8_t act;         // 220-d action index
     uint8_t cn;          // child's edge count (valid when child >= 0)
-    uint8_t pad[6];
+    uint16_t owner;      // node that owns this edge run (subtree compaction, lz_tree_advance)
+    uint8_t pad[4];
 };
 static_assert(sizeof(Edge) == 32, "edge record is 32 bytes");
 // 48-byte node record
 struct Node {
     Packed state;
     int32_t edge_begin, nedges;      // nedges = -1: not expanded
-    int32_t pad[2];
+    int32_t parent;                  // parent node (-1 for the root)
+    int32_t pad;
 };
 static_assert(sizeof(Node) == 48, "node record is 48 bytes");
 __device__ __forceinline__ int edge_n(uint32_t ni) { return (int)(ni & 0xFFFFFFu); }
@@ -120,14 +123,13 @@ __global__ __launch_bounds__(kBlock) void packed_planes_kernel(const Packed* __r
 }
 
 // ---- begin a search: fresh tree per game -----------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void tree_begin_kernel(Tree t) {
-    const int g = blockIdx.x * kBlock + threadIdx.x;
-    if (g >= t.B) return;
+__device__ __forceinline__ void begin_game(const Tree& t, int g) {
     const Packed rs = t.root_state[g];
     Node& root = t.nodes[(size_t)g * t.node_cap];
     root.state = rs;
     root.edge_begin = 0;
     root.nedges = -1;                                      // unexpanded
+    root.parent = -1;
     t.n_nodes[g] = 1;
     t.n_edges[g] = 0;
     t.root_visits[g] = 0;
@@ -141,6 +143,11 @@ __global__ __launch_bounds__(kBlock) void tree_begin_kernel(Tree t) {
     t.leaf_kind[g] = (term || !act) ? kLeafInactive : kLeafExpand;
     t.leaf_state[g] = rs;                                  // the root is the first pending evaluation
     t.leaf_value[g] = 0.f;
+}
+__global__ __launch_bounds__(kBlock) void tree_begin_kernel(Tree t) {
+    const int g = blockIdx.x * kBlock + threadIdx.x;
+    if (g >= t.B) return;
+    begin_game(t, g);
 }
 
 // ---- select: one wave per game ---------------------------------------------------------------------------
@@ -245,6 +252,38 @@ __device__ __forceinline__ void tree_expand(const Tree& t, int g, int lane, cons
     Node* nodes = t.nodes + (size_t)g * t.node_cap;
     Edge* edges = t.edges + (size_t)g * t.edge_cap;
     const int* path = t.path + (size_t)g * t.path_cap;
+    if (kind == kLeafReusedRoot) {
+        // portable_mcts.py:302-317 / :617-621: a root kept by advance_root gets a fresh noise mix on its
+        // existing priors, renormalised by max(sum, 1e-8); nothing else happens before the first selection.
+        if (IS_ROOT && noise != nullptr) {
+            const int ne = nodes[0].nedges, e0 = nodes[0].edge_begin;
+            if (ne > 1) {
+                const float keep = (float)(1.0 - (double)epsilon);
+                float pr[2]; bool ok[2];
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const int k = r * kWave + lane;
+                    ok[r] = k < ne;
+                    pr[r] = ok[r] ? keep * edges[e0 + k].P + epsilon * noise[(size_t)g * noise_stride + k] : 0.f;
+                }
+                float psum = 0.f;
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    uint64_t m = __ballot(ok[r]);
+                    while (m) {
+                        const int l = __builtin_amdgcn_readfirstlane(__ffsll((unsigned long long)m) - 1);
+                        psum += lzw::lane_bcast(pr[r], l);
+                        m &= m - 1;
+                    }
+                }
+                const float denom = psum < 1e-8f ? 1e-8f : psum;
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+                    if (ok[r]) edges[e0 + r * kWave + lane].P = pr[r] / denom;
+            }
+        }
+        return;
+    }
     const int plen = IS_ROOT ? 0 : t.path_len[g];
     double backup_value = 0.0;
 
@@ -336,12 +375,14 @@ __device__ __forceinline__ void tree_expand(const Tree& t, int g, int lane, cons
                     Edge& in = edges[path[plen - 1]];
                     in.child = node_id; in.cbegin = e0; in.cn = (uint8_t)n;
                     nodes[node_id].state = t.leaf_state[g];
+                    nodes[node_id].parent = (int)in.owner;
                 }
                 nodes[node_id].edge_begin = e0;
                 nodes[node_id].nedges = n;
                 if (IS_ROOT) t.root_init_value[g] = values[g];
             }
             e0 = __builtin_amdgcn_readfirstlane(e0);
+            node_id = __builtin_amdgcn_readfirstlane(node_id);
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 if (!lg[it]) continue;
@@ -363,7 +404,8 @@ __device__ __forceinline__ void tree_expand(const Tree& t, int g, int lane, cons
                 rec.cbegin = 0;
                 rec.act = (uint8_t)a;
                 rec.cn = 0;
-                rec.pad[0] = rec.pad[1] = rec.pad[2] = rec.pad[3] = rec.pad[4] = rec.pad[5] = 0;
+                rec.owner = (uint16_t)node_id;
+                rec.pad[0] = rec.pad[1] = rec.pad[2] = rec.pad[3] = 0;
                 edges[e0 + slot[it]] = rec;
             }
             backup_value = (double)values[g];
@@ -432,10 +474,186 @@ __global__ __launch_bounds__(kBlock) void tree_expand_select_kernel(Tree t, cons
     tree_select(t, g, lane);
 }
 
+// ---- advance (a21): promote the played child to root, keep its subtree ---------------------------------------
+// src/mcts.py:577-592, portable_mcts.py:74-87, portable_mcts.cpp:739-769.  One wave per game, in place:
+//   1. mark the subtree of the chosen child: node ids ascend in expansion order, so a node is kept iff its parent
+//      is kept -- 64 nodes per step, marks as 64-bit ballots in LDS, same-chunk chains resolved by iterating;
+//   2. slide the kept nodes down to their rank (new id <= old id, chunk loads complete before chunk stores);
+//   3. slide the kept edges down (edge runs ascend with their owner's id, so compaction keeps every run
+//      contiguous), translating owner / child ids by rank and child edge offsets from the moved nodes.
+// A game whose child was never expanded, was re-seated, or whose kept subtree would not leave room for the next
+// search (`dropped` counts those) simply starts a fresh tree from root_state, exactly like lz_tree_begin.
+constexpr int kMarkWords = 256;        // subtree reuse supports node_cap <= 16384
+__device__ __forceinline__ int wave_sum_i32(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+__global__ __launch_bounds__(kBlock) void tree_advance_kernel(Tree t, const int* __restrict__ played_action,
+                                                              const uint8_t* __restrict__ reset, int reserve_nodes,
+                                                              int reserve_edges, int* __restrict__ dropped) {
+    __shared__ uint64_t s_mark[kWavesPerBlock][kMarkWords];
+    __shared__ int s_nprefix[kWavesPerBlock][kMarkWords];
+    __shared__ int s_eprefix[kWavesPerBlock][kMarkWords];
+    const int lane = lane_id();
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int g = wave_game();
+    if (g >= t.B) return;
+    Node* nodes = t.nodes + (size_t)g * t.node_cap;
+    Edge* edges = t.edges + (size_t)g * t.edge_cap;
+    uint64_t* mark = s_mark[wv];
+    int* nprefix = s_nprefix[wv];
+    int* eprefix = s_eprefix[wv];
+    const uint64_t lt = (1ull << lane) - 1ull;
+    auto rank_of = [&](int id) { return nprefix[id >> 6] + __popcll(mark[id >> 6] & ((1ull << (id & 63)) - 1ull)); };
+
+    const Packed rs = t.root_state[g];
+    const bool act = t.active == nullptr || t.active[g] != 0;
+    const int ne = nodes[0].nedges, e0 = nodes[0].edge_begin;
+    const int played = played_action != nullptr ? played_action[g] : -1;
+    int c = -1, new_n = 0;
+    double new_w = 0.0;
+    if (act && !(reset != nullptr && reset[g]) && !t.root_terminal[g] && ne > 0 && played >= 0) {
+        int found = -1;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int k = r * kWave + lane;
+            const uint64_t hit = __ballot(k < ne && (int)edges[e0 + (k < ne ? k : 0)].act == played);
+            if (found < 0 && hit) found = r * kWave + __ffsll((unsigned long long)hit) - 1;
+        }
+        if (found >= 0) {
+            const Edge E = edges[e0 + found];
+            if (E.child > 0 && !(edge_info(E.n_info) & kInfoTerminal)) {
+                const Packed cs = nodes[E.child].state;     // must be the state the host moved to
+                if (cs.w0 == rs.w0 && cs.w1 == rs.w1 && cs.w2 == rs.w2 && cs.w3 == rs.w3) {
+                    c = E.child; new_n = edge_n(E.n_info); new_w = E.W;
+                }
+            }
+        }
+    }
+    const int nn = t.n_nodes[g], n_e = t.n_edges[g];
+    int kept_nodes = 0, kept_edges = 0;
+    if (c > 0) {
+        // ---- pass 1: marks + per-word prefix counts ----
+        const int words = (nn + 63) >> 6;
+        for (int w = 0; w < words; ++w) {
+            const int id = w * kWave + lane;
+            const bool valid = id < nn;
+            int parent = -1, cnt = 0;
+            if (valid) { parent = nodes[id].parent; cnt = nodes[id].nedges; }
+            const bool cand = valid && id > c && parent >= c;   // descendants have larger ids than their ancestors
+            bool kept = valid && id == c;
+            if (cand && parent < w * kWave) kept = (mark[parent >> 6] >> (parent & 63)) & 1ull;
+            uint64_t bal = __ballot(kept);
+            for (;;) {                                           // parents inside this chunk
+                const bool nk = kept || (cand && parent >= w * kWave && ((bal >> (parent - w * kWave)) & 1ull));
+                const uint64_t nb = __ballot(nk);
+                kept = nk;
+                if (nb == bal) break;
+                bal = nb;
+            }
+            if (lane == 0) { mark[w] = bal; nprefix[w] = kept_nodes; eprefix[w] = kept_edges; }
+            kept_nodes += __popcll(bal);
+            kept_edges += wave_sum_i32(kept ? cnt : 0);
+        }
+        if (kept_nodes + reserve_nodes > t.node_cap || kept_edges + reserve_edges > t.edge_cap || words > kMarkWords) {
+            c = -1;
+            if (lane == 0 && dropped != nullptr) atomicAdd(dropped, 1);
+        }
+    }
+    if (c <= 0) {
+        if (lane == 0) begin_game(t, g);
+        return;
+    }
+    // ---- pass 2: nodes ----
+    const int words = (nn + 63) >> 6;
+    for (int w = 0; w < words; ++w) {
+        const uint64_t m = mark[w];
+        if (!m) continue;
+        const int id = w * kWave + lane;
+        const bool kept = (m >> lane) & 1ull;
+        Node rec;
+        int cnt = 0;
+        if (kept) { rec = nodes[id]; cnt = rec.nedges; }
+        int incl = cnt;
+#pragma unroll
+        for (int o = 1; o < kWave; o <<= 1) { const int up = __shfl_up(incl, o); if (lane >= o) incl += up; }
+        if (kept) {
+            rec.edge_begin = eprefix[w] + incl - cnt;
+            rec.parent = id == c ? -1 : rank_of(rec.parent);
+            nodes[nprefix[w] + __popcll(m & lt)] = rec;
+        }
+    }
+    __threadfence_block();
+    // ---- pass 3: edges ----
+    int run = 0;
+    for (int base = 0; base < n_e; base += kWave) {
+        const int e = base + lane;
+        const bool valid = e < n_e;
+        Edge rec;
+        bool kept = false;
+        if (valid) {
+            rec = edges[e];
+            kept = (mark[rec.owner >> 6] >> (rec.owner & 63)) & 1ull;
+        }
+        const uint64_t bal = __ballot(kept);
+        if (kept) {
+            rec.owner = (uint16_t)rank_of(rec.owner);
+            if (rec.child >= 0) {
+                const int nc = rank_of(rec.child);
+                rec.child = nc;
+                rec.cbegin = nodes[nc].edge_begin;
+            }
+            edges[run + __popcll(bal & lt)] = rec;
+        }
+        run += __popcll(bal);
+    }
+    if (lane == 0) {
+        t.n_nodes[g] = kept_nodes;
+        t.n_edges[g] = kept_edges;
+        t.root_visits[g] = new_n;
+        t.root_W[g] = new_w;
+        t.root_init_value[g] = 0.f;
+        t.path_len[g] = 0;
+        t.root_terminal[g] = 0;
+        t.leaf_kind[g] = kLeafReusedRoot;
+        t.leaf_state[g] = rs;          // evaluated with the rest of the batch, result unused
+        t.leaf_value[g] = 0.f;
+    }
+}
+
 // ---- finish: root policy / pick -----------------------------------------------------------------------------
-// policy = softmax(log(N)/T) over visited children (T <= 1e-6: one-hot argmax) (portable_mcts.py:150-205)
-// pick   = inverse-CDF sample with the given uniform, or N -> Q -> P -> index (portable_mcts.py:208-261)
+// policy = softmax(log(score)/T) over children with score > 0 (T <= 1e-6: one-hot argmax), score = N or, for the
+//          training target, N + beta * normalised prior                        (portable_mcts.py:150-205, :690-700)
+// pick   = uniform over the legal children (opening plies, :709-712), inverse-CDF sample of the selection policy
+//          with the given uniform, or N -> Q -> P -> index                       (portable_mcts.py:208-261)
+__device__ __forceinline__ void score_policy(const float (&sc)[2], const bool (&ok)[2], float temp, int lane,
+                                             float (&pol)[2]) {
+    const float smax = lzw::wave_max(fmaxf(ok[0] ? sc[0] : -1.f, ok[1] ? sc[1] : -1.f));
+    if (temp <= 1e-6f) {
+        const uint64_t lo = __ballot(ok[0] && sc[0] == smax);
+        int am;
+        if (lo) am = __ffsll((unsigned long long)lo) - 1;
+        else am = kWave + __ffsll((unsigned long long)__ballot(ok[1] && sc[1] == smax)) - 1;
+        pol[0] = (lane == am) ? 1.f : 0.f;
+        pol[1] = (kWave + lane == am) ? 1.f : 0.f;
+    } else {
+        const float tt = fmaxf(temp, 1e-6f);
+        const float lg0 = (ok[0] && sc[0] > 0.f) ? logf(sc[0]) / tt : -INFINITY;
+        const float lg1 = (ok[1] && sc[1] > 0.f) ? logf(sc[1]) / tt : -INFINITY;
+        const float mx = lzw::wave_max(fmaxf(lg0, lg1));
+        const float e0f = lg0 == -INFINITY ? 0.f : expf(lg0 - mx), e1f = lg1 == -INFINITY ? 0.f : expf(lg1 - mx);
+        const float sum = lzw::wave_sum(e0f + e1f);
+        pol[0] = e0f / sum; pol[1] = e1f / sum;
+    }
+}
+
 __global__ __launch_bounds__(kBlock) void tree_finish_kernel(Tree t, const float* __restrict__ temps,
+                                                             const float* __restrict__ target_temps,
+                                                             float prior_pseudocount,
+                                                             const uint8_t* __restrict__ force_uniform,
+                                                             int sample_moves,
                                                              const float* __restrict__ uniforms,
                                                              float* __restrict__ policy_dense,
                                                              int* __restrict__ chosen_index,
@@ -491,30 +709,33 @@ __global__ __launch_bounds__(kBlock) void tree_finish_kernel(Tree t, const float
             child_prior[(size_t)g * out_cap + k] = pr[r];
         }
     }
-    // ---- policy ----
+    // ---- selection policy (drives the move), and the training target written to policy_dense ----
     float pol[2] = {0.f, 0.f};
-    float vmax = lzw::wave_max(fmaxf(ok[0] ? v[0] : -1.f, ok[1] ? v[1] : -1.f));
-    if (temp <= 1e-6f) {
-        uint64_t lo = __ballot(ok[0] && v[0] == vmax);
-        int am;
-        if (lo) am = __ffsll((unsigned long long)lo) - 1;
-        else am = kWave + __ffsll((unsigned long long)__ballot(ok[1] && v[1] == vmax)) - 1;
-        pol[0] = (lane == am) ? 1.f : 0.f;
-        pol[1] = (kWave + lane == am) ? 1.f : 0.f;
-    } else {
-        const float tt = fmaxf(temp, 1e-6f);
-        float lg0 = (ok[0] && v[0] > 0.f) ? logf(v[0]) / tt : -INFINITY;
-        float lg1 = (ok[1] && v[1] > 0.f) ? logf(v[1]) / tt : -INFINITY;
-        const float mx = lzw::wave_max(fmaxf(lg0, lg1));
-        float e0f = lg0 == -INFINITY ? 0.f : expf(lg0 - mx), e1f = lg1 == -INFINITY ? 0.f : expf(lg1 - mx);
-        const float sum = lzw::wave_sum(e0f + e1f);
-        pol[0] = e0f / sum; pol[1] = e1f / sum;
-    }
+    const float vmax = lzw::wave_max(fmaxf(ok[0] ? v[0] : -1.f, ok[1] ? v[1] : -1.f));
+    score_policy(v, ok, temp, lane, pol);
+    if (target_temps == nullptr && !(prior_pseudocount > 0.f)) {
 #pragma unroll
-    for (int r = 0; r < 2; ++r) if (ok[r]) prow[act[r]] = pol[r];
+        for (int r = 0; r < 2; ++r) if (ok[r]) prow[act[r]] = pol[r];
+    } else {
+        float sc[2] = {v[0], v[1]};
+        if (prior_pseudocount > 0.f) {
+            const float c0 = ok[0] ? fmaxf(pr[0], 1e-8f) : 0.f, c1 = ok[1] ? fmaxf(pr[1], 1e-8f) : 0.f;
+            const float psum = lzw::wave_sum(c0 + c1);
+            const bool bad = !(psum > 0.f) || !isfinite(psum);
+            sc[0] = v[0] + prior_pseudocount * (bad ? 1.0f / (float)ne : c0 / psum);
+            sc[1] = v[1] + prior_pseudocount * (bad ? 1.0f / (float)ne : c1 / psum);
+        }
+        float tpol[2] = {0.f, 0.f};
+        score_policy(sc, ok, target_temps != nullptr ? target_temps[g] : temp, lane, tpol);
+#pragma unroll
+        for (int r = 0; r < 2; ++r) if (ok[r]) prow[act[r]] = tpol[r];
+    }
     // ---- pick ----
     int pick = -1;
-    if (uniforms != nullptr) {
+    if (force_uniform != nullptr && force_uniform[g] && uniforms != nullptr) {
+        pick = (int)(uniforms[g] * (float)ne);
+        pick = pick < 0 ? 0 : (pick >= ne ? ne - 1 : pick);
+    } else if (sample_moves && uniforms != nullptr) {
         const float target = uniforms[g];
         float run = 0.f;
         int last = -1;
@@ -634,7 +855,9 @@ int lz_tree_expand(const LzTreeDesc* d, int is_root, const float* lp1, const flo
     return st();
 }
 
-int lz_tree_finish(const LzTreeDesc* d, const float* temperatures, const float* uniforms, float* policy_dense,
+int lz_tree_finish(const LzTreeDesc* d, const float* temperatures, const float* target_temperatures,
+                   float prior_pseudocount, const uint8_t* force_uniform, int sample_moves, const float* uniforms,
+                   float* policy_dense,
                    int32_t* chosen_index, int32_t* chosen_code, uint8_t* chosen_valid, uint8_t* terminal_mask,
                    float* root_value, int32_t* child_count, int32_t* child_action, int32_t* child_visits,
                    float* child_prior, int64_t out_cap, void* stream) {
@@ -642,22 +865,36 @@ int lz_tree_finish(const LzTreeDesc* d, const float* temperatures, const float* 
         !terminal_mask || !root_value || !child_count || !child_action || !child_visits || !child_prior || out_cap < 1)
         return LZ_ERR_ARG;
     if (d->num_games == 0) return LZ_OK;
+    if (!(prior_pseudocount >= 0.f) || ((force_uniform || sample_moves) && !uniforms)) return LZ_ERR_ARG;
     hipLaunchKernelGGL(tree_finish_kernel, dim3(gw(d->num_games)), dim3(kBlock), 0, as_stream(stream), make_tree(d),
-                       temperatures, uniforms, policy_dense, chosen_index, reinterpret_cast<int4*>(chosen_code),
+                       temperatures, target_temperatures, prior_pseudocount, force_uniform, sample_moves, uniforms, policy_dense, chosen_index, reinterpret_cast<int4*>(chosen_code),
                        chosen_valid, terminal_mask, root_value, child_count, child_action, child_visits, child_prior,
                        (int)out_cap);
     return st();
 }
 
+int lz_tree_advance(const LzTreeDesc* d, const int32_t* played_action, const uint8_t* reset, int64_t next_sims,
+                    int32_t* dropped, void* stream) {
+    if (!tree_ok(d) || next_sims < 0) return LZ_ERR_ARG;
+    if (d->num_games == 0) return LZ_OK;
+    if (d->node_cap > 65535) return LZ_ERR_ARG;              // edge records carry 16-bit owner ids
+    const int64_t rn = next_sims + 1, re = (next_sims + 1) * kMaxChildren;
+    if (rn > d->node_cap || re > d->edge_cap) return LZ_ERR_ARG;
+    hipLaunchKernelGGL(tree_advance_kernel, dim3(gw(d->num_games)), dim3(kBlock), 0, as_stream(stream), make_tree(d),
+                       played_action, reset, (int)rn, (int)re, dropped);
+    return st();
+}
+
 // Whole search of one move, enqueued from C++ (no Python in the simulation loop, hipGraph-capturable):
-//   begin -> [planes -> net -> expand_root] -> sims x [select -> planes -> net -> expand+backup]
-int lz_tree_search(const LzTreeDesc* d, const LzNetDesc* net, int64_t sims, float* planes, float* lp1, float* lp2,
-                   float* lpmc, float* values, const float* noise, int64_t noise_stride, float epsilon,
-                   void* stream) {
+//   begin -> [net -> expand_root + select] -> (sims-1) x [net -> expand+backup + select] -> net -> expand+backup
+// `continue_trees`: the roots were prepared by lz_tree_advance (kept subtrees or fresh roots), so no begin.
+static int tree_search_impl(const LzTreeDesc* d, const LzNetDesc* net, int64_t sims, float* planes, float* lp1,
+                            float* lp2, float* lpmc, float* values, const float* noise, int64_t noise_stride,
+                            float epsilon, bool continue_trees, void* stream) {
     if (!tree_ok(d) || !net || sims < 0 || !lp1 || !lp2 || !lpmc || !values) return LZ_ERR_ARG;
     const int64_t B = d->num_games;
     if (B == 0) return LZ_OK;
-    int rc = lz_tree_begin(d, stream);
+    int rc = continue_trees ? LZ_OK : lz_tree_begin(d, stream);
     if (rc) return rc;
     (void)planes;   // the network kernel stages its input straight from the 32-byte packed leaf states
     const Tree t = make_tree(d);
@@ -677,6 +914,18 @@ int lz_tree_search(const LzTreeDesc* d, const LzNetDesc* net, int64_t sims, floa
         }
     }
     return st();
+}
+
+int lz_tree_search(const LzTreeDesc* d, const LzNetDesc* net, int64_t sims, float* planes, float* lp1, float* lp2,
+                   float* lpmc, float* values, const float* noise, int64_t noise_stride, float epsilon,
+                   void* stream) {
+    return tree_search_impl(d, net, sims, planes, lp1, lp2, lpmc, values, noise, noise_stride, epsilon, false, stream);
+}
+
+int lz_tree_search_continue(const LzTreeDesc* d, const LzNetDesc* net, int64_t sims, float* planes, float* lp1,
+                            float* lp2, float* lpmc, float* values, const float* noise, int64_t noise_stride,
+                            float epsilon, void* stream) {
+    return tree_search_impl(d, net, sims, planes, lp1, lp2, lpmc, values, noise, noise_stride, epsilon, true, stream);
 }
 
 }  // extern "C"

@@ -174,7 +174,10 @@ def run_self_play_worker(*, worker_idx: int, shard_device: str, shard_games: int
                           sample_moves=bool(sample_moves), concurrent_games=max(1, min(n, concurrent)), verbose=False)
             if backend in ("portable", "tree"):
                 from .tree_engine import self_play_tree_gpu
-                return self_play_tree_gpu(evaluator, **common)
+                return self_play_tree_gpu(evaluator, opening_random_moves=int(opening_random_moves),
+                                          policy_target_temperature=policy_target_temperature,
+                                          policy_target_prior_pseudocount=float(policy_target_prior_pseudocount),
+                                          **common)
             from .self_play_gpu_runner import self_play_v1_gpu
             return self_play_v1_gpu(evaluator, opening_random_moves=int(opening_random_moves), sparse_ply=int(sparse_ply),
                                     sparse_top_k=int(sparse_top_k), **common)

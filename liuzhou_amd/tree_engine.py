@@ -39,16 +39,24 @@ class LzTreeDesc(C.Structure):
                    "active")]
 
 
+REUSE_EDGES_PER_NODE = 40      # arena sizing for kept subtrees (average fan-out is ~25; overflow drops the subtree)
+
+
 class TreeEngine:
-    def __init__(self, num_games: int, max_sims: int, device, exploration_weight: float = 1.0) -> None:
+    def __init__(self, num_games: int, max_sims: int, device, exploration_weight: float = 1.0,
+                 reuse_factor: float = 0.0) -> None:
+        """`reuse_factor` > 0 reserves room for kept subtrees of up to reuse_factor * max_sims nodes (advance())."""
         dev = torch.device(device)
         if dev.type != "cuda":
             raise RuntimeError("TreeEngine needs a HIP device (no CPU path)")
         self.device, self.B, self.max_sims = dev, int(num_games), int(max_sims)
         B = self.B
-        self.node_cap = self.max_sims + 2
-        self.edge_cap = (self.max_sims + 1) * MAX_CHILDREN
-        self.path_cap = self.max_sims + 3
+        extra = int(max(0.0, float(reuse_factor)) * self.max_sims)
+        self.node_cap = self.max_sims + 2 + extra
+        self.edge_cap = (self.max_sims + 1) * MAX_CHILDREN + extra * REUSE_EDGES_PER_NODE
+        self.path_cap = self.node_cap + 1
+        if extra and self.node_cap > 16384:
+            raise ValueError(f"subtree reuse supports at most 16384 nodes per game, got {self.node_cap}")
         z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)
         self.buf: Dict[str, torch.Tensor] = {
             "root_state": z((B, 4), torch.int64),
@@ -81,6 +89,7 @@ class TreeEngine:
         self.child_action = z((B, OUT_CAP), torch.int32)
         self.child_visits = z((B, OUT_CAP), torch.int32)
         self.child_prior = z((B, OUT_CAP), torch.float32)
+        self.reuse_dropped = z((1,), torch.int32)
 
     def hbm_bytes(self) -> int:
         return sum(t.numel() * t.element_size() for t in self.buf.values())
@@ -125,23 +134,46 @@ class TreeEngine:
                                            L.ptr(lpm), L.ptr(priors220), L.ptr(values), L.ptr(noise), L.i64(nz_stride),
                                            C.c_float(float(epsilon)), self._stream()), "tree_expand")
 
-    def finish(self, temperatures: torch.Tensor, uniforms: Optional[torch.Tensor]) -> None:
+    def finish(self, temperatures: torch.Tensor, uniforms: Optional[torch.Tensor],
+               target_temperatures: Optional[torch.Tensor] = None, prior_pseudocount: float = 0.0,
+               force_uniform: Optional[torch.Tensor] = None, sample_moves: Optional[bool] = None) -> None:
+        """`sample_moves` defaults to "sample iff uniforms are given"."""
+        sample = uniforms is not None if sample_moves is None else bool(sample_moves)
+        if force_uniform is not None and force_uniform.dtype != torch.uint8:
+            force_uniform = force_uniform.to(torch.uint8)
         with torch.cuda.device(self.device):
-            L.check(L.lib().lz_tree_finish(C.byref(self.desc), L.ptr(temperatures), L.ptr(uniforms),
+            L.check(L.lib().lz_tree_finish(C.byref(self.desc), L.ptr(temperatures), L.ptr(target_temperatures),
+                                           C.c_float(float(prior_pseudocount)), L.ptr(force_uniform), C.c_int(int(sample)),
+                                           L.ptr(uniforms),
                                            L.ptr(self.policy_dense), L.ptr(self.chosen_index), L.ptr(self.chosen_code),
                                            L.ptr(self.chosen_valid), L.ptr(self.terminal_mask), L.ptr(self.root_value),
                                            L.ptr(self.child_count), L.ptr(self.child_action), L.ptr(self.child_visits),
                                            L.ptr(self.child_prior), L.i64(OUT_CAP), self._stream()), "tree_finish")
 
-    def search(self, net: FusedNet, sims: int, noise: Optional[torch.Tensor] = None, epsilon: float = 0.25) -> None:
-        """Whole search of one move (C++ loop: begin, root, sims x select/eval/expand)."""
+    def advance(self, played_action: Optional[torch.Tensor] = None, reset: Optional[torch.Tensor] = None,
+                next_sims: Optional[int] = None) -> None:
+        """Tree reuse (a21): promote the played child of every game to root, keeping its subtree.  Call after
+        set_roots() with the post-move states; `played_action` int32[B] defaults to the last finish()'s picks."""
+        pa = self.chosen_index if played_action is None else played_action.to(torch.int32).contiguous()
+        if reset is not None and reset.dtype != torch.uint8:
+            reset = reset.to(torch.uint8)
+        sims = self.max_sims if next_sims is None else int(next_sims)
+        with torch.cuda.device(self.device):
+            L.check(L.lib().lz_tree_advance(C.byref(self.desc), L.ptr(pa), L.ptr(reset), L.i64(sims),
+                                            L.ptr(self.reuse_dropped), self._stream()), "tree_advance")
+
+    def search(self, net: FusedNet, sims: int, noise: Optional[torch.Tensor] = None, epsilon: float = 0.25,
+               continue_trees: bool = False) -> None:
+        """Whole search of one move (C++ loop: begin, root, sims x select/eval/expand); `continue_trees`: the
+        trees were prepared by advance() (kept subtrees / fresh roots), no begin."""
         if int(sims) > self.max_sims:
             raise ValueError(f"sims={sims} exceeds the arena capacity max_sims={self.max_sims}")
         nz_stride = int(noise.shape[1]) if noise is not None else 0
+        fn = L.lib().lz_tree_search_continue if continue_trees else L.lib().lz_tree_search
         with torch.cuda.device(self.device):
-            L.check(L.lib().lz_tree_search(C.byref(self.desc), C.byref(net.desc), L.i64(sims), L.ptr(self.planes),
-                                           L.ptr(self.lp1), L.ptr(self.lp2), L.ptr(self.lpm), L.ptr(self.values),
-                                           L.ptr(noise), L.i64(nz_stride), C.c_float(float(epsilon)), self._stream()),
+            L.check(fn(C.byref(self.desc), C.byref(net.desc), L.i64(sims), L.ptr(self.planes),
+                       L.ptr(self.lp1), L.ptr(self.lp2), L.ptr(self.lpm), L.ptr(self.values),
+                       L.ptr(noise), L.i64(nz_stride), C.c_float(float(epsilon)), self._stream()),
                     "tree_search")
 
 
@@ -158,9 +190,19 @@ class PortableTreeMCTS:
 
     def __init__(self, net: FusedNet, num_games: int, num_simulations: int, device, exploration_weight: float = 1.0,
                  add_dirichlet_noise: bool = True, dirichlet_alpha: float = 0.3, dirichlet_epsilon: float = 0.25,
-                 sample_moves: bool = True, use_graph: Optional[bool] = None) -> None:
+                 sample_moves: bool = True, use_graph: Optional[bool] = None, reuse_tree: bool = False,
+                 reuse_factor: float = 3.0, policy_target_temperature: Optional[float] = None,
+                 policy_target_prior_pseudocount: float = 0.0) -> None:
+        """`reuse_tree`: keep the played child's subtree between consecutive search_batch calls on the same games
+        (the reference's portable self-play does, v1/python/portable_self_play.py:191); the arenas then hold
+        (1 + reuse_factor) * sims nodes per game.  `policy_target_*`: portable_mcts.py:690-700."""
         self.net, self.sims = net, int(num_simulations)
-        self.engine = TreeEngine(num_games, num_simulations, device, exploration_weight)
+        self.reuse_tree = bool(reuse_tree)
+        self.engine = TreeEngine(num_games, num_simulations, device, exploration_weight,
+                                 reuse_factor=float(reuse_factor) if self.reuse_tree else 0.0)
+        self.target_temperature = None if policy_target_temperature is None else float(policy_target_temperature)
+        self.prior_pseudocount = float(policy_target_prior_pseudocount)
+        self._have_trees = False
         self.add_noise, self.alpha, self.eps = bool(add_dirichlet_noise), float(dirichlet_alpha), float(dirichlet_epsilon)
         self.sample_moves = bool(sample_moves)
         self.leaf_evals = 0
@@ -172,34 +214,54 @@ class PortableTreeMCTS:
         self._graphs = {}
         self._noise_buf = torch.zeros((self.engine.B, OUT_CAP), dtype=torch.float32, device=self.engine.device)
 
-    def _search(self, add_noise: bool) -> None:
+    def _search(self, add_noise: bool, continue_trees: bool) -> None:
         e = self.engine
+        noise = self._noise_buf if add_noise else None
         if not self.use_graph:
-            e.search(self.net, self.sims, self._noise_buf if add_noise else None, self.eps)
+            e.search(self.net, self.sims, noise, self.eps, continue_trees)
             return
-        g = self._graphs.get(add_noise)
+        key = (add_noise, continue_trees)
+        g = self._graphs.get(key)
         if g is None:
-            # warm-up launch outside capture, then capture on a side stream as torch requires
-            e.search(self.net, self.sims, self._noise_buf if add_noise else None, self.eps)
+            if not continue_trees:
+                # warm-up launch outside capture (a fresh search starts by resetting the trees, so running it twice
+                # is harmless); a continued search must run exactly once and is only reached after a fresh one
+                e.search(self.net, self.sims, noise, self.eps, False)
             torch.cuda.synchronize(e.device)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                e.search(self.net, self.sims, self._noise_buf if add_noise else None, self.eps)
-            self._graphs[add_noise] = g
+                e.search(self.net, self.sims, noise, self.eps, continue_trees)
+            self._graphs[key] = g
         g.replay()
 
+    def reset_trees(self) -> None:
+        """Forget the kept subtrees: the next search_batch starts every game from a fresh root."""
+        self._have_trees = False
+
     def search_batch(self, state: GpuStateBatch, *, temperatures: torch.Tensor, active: Optional[torch.Tensor] = None,
-                     add_dirichlet_noise: Optional[bool] = None) -> RootSearchBatchOutput:
+                     add_dirichlet_noise: Optional[bool] = None, reset: Optional[torch.Tensor] = None,
+                     played_action: Optional[torch.Tensor] = None,
+                     force_uniform_random_mask: Optional[torch.Tensor] = None) -> RootSearchBatchOutput:
+        """`state`: the games' current positions.  With `reuse_tree`, games whose position is the child reached by
+        `played_action` (default: the move this engine picked last time) keep that child's subtree; `reset` marks
+        games that were re-seated.  Anything that does not match simply starts a fresh tree."""
         e = self.engine
         dev = e.device
         add_noise = self.add_noise if add_dirichlet_noise is None else bool(add_dirichlet_noise)
         e.set_roots(state, active)
+        continue_trees = self.reuse_tree and self._have_trees
+        if continue_trees:
+            e.advance(played_action, reset, self.sims)
         if add_noise:
             self._noise_buf.copy_(dirichlet_noise((e.B, OUT_CAP), self.alpha, dev))
-        self._search(add_noise)
+        self._search(add_noise, continue_trees)
+        self._have_trees = True
         self.leaf_evals += e.B * (self.sims + 1)
-        uniforms = torch.rand((e.B,), dtype=torch.float32, device=dev) if self.sample_moves else None
-        e.finish(temperatures.to(torch.float32).contiguous(), uniforms)
+        need_u = self.sample_moves or force_uniform_random_mask is not None
+        uniforms = torch.rand((e.B,), dtype=torch.float32, device=dev) if need_u else None
+        temps = temperatures.to(torch.float32).contiguous()
+        tt = None if self.target_temperature is None else torch.full_like(temps, self.target_temperature)
+        e.finish(temps, uniforms, tt, self.prior_pseudocount, force_uniform_random_mask, self.sample_moves)
         model_input = states_to_model_input(state)
         legal_mask, _ = encode_actions_fast(state)
         return RootSearchBatchOutput(
@@ -213,7 +275,8 @@ class SteadyStateTreeSelfPlay:
 
     def __init__(self, model, num_games: int, sims: int, device, dtype: str = "float16", seed: int = 12345,
                  temperature_init: float = 1.0, temperature_final: float = 0.1, temperature_threshold: int = 10,
-                 max_game_plies: int = 512, exploration_weight: float = 1.0) -> None:
+                 max_game_plies: int = 512, exploration_weight: float = 1.0, reuse_tree: bool = False,
+                 reuse_factor: float = 3.0) -> None:
         from .steady_state import SteadyStateRootSelfPlay
         from .mcts_gpu import V1RootMCTSConfig
         dev = torch.device(device)
@@ -223,7 +286,9 @@ class SteadyStateTreeSelfPlay:
         self.pop = SteadyStateRootSelfPlay(self.net, num_games, V1RootMCTSConfig(num_simulations=1), dev, seed=seed,
                                            temperature_init=temperature_init, temperature_final=temperature_final,
                                            temperature_threshold=temperature_threshold, max_game_plies=max_game_plies)
-        self.mcts = PortableTreeMCTS(self.net, num_games, sims, dev, exploration_weight)
+        self.mcts = PortableTreeMCTS(self.net, num_games, sims, dev, exploration_weight, reuse_tree=reuse_tree,
+                                     reuse_factor=reuse_factor)
+        self._reseated = torch.zeros((self.B,), dtype=torch.uint8, device=dev)
         self.positions = 0
         self._nn_events = []
 
@@ -237,7 +302,8 @@ class SteadyStateTreeSelfPlay:
     def step(self) -> None:
         p = self.pop
         temps = torch.where(p.plies < p.t_thr, p.t_init, p.t_final).to(torch.float32)
-        search = self.mcts.search_batch(p.states, temperatures=temps)
+        search = self.mcts.search_batch(p.states, temperatures=temps, reset=self._reseated)
+        self._reseated.zero_()
         rows = p.buffer.append_steps(search.model_input, search.legal_mask, search.policy_dense, p.states.current_player)
         p.step_index[p.all_idx, p.step_counts] = rows
         p.step_counts.add_(p.ones)
@@ -251,19 +317,26 @@ class SteadyStateTreeSelfPlay:
             p.outcome.add_(out)
             p.games_finished += int(fin.numel())
             p._reset_slots(fin)
+            self._reseated.index_fill_(0, fin, 1)
 
 
 def self_play_tree_gpu(model, num_games: int, mcts_simulations: int, temperature_init: float, temperature_final: float,
                        temperature_threshold: int, exploration_weight: float, device: str,
                        add_dirichlet_noise: bool = True, dirichlet_alpha: float = 0.3, dirichlet_epsilon: float = 0.25,
-                       soft_value_k: float = 2.0, max_game_plies: int = 512, sample_moves: bool = True,
-                       concurrent_games: int = 8, verbose: bool = False) -> Tuple[TensorSelfPlayBatch, SelfPlayV1Stats]:
-    """Tree-search twin of self_play_v1_gpu (same outputs); mirrors v1/python/portable_self_play.py:82-284."""
+                       soft_value_k: float = 2.0, opening_random_moves: int = 0, max_game_plies: int = 512,
+                       sample_moves: bool = True, concurrent_games: int = 8, verbose: bool = False,
+                       policy_target_temperature: Optional[float] = None,
+                       policy_target_prior_pseudocount: float = 0.0, reuse_tree: bool = True,
+                       reuse_factor: float = 3.0) -> Tuple[TensorSelfPlayBatch, SelfPlayV1Stats]:
+    """Tree-search twin of self_play_v1_gpu (same outputs); mirrors v1/python/portable_self_play.py:82-284,
+    including the subtree reuse it performs on every move (:191, `reuse_tree`)."""
     dev = torch.device(device)
     net = model if isinstance(model, FusedNet) else FusedNet(model, dev)
     wave = max(1, min(int(concurrent_games), int(num_games)))
     mcts = PortableTreeMCTS(net, wave, mcts_simulations, dev, exploration_weight, add_dirichlet_noise, dirichlet_alpha,
-                            dirichlet_epsilon, sample_moves)
+                            dirichlet_epsilon, sample_moves, reuse_tree=reuse_tree, reuse_factor=reuse_factor,
+                            policy_target_temperature=policy_target_temperature,
+                            policy_target_prior_pseudocount=policy_target_prior_pseudocount)
     buffer = TensorTrajectoryBuffer(dev, TOTAL_ACTION_DIM, max_steps_hint=max_game_plies, concurrent_games_hint=wave)
     outcome = torch.zeros((3,), dtype=torch.int64, device=dev)
     lengths = torch.zeros((int(num_games),), dtype=torch.int64, device=dev)
@@ -277,13 +350,15 @@ def self_play_tree_gpu(model, num_games: int, mcts_simulations: int, temperature
         done = torch.zeros((wave,), dtype=torch.bool, device=dev)
         if g < wave:
             done[g:] = True
+        mcts.reset_trees()
         while True:
             active = torch.nonzero(~done).view(-1)
             if int(active.numel()) == 0:
                 break
             temps = torch.where(plies < int(temperature_threshold), float(temperature_init),
                                 float(temperature_final)).to(torch.float32)
-            out = mcts.search_batch(states, temperatures=temps, active=~done)
+            force = (plies < int(opening_random_moves)) if int(opening_random_moves) > 0 else None
+            out = mcts.search_batch(states, temperatures=temps, active=~done, force_uniform_random_mask=force)
             rows = buffer.append_steps(out.model_input.index_select(0, active), out.legal_mask.index_select(0, active),
                                        out.policy_dense.index_select(0, active),
                                        states.current_player.index_select(0, active))

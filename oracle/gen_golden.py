@@ -17,6 +17,7 @@ Fixture groups:
   g6_root_puct.npz  root bandit allocation
   g7_ops.npz        pack / finalize / self-play-step / trajectory-finalize op vectors
   g8_selfplay.npz   4-game root-PUCT self-play trace of the reference v1 runner (CPU)
+  g10_tree_selfplay.npz  full-tree self-play traces of the reference portable runner (subtree reuse on every move)
   g9_net.npz        network outputs for seeded weights (tiny / 6x64 / 10x128)
 """
 from __future__ import annotations
@@ -570,6 +571,38 @@ def gen_selfplay():
 
 
 # --------------------------------------------------------------------------------------------
+# G10: reference portable (full tree, subtree reuse) self-play traces on CPU
+# --------------------------------------------------------------------------------------------
+def gen_tree_selfplay():
+    from v1.python.portable_self_play import self_play_v1_portable
+    out = {}
+    for tag, kw in (
+        ("a", dict(num_games=3, mcts_simulations=24, max_game_plies=48, concurrent_games=3)),
+        ("b", dict(num_games=2, mcts_simulations=16, max_game_plies=14, concurrent_games=2,
+                   policy_target_temperature=1.0, policy_target_prior_pseudocount=0.5)),
+    ):
+        model = small_model()
+        torch.manual_seed(0); np.random.seed(0); random.seed(0)
+        batch, stats = self_play_v1_portable(
+            model=model, temperature_init=1.0, temperature_final=0.1, temperature_threshold=10,
+            exploration_weight=1.0, device="cpu", add_dirichlet_noise=False, soft_value_k=2.0,
+            opening_random_moves=0, sample_moves=False, **kw)
+        n = batch.num_samples
+        out.update({
+            f"{tag}_state_tensors": np.packbits(batch.state_tensors.numpy().astype(bool).reshape(n, -1), axis=1),
+            f"{tag}_legal_masks": np.packbits(batch.legal_masks.numpy(), axis=1),
+            f"{tag}_policy_targets": batch.policy_targets.numpy(),
+            f"{tag}_value_targets": batch.value_targets.numpy(),
+            f"{tag}_soft_value_targets": batch.soft_value_targets.numpy(),
+            f"{tag}_outcome": np.array([stats.black_wins, stats.white_wins, stats.draws], np.int64),
+            f"{tag}_config": np.array([kw["num_games"], kw["mcts_simulations"], kw["max_game_plies"]], np.int64),
+        })
+        print(f"[g10/{tag}] tree self-play samples={n} avg_len={stats.avg_game_length:.1f} "
+              f"({stats.positions_per_sec:.1f} pos/s reference-on-CPU)")
+    np.savez_compressed(os.path.join(OUT, "g10_tree_selfplay.npz"), **out)
+
+
+# --------------------------------------------------------------------------------------------
 # G9: network
 # --------------------------------------------------------------------------------------------
 def gen_net(chosen):
@@ -624,6 +657,8 @@ def main():
         gen_selfplay()
     if not which or "g9" in which:
         gen_net(chosen)
+    if not which or "g10" in which:
+        gen_tree_selfplay()
     for f in sorted(os.listdir(OUT)):
         print(f"  {f}: {os.path.getsize(os.path.join(OUT, f)) / 1024:.1f} KiB")
 

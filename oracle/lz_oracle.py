@@ -460,9 +460,15 @@ class OracleTree:
         return int(self._L.lzo_tree_node_count(self._t))
 
 
-def policy_from_visits(visits: np.ndarray, temperature: float) -> np.ndarray:
-    """portable_mcts.py:150-205 with prior_pseudocount = 0 (fp32 like torch)."""
+def policy_from_visits(visits: np.ndarray, temperature: float, priors: Optional[np.ndarray] = None,
+                       prior_pseudocount: float = 0.0) -> np.ndarray:
+    """portable_mcts.py:150-205 (fp32 like torch): scores = visits (+ beta * normalised priors)."""
     v = np.asarray(visits, np.float32)
+    if prior_pseudocount > 0.0:
+        p = np.maximum(np.asarray(priors, np.float32), np.float32(1e-8))
+        ps = float(p.sum(dtype=np.float32))
+        p = np.full_like(p, 1.0 / max(1, p.size)) if (not np.isfinite(ps) or ps <= 0.0) else (p / np.float32(ps))
+        v = (v + np.float32(prior_pseudocount) * p).astype(np.float32)
     if temperature <= 1e-6:
         out = np.zeros_like(v); out[int(np.argmax(v))] = 1.0
         return out

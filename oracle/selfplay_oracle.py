@@ -124,8 +124,9 @@ def self_play_root(model, num_games: int, sims: int, temperature_init: float = 1
 # ---------------------------------------------------------------------------------------------
 def tree_search_batch(evaluate: Callable[[Dict[str, np.ndarray]], Tuple[np.ndarray, np.ndarray]], trees, sims: int,
                       noise_fn: Optional[Callable[[int, int], np.ndarray]] = None, eps: float = 0.25) -> int:
-    """Run `sims` simulations on every OracleTree.  `evaluate(states) -> (priors[B,220], values[B])`.
-    Returns the number of leaf evaluations."""
+    """Run `sims` simulations on every OracleTree (portable_mcts.py:570-650).  `evaluate(states) ->
+    (priors[B,220], values[B])`.  Roots kept by `advance` are not re-evaluated; with noise they get a fresh mix
+    (:617-621).  Returns the number of leaf evaluations."""
     evals = 0
     pend = [i for i, t in enumerate(trees) if t.prepare_root()]
     if pend:
@@ -135,6 +136,12 @@ def tree_search_batch(evaluate: Callable[[Dict[str, np.ndarray]], Tuple[np.ndarr
         for k, i in enumerate(pend):
             nz = noise_fn(i, int((O.encode_actions(O.select_states(st, [k]))[0]).sum())) if noise_fn else None
             trees[i].complete(pri[k], float(val[k]), nz, eps)
+    if noise_fn:
+        fresh = set(pend)
+        for i, t in enumerate(trees):
+            n = int(t.root_children()[0].size)
+            if i not in fresh and n > 0:
+                t.root_noise(noise_fn(i, n), eps)
     for _ in range(sims):
         pend = [i for i, t in enumerate(trees) if t.select()]
         if not pend:
@@ -157,33 +164,85 @@ def make_net_evaluator(model):
     return evaluate
 
 
+def deterministic_pick(idx, vis, vs, pr, pl, root_player: int) -> int:
+    """portable_mcts.py:208-261: most visits, then Q (atol 1e-6), then prior (atol 1e-8), then lowest index."""
+    q = np.where(vis > 0, np.where(pl == root_player, vs, -vs) / np.maximum(vis, 1), 0.0).astype(np.float32)
+    cand = np.nonzero(vis == vis.max())[0]
+    cand = cand[np.abs(q[cand] - q[cand].max()) <= np.float32(1e-6)]
+    cand = cand[np.abs(pr[cand] - pr[cand].max()) <= np.float32(1e-8)]
+    return int(idx[cand.min()])
+
+
 def self_play_tree(model, num_games: int, sims: int, temperature_init: float = 1.0, temperature_final: float = 0.1,
-                   temperature_threshold: int = 10, c: float = 1.0, max_total_plies: Optional[int] = None,
-                   reuse_tree: bool = False, time_budget_s: Optional[float] = None):
-    """variant-P deterministic self-play (argmax N, lowest index) used as the CPU baseline."""
+                   temperature_threshold: int = 10, c: float = 1.0, soft_k: float = 2.0, max_game_plies: int = 512,
+                   concurrent_games: Optional[int] = None, reuse_tree: bool = True,
+                   policy_target_temperature: Optional[float] = None, policy_target_prior_pseudocount: float = 0.0,
+                   time_budget_s: Optional[float] = None, collect: bool = False):
+    """variant-P deterministic self-play (sample_moves=False, no noise): v1/python/portable_self_play.py:82-284.
+    The reference keeps the played child's subtree on every move (`advance_root`, :191); `reuse_tree=False`
+    rebuilds the tree instead.  Returns a stats dict (+ the 5 trajectory tensors when `collect`)."""
     evaluate = make_net_evaluator(model)
-    cur = [O.state_from_batch(O.initial_states(1), 0) for _ in range(num_games)]
-    done = [False] * num_games
-    positions = 0
-    evals = 0
+    wave = num_games if concurrent_games is None else max(1, min(int(concurrent_games), int(num_games)))
+    rows: Dict[str, list] = dict(S=[], L=[], P=[], V=[], SV=[])
+    positions = evals = 0
+    outcome = np.zeros(3, np.int64)
     t0 = time.perf_counter()
-    waves = 0
-    while not all(done) and (max_total_plies is None or waves < max_total_plies):
-        if time_budget_s is not None and waves > 0 and time.perf_counter() - t0 > time_budget_s:
+    out_of_time = False
+    for base in range(0, num_games, wave):
+        n = min(wave, num_games - base)
+        trees = [O.OracleTree(O.state_from_batch(O.initial_states(1), 0), c) for _ in range(n)]
+        cur = [O.state_from_batch(O.initial_states(1), 0) for _ in range(n)]
+        steps = [[] for _ in range(n)]
+        plies = [0] * n
+        done = [False] * n
+        waves = 0
+        while not all(done):
+            if time_budget_s is not None and waves > 0 and time.perf_counter() - t0 > time_budget_s:
+                out_of_time = True
+                break
+            act = [i for i in range(n) if not done[i]]
+            evals += tree_search_batch(evaluate, [trees[i] for i in act], sims)
+            for i in act:
+                t = trees[i]
+                if t.root_terminal():
+                    done[i] = True
+                else:
+                    idx, vis, vs, pr, pl = t.root_children()
+                    temp = temperature_init if plies[i] < temperature_threshold else temperature_final
+                    tt = temp if policy_target_temperature is None else float(policy_target_temperature)
+                    pol = np.zeros(220, np.float32)
+                    pol[idx] = O.policy_from_visits(vis, tt, pr, policy_target_prior_pseudocount)
+                    if collect:
+                        one = O.batch_from_states([cur[i]])
+                        steps[i].append((O.states_to_model_input(one)[0], O.encode_actions(one)[0][0], pol,
+                                         1 if int(cur[i].player) >= 0 else -1))
+                    pick = deterministic_pick(idx, vis, vs, pr, pl, t.root_player())
+                    positions += 1
+                    cur[i] = O.apply_index(cur[i], pick)
+                    if not (reuse_tree and t.advance(pick)):
+                        trees[i] = O.OracleTree(cur[i], c)
+                    plies[i] += 1
+                    if O.game_status(cur[i]) != 0 or plies[i] >= max_game_plies:
+                        done[i] = True
+                if done[i]:
+                    st = O.game_status(cur[i])
+                    res = 1.0 if st == 1 else (-1.0 if st == -1 else 0.0)
+                    outcome[0 if res > 0 else (1 if res < 0 else 2)] += 1
+                    if collect:
+                        soft = float(O.soft_value_from_board(O.batch_from_states([cur[i]])["board"], soft_k)[0])
+                        for x, m, p, sg in steps[i]:
+                            rows["S"].append(x); rows["L"].append(m); rows["P"].append(p)
+                            rows["V"].append(np.float32(res * sg)); rows["SV"].append(np.float32(soft * sg))
+            waves += 1
+        if out_of_time:
             break
-        act = [i for i in range(num_games) if not done[i]]
-        trees = [O.OracleTree(cur[i], c) for i in act]
-        evals += tree_search_batch(evaluate, trees, sims)
-        for t, i in zip(trees, act):
-            if t.root_terminal():
-                done[i] = True
-                continue
-            idx, vis, _, _, _ = t.root_children()
-            positions += 1
-            cur[i] = O.apply_index(cur[i], int(idx[int(np.argmax(vis))]))
-            if O.game_status(cur[i]) != 0:
-                done[i] = True
-        waves += 1
     elapsed = time.perf_counter() - t0
-    return dict(num_positions=positions, elapsed_sec=elapsed, positions_per_sec=positions / max(elapsed, 1e-9),
-                leaf_evals=evals)
+    out = dict(num_positions=positions, elapsed_sec=elapsed, positions_per_sec=positions / max(elapsed, 1e-9),
+               leaf_evals=evals, black_wins=int(outcome[0]), white_wins=int(outcome[1]), draws=int(outcome[2]))
+    if collect:
+        out["tensors"] = dict(
+            state_tensors=np.stack(rows["S"]) if rows["S"] else np.zeros((0, 11, 6, 6), np.float32),
+            legal_masks=np.stack(rows["L"]) if rows["L"] else np.zeros((0, 220), bool),
+            policy_targets=np.stack(rows["P"]) if rows["P"] else np.zeros((0, 220), np.float32),
+            value_targets=np.array(rows["V"], np.float32), soft_value_targets=np.array(rows["SV"], np.float32))
+    return out

@@ -132,3 +132,137 @@ def test_fused_search_runs_and_conserves_visits():
     assert bool(out.chosen_valid_mask.all())
     picked = out.legal_mask.gather(1, out.chosen_action_indices.view(-1, 1)).view(-1)
     assert bool(picked.all())
+
+
+@pytest.mark.parametrize("sims,games,moves,noise", [(48, 48, 4, True), (200, 24, 3, False)])
+def test_tree_reuse_bit_exact_vs_oracle_over_consecutive_moves(sims, games, moves, noise):
+    """a21 (advance_root): the played child's subtree is kept, compacted in place, re-noised and searched on."""
+    _need_gpu()
+    from tests.tree_parity import run_injected_reuse_parity
+    eng, kept = run_injected_reuse_parity(DEV, num_games=games, sims=sims, moves=moves, seed=sims, with_noise=noise)
+    assert kept > 0, "no game ever kept a subtree -- the test did not exercise the reuse path"
+
+
+def test_tree_reuse_falls_back_to_fresh_roots():
+    """reset flags, unknown played actions and states that are not the child all start a fresh tree; a subtree that
+    would not leave room for the next search is dropped and counted."""
+    _need_gpu()
+    from liuzhou_amd.tree_engine import TreeEngine
+    from tests.tree_parity import hash_evaluator, unpack_packed
+    from oracle import lz_oracle as O
+    z = load("g1_rules.npz")
+    st = states(z, "s")
+    idx = np.random.default_rng(5).integers(0, st["board"].shape[0], 32)
+    sub = {f: np.ascontiguousarray(np.asarray(st[f])[idx]) for f in FIELDS}
+    B, sims = 32, 40
+
+    def search(eng):
+        for s in range(sims + 1):
+            if s:
+                eng.select()
+            leaf = unpack_packed(eng.buf["leaf_state"].cpu().numpy())
+            pri, val = hash_evaluator(leaf)
+            eng.expand(is_root=(s == 0), values=torch.from_numpy(val).to(DEV), priors220=torch.from_numpy(pri).to(DEV))
+        eng.finish(torch.full((B,), 0.1, device=DEV), None)
+
+    for factor, expect_drop in ((4.0, False), (0.02, True)):
+        eng = TreeEngine(B, sims, DEV, 1.0, reuse_factor=factor)
+        eng.set_roots(to_gpu_batch(sub, DEV)); eng.begin(); search(eng)
+        chosen = eng.chosen_index.cpu().numpy()
+        term = eng.terminal_mask.cpu().numpy()
+        nxt = [O.state_from_batch(sub, i) if term[i] else O.apply_index(O.state_from_batch(sub, i), int(chosen[i]))
+               for i in range(B)]
+        nb = O.batch_from_states(nxt)
+        reset = torch.zeros(B, dtype=torch.uint8, device=DEV); reset[::4] = 1
+        played = eng.chosen_index.clone(); played[1::4] = -1
+        wrong = {f: np.array(nb[f]) for f in FIELDS}
+        for i in range(2, B, 4):                       # a state that is not the played child's
+            for f in FIELDS:
+                wrong[f][i] = np.asarray(sub[f])[i]
+        eng.set_roots(to_gpu_batch(wrong, DEV))
+        eng.advance(played, reset)
+        kind = eng.buf["leaf_kind"].cpu().numpy()
+        fresh_expected = np.zeros(B, bool); fresh_expected[::4] = True; fresh_expected[1::4] = True; fresh_expected[2::4] = True
+        assert not np.any(kind[fresh_expected] == 3)
+        rest = ~fresh_expected & ~term
+        dropped = int(eng.reuse_dropped.item())
+        if expect_drop:
+            assert dropped > 0 and not np.any(kind == 3)
+        else:
+            assert dropped == 0 and np.any(kind[rest] == 3)
+        # whatever was kept or dropped, the next search is a valid one
+        search(eng)
+        vis = eng.child_visits.cpu().numpy(); cnt = eng.child_count.cpu().numpy()
+        for g in np.nonzero(kind == 1)[0]:
+            assert int(vis[g, :cnt[g]].sum()) == sims
+
+
+def test_tree_finish_policy_target_options_and_uniform_openings():
+    """policy_target_temperature / prior pseudocount (portable_mcts.py:150-205, :690-700) and the uniform pick of
+    the opening plies (:709-712)."""
+    _need_gpu()
+    from oracle import lz_oracle as O
+    eng = run_injected_parity(DEV, num_games=96, sims=40, seed=11, temperature=0.1)
+    B = eng.B
+    cnt = eng.child_count.cpu().numpy(); act = eng.child_action.cpu().numpy()
+    vis = eng.child_visits.cpu().numpy(); pri = eng.child_prior.cpu().numpy()
+    temps = torch.full((B,), 0.1, device=DEV)
+    tt = torch.full((B,), 1.0, device=DEV)
+    u = torch.rand(B, device=DEV)
+    force = (torch.arange(B, device=DEV) % 2 == 0)
+    before = eng.chosen_index.clone()
+    eng.finish(temps, u, tt, 0.5, force, sample_moves=False)
+    pol = eng.policy_dense.cpu().numpy(); chosen = eng.chosen_index.cpu().numpy(); uu = u.cpu().numpy()
+    for g in range(B):
+        k = int(cnt[g])
+        if k == 0:
+            continue
+        want = np.zeros(220, np.float32)
+        want[act[g, :k]] = O.policy_from_visits(vis[g, :k], 1.0, pri[g, :k], 0.5)
+        np.testing.assert_allclose(pol[g], want, atol=2e-6, rtol=0)
+        if g % 2 == 0:
+            assert chosen[g] == act[g, min(k - 1, int(np.float32(uu[g]) * np.float32(k)))]
+        else:
+            assert chosen[g] == int(before[g])          # deterministic pick untouched by the target options
+
+
+def test_fused_search_with_subtree_reuse_accumulates_visits():
+    """PortableTreeMCTS(reuse_tree=True): second search of the same games continues from the kept subtree -- the
+    root's children carry the visits they had as grandchildren plus the new simulations."""
+    _need_gpu()
+    from liuzhou_amd.net import ChessNet, MODEL_CONFIGS
+    from liuzhou_amd.net_hip import FusedNet
+    from liuzhou_amd.tree_engine import PortableTreeMCTS
+    from liuzhou_amd import v0_core
+    torch.manual_seed(20260314)
+    net = FusedNet(ChessNet(**MODEL_CONFIGS["b6c64"]).eval().to(DEV))
+    z = load("g1_rules.npz")
+    st = states(z, "s")
+    B, sims = 256, 60
+    idx = np.random.default_rng(2).integers(0, st["board"].shape[0], B)
+    batch = to_gpu_batch({f: np.ascontiguousarray(np.asarray(st[f])[idx]) for f in FIELDS}, DEV)
+    for use_graph in (False, True):
+        mcts = PortableTreeMCTS(net, B, sims, DEV, reuse_tree=True, sample_moves=False, use_graph=use_graph)
+        cur = batch.select(torch.arange(B, device=DEV))
+        plies = torch.zeros(B, dtype=torch.int64, device=DEV); done = torch.zeros(B, dtype=torch.bool, device=DEV)
+        all_idx = torch.arange(B, device=DEV)
+        prev_child_visits = None
+        for mv in range(4):
+            out = mcts.search_batch(cur, temperatures=torch.full((B,), 0.1, device=DEV), active=~done)
+            e = mcts.engine
+            vis = e.child_visits.cpu().numpy(); cnt = e.child_count.cpu().numpy(); act = e.child_action.cpu().numpy()
+            kind_total = np.array([int(vis[g, :cnt[g]].sum()) for g in range(B)])
+            live = (~done).cpu().numpy() & ~out.terminal_mask.cpu().numpy()
+            if mv == 0:
+                assert np.all(kind_total[live] == sims)
+            else:
+                # kept root: visits carried over = (visits of the played child - 1), then + sims
+                carried = np.maximum(prev_child_visits - 1, 0)
+                assert np.all(kind_total[live] == carried[live] + sims), (mv, use_graph)
+            chosen = e.chosen_index.cpu().numpy()
+            prev_child_visits = np.array([vis[g, list(act[g, :cnt[g]]).index(chosen[g])] if live[g] else 0
+                                          for g in range(B)])
+            v0_core.self_play_step_inplace(*cur.tensors(), plies, done, all_idx, out.chosen_action_codes,
+                                           out.terminal_mask, out.chosen_valid_mask, 512, 2.0)
+        assert int(mcts.engine.reuse_dropped.item()) == 0
+        assert prev_child_visits.max() > 1

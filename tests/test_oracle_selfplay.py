@@ -22,3 +22,32 @@ def test_oracle_root_selfplay_matches_reference_trace():
     np.testing.assert_array_equal(tensors["value_targets"], z["value_targets"])
     np.testing.assert_allclose(tensors["soft_value_targets"], z["soft_value_targets"], atol=1e-6, rtol=0)
     assert (stats["black_wins"], stats["white_wins"], stats["draws"]) == (int(z["black_wins"]), int(z["white_wins"]), int(z["draws"]))
+
+
+def _tree_trace(z, tag, **kw):
+    torch.manual_seed(7)
+    model = ChessNet(**MODEL_CONFIGS["tiny"]).eval()
+    games, sims, max_plies = (int(x) for x in z[f"{tag}_config"])
+    out = SO.self_play_tree(model, num_games=games, sims=sims, temperature_init=1.0, temperature_final=0.1,
+                            temperature_threshold=10, c=1.0, soft_k=2.0, max_game_plies=max_plies,
+                            concurrent_games=games, reuse_tree=True, collect=True, **kw)
+    t = out["tensors"]
+    n = z[f"{tag}_policy_targets"].shape[0]
+    assert out["num_positions"] == n
+    want_states = np.unpackbits(z[f"{tag}_state_tensors"], axis=1)[:, :11 * 36].reshape(n, 11, 6, 6).astype(np.float32)
+    assert np.array_equal(t["state_tensors"], want_states)
+    assert np.array_equal(t["legal_masks"], np.unpackbits(z[f"{tag}_legal_masks"], axis=1)[:, :220].astype(bool))
+    np.testing.assert_allclose(t["policy_targets"], z[f"{tag}_policy_targets"], atol=1e-6, rtol=0)
+    np.testing.assert_array_equal(t["value_targets"], z[f"{tag}_value_targets"])
+    np.testing.assert_allclose(t["soft_value_targets"], z[f"{tag}_soft_value_targets"], atol=1e-6, rtol=0)
+    assert [out["black_wins"], out["white_wins"], out["draws"]] == [int(x) for x in z[f"{tag}_outcome"]]
+
+
+def test_oracle_tree_selfplay_with_subtree_reuse_matches_reference_trace():
+    """g10/a: the reference portable runner keeps the played child's subtree on every move (advance_root)."""
+    _tree_trace(load("g10_tree_selfplay.npz"), "a")
+
+
+def test_oracle_tree_selfplay_policy_target_options_match_reference_trace():
+    """g10/b: policy_target_temperature / policy_target_prior_pseudocount (portable_mcts.py:690-700)."""
+    _tree_trace(load("g10_tree_selfplay.npz"), "b", policy_target_temperature=1.0, policy_target_prior_pseudocount=0.5)

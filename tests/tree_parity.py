@@ -145,3 +145,83 @@ def run_injected_parity(device, num_games=64, sims=64, seed=0, states=None, c=1.
         cand = cand[np.abs(pr[cand] - pr[cand].max()) <= 1e-8]
         assert int(chosen[i]) == int(idx[cand.min()]), i
     return eng
+
+
+def run_injected_reuse_parity(device, num_games=48, sims=48, moves=4, seed=3, c=1.0, with_noise=True, eps=0.25,
+                              reuse_factor=4.0):
+    """Tree reuse (a21): `moves` consecutive searches per game; after each one the deterministic pick is played on
+    both sides, the oracle promotes the child with `advance` (portable_mcts.py:74-87) and the GPU engine with
+    lz_tree_advance.  Bit-exact visit counts / priors after every move, including the re-noised kept roots."""
+    from liuzhou_amd.tree_engine import TreeEngine, OUT_CAP
+    from tests.golden_utils import load, states as gstates
+    z = load("g1_rules.npz")
+    st_all = gstates(z, "s")
+    rng = np.random.default_rng(seed)
+    idx0 = rng.integers(0, st_all["board"].shape[0], num_games)
+    states = {f: np.ascontiguousarray(np.asarray(st_all[f])[idx0]) for f in FIELDS}
+    B = num_games
+    eng = TreeEngine(B, sims, device, c, reuse_factor=reuse_factor)
+    cur = [O.state_from_batch(states, i) for i in range(B)]
+    trees = [O.OracleTree(cur[i], c) for i in range(B)]
+    kept_total = 0
+    for mv in range(moves):
+        batch = O.batch_from_states(cur)
+        eng.set_roots(to_gpu_batch(batch, device))
+        if mv == 0:
+            eng.begin()
+        else:
+            eng.advance()                       # played action = the last finish()'s pick
+        noise = rng.gamma(0.3, 1.0, size=(B, OUT_CAP)).astype(np.float32) + np.float32(1e-6) if with_noise else None
+        nz_dev = None if noise is None else torch.from_numpy(noise).to(device)
+
+        kind = eng.buf["leaf_kind"].cpu().numpy()
+        leaf = unpack_packed(eng.buf["leaf_state"].cpu().numpy())
+        pend = [t.prepare_root() for t in trees]
+        assert np.array_equal(kind == 1, np.array(pend)), f"move {mv}: fresh / kept roots differ"
+        if mv > 0:
+            kept = [(not p) and t.root_children()[0].size > 0 for p, t in zip(pend, trees)]
+            assert np.array_equal(kind == 3, np.array(kept)), f"move {mv}: kept roots differ"
+            kept_total += int(np.sum(kept))
+        pri, val = hash_evaluator(leaf)
+        for i, t in enumerate(trees):
+            if pend[i]:
+                t.complete(pri[i], float(val[i]), None if noise is None else noise[i], eps)
+            elif noise is not None and t.root_children()[0].size > 0:
+                t.root_noise(noise[i], eps)
+        eng.expand(is_root=True, values=torch.from_numpy(val).to(device), priors220=torch.from_numpy(pri).to(device),
+                   noise=nz_dev, epsilon=eps)
+        for _ in range(sims):
+            eng.select()
+            kind = eng.buf["leaf_kind"].cpu().numpy()
+            leaf = unpack_packed(eng.buf["leaf_state"].cpu().numpy())
+            pend = [t.select() for t in trees]
+            assert np.array_equal(kind == 1, np.array(pend)), f"move {mv}: pending evaluations differ"
+            pri, val = hash_evaluator(leaf)
+            for i, t in enumerate(trees):
+                if pend[i]:
+                    t.complete(pri[i], float(val[i]))
+            eng.expand(is_root=False, values=torch.from_numpy(val).to(device), priors220=torch.from_numpy(pri).to(device))
+        temps = torch.full((B,), 0.1, dtype=torch.float32, device=device)
+        eng.finish(temps, None)
+        got_v, got_p = engine_visits(eng)
+        chosen = eng.chosen_index.cpu().numpy()
+        rv = eng.root_value.cpu().numpy()
+        term = eng.terminal_mask.cpu().numpy()
+        for i, t in enumerate(trees):
+            if t.root_terminal():
+                assert term[i] and chosen[i] == -1, (mv, i)
+                continue
+            idx, vis, vs, pr, pl = t.root_children()
+            want = np.zeros(220, np.int32); want[idx] = vis
+            assert np.array_equal(got_v[i], want), (mv, i, np.abs(got_v[i] - want).sum())
+            wp = np.zeros(220, np.float32); wp[idx] = pr
+            assert np.array_equal(got_p[i], wp), (mv, i)
+            assert abs(float(rv[i]) - t.root_value_sum() / max(1, t.root_visits())) < 1e-6
+            from oracle.selfplay_oracle import deterministic_pick
+            pick = deterministic_pick(idx, vis, vs, pr, pl, t.root_player())
+            assert int(chosen[i]) == pick, (mv, i)
+            cur[i] = O.apply_index(cur[i], pick)
+            if not t.advance(pick):
+                trees[i] = O.OracleTree(cur[i], c)
+    assert int(eng.reuse_dropped.item()) == 0
+    return eng, kept_total
