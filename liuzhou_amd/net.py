@@ -157,3 +157,37 @@ def build_model(name: str = "b10c128", seed: Optional[int] = None) -> ChessNet:
     if seed is not None:
         torch.manual_seed(int(seed))
     return ChessNet(**MODEL_CONFIGS[name]).eval()
+
+
+def stable_resnet_init(model: nn.Module, seed: int) -> None:
+    """Bootstrap initialisation of a model without a checkpoint (v1/train.py:162-217, seed = MODEL_INIT_SEED):
+    He-normal (fan_out) conv / linear weights, zero biases, unit BatchNorm except a zero gamma on every block's
+    second norm (blocks start as the identity), and std-1e-3 output layers (three policy 1x1 convs, value fc2).
+    Draw order follows `model.modules()`, the caller's RNG streams are left untouched."""
+    if int(seed) <= 0:
+        raise ValueError(f"seed must be positive for model init, got {seed}")
+    import random
+    cuda = torch.cuda.is_available()
+    saved = (random.getstate(), torch.random.get_rng_state(), torch.cuda.get_rng_state_all() if cuda else None)
+    try:
+        random.seed(int(seed)); torch.manual_seed(int(seed))
+        if cuda:
+            torch.cuda.manual_seed_all(int(seed))
+        for m in model.modules():
+            if isinstance(m, (nn.Conv2d, nn.Linear)):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+                if m.bias is not None:
+                    nn.init.zeros_(m.bias)
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.ones_(m.weight); nn.init.zeros_(m.bias)
+        for block in getattr(model, "blocks", []):
+            nn.init.zeros_(block.bn2.weight)
+        small = [getattr(model.policy_head, n) for n in ("out_pos1", "out_pos2", "out_mark")] + [model.value_head.fc2]
+        for layer in small:
+            nn.init.normal_(layer.weight, mean=0.0, std=1e-3)
+            if layer.bias is not None:
+                nn.init.zeros_(layer.bias)
+    finally:
+        random.setstate(saved[0]); torch.random.set_rng_state(saved[1])
+        if saved[2] is not None:
+            torch.cuda.set_rng_state_all(saved[2])

@@ -122,6 +122,65 @@ def _infer_model(state: Dict[str, torch.Tensor]) -> ChessNet:
                     value_bucket_bins=int(state["value_head.fc2.weight"].shape[0]))
 
 
+def write_worker_chunks(run_once, *, worker_idx: int, device: str, games: int, games_per_chunk: int,
+                        soft_label_alpha: float, chunk_dir: str, chunk_prefix: str, chunk_file_ext: str,
+                        output_path: str, target_samples_per_shard: int, chunk_target_bytes: int,
+                        meta_common: Dict[str, Any]) -> Dict[str, Any]:
+    """Chunk loop of the worker (self_play_worker.py:430-546): `run_once(n) -> (TensorSelfPlayBatch, stats)` is called
+    until `games` are played; every result is cut into `<prefix>.chunkNNNNN<ext>` payloads
+    (`payload_format: v1_sharded_shard`) and the worker manifest (`v1_worker_chunk_manifest`) goes to `output_path`."""
+    alpha = float(max(0.0, min(1.0, soft_label_alpha)))
+    stats_chunks: List[SelfPlayV1Stats] = []
+    val_s, soft_s, mix_s = [], [], []
+    files: List[str] = []
+    sizes: List[int] = []
+    bps_num = bps_den = 0
+    remaining = int(games)
+    started = time.perf_counter()
+    while remaining > 0:
+        n = min(int(games_per_chunk), remaining)
+        batch, st = run_once(n)
+        cpu = batch.to("cpu")
+        stats_chunks.append(st)
+        val_s.append(summarize_scalar_targets(cpu.value_targets))
+        soft_s.append(summarize_scalar_targets(cpu.soft_value_targets))
+        mix_s.append(summarize_scalar_targets(torch.clamp((1.0 - alpha) * cpu.value_targets + alpha * cpu.soft_value_targets, -1.0, 1.0)))
+        bps = estimate_bytes_per_sample(cpu)
+        bps_num += bps * max(1, cpu.num_samples)
+        bps_den += max(1, cpu.num_samples)
+        for a, b in plan_sample_ranges(total_samples=cpu.num_samples, num_shards=1,
+                                       target_samples_per_shard=int(target_samples_per_shard),
+                                       chunk_target_bytes=int(chunk_target_bytes), bytes_per_sample=bps):
+            name = f"{chunk_prefix}.chunk{len(files):05d}{chunk_file_ext}"
+            meta = {"payload_format": "v1_sharded_shard", "worker_idx": int(worker_idx), "device": str(device),
+                    "games": int(games), "games_per_chunk": int(games_per_chunk),
+                    "num_selfplay_batches": len(stats_chunks), "saved_chunk_index": len(files)}
+            meta.update(meta_common)
+            meta["source_worker_manifest"] = os.path.basename(str(output_path))
+            save_self_play_payload(path=os.path.join(chunk_dir, name), samples=slice_batch_cpu(cpu, start=a, end=b),
+                                   stats_payload={}, metadata=meta)
+            files.append(name)
+            sizes.append(int(b - a))
+        remaining -= n
+    stats = merge_self_play_stats(stats_chunks, max(1e-9, time.perf_counter() - started))
+    wmeta = {"worker_idx": int(worker_idx), "device": str(device), "games": int(games),
+             "games_per_chunk": int(games_per_chunk), "num_selfplay_batches": len(stats_chunks),
+             "saved_chunks": len(files)}
+    wmeta.update(meta_common)
+    manifest = {
+        "payload_format": "v1_worker_chunk_manifest", "version": 1, "num_samples": int(sum(sizes)),
+        "num_shards": len(files), "shard_files": list(files), "shard_sizes": list(sizes),
+        "chunk_target_bytes": int(chunk_target_bytes), "avg_bytes_per_sample": int(bps_num // max(1, bps_den)),
+        "stats": stats.to_dict(), "value_target_summary": merge_target_summaries(val_s),
+        "soft_value_target_summary": merge_target_summaries(soft_s),
+        "mixed_value_target_summary": merge_target_summaries(mix_s), "metadata": wmeta,
+    }
+    os.makedirs(os.path.dirname(str(output_path)) or ".", exist_ok=True)
+    torch.save(manifest, str(output_path))
+    return {"worker_idx": int(worker_idx), "device": str(device), "games": int(games), "output_path": str(output_path),
+            "num_samples": int(sum(sizes)), "saved_chunks": len(files)}
+
+
 def run_self_play_worker(*, worker_idx: int, shard_device: str, shard_games: int, seed: int, model_state_path: str,
                          output_path: str, mcts_simulations: int, temperature_init: float, temperature_final: float,
                          temperature_threshold: int, exploration_weight: float, dirichlet_alpha: float,
@@ -182,63 +241,17 @@ def run_self_play_worker(*, worker_idx: int, shard_device: str, shard_games: int
             return self_play_v1_gpu(evaluator, opening_random_moves=int(opening_random_moves), sparse_ply=int(sparse_ply),
                                     sparse_top_k=int(sparse_top_k), **common)
 
-        alpha = float(max(0.0, min(1.0, soft_label_alpha)))
-        stats_chunks: List[SelfPlayV1Stats] = []
-        val_s, soft_s, mix_s = [], [], []
-        files: List[str] = []
-        sizes: List[int] = []
-        bps_num = bps_den = 0
-        remaining = games
-        started = time.perf_counter()
-        while remaining > 0:
-            n = min(concurrent, remaining)
-            batch, st = run_once(n)
-            cpu = batch.to("cpu")
-            stats_chunks.append(st)
-            val_s.append(summarize_scalar_targets(cpu.value_targets))
-            soft_s.append(summarize_scalar_targets(cpu.soft_value_targets))
-            mix_s.append(summarize_scalar_targets(torch.clamp((1.0 - alpha) * cpu.value_targets + alpha * cpu.soft_value_targets, -1.0, 1.0)))
-            bps = estimate_bytes_per_sample(cpu)
-            bps_num += bps * max(1, cpu.num_samples)
-            bps_den += max(1, cpu.num_samples)
-            for a, b in plan_sample_ranges(total_samples=cpu.num_samples, num_shards=1,
-                                           target_samples_per_shard=int(target_samples_per_shard),
-                                           chunk_target_bytes=int(chunk_target_bytes), bytes_per_sample=bps):
-                name = f"{prefix}.chunk{len(files):05d}{chunk_file_ext}"
-                meta = {"payload_format": "v1_sharded_shard", "worker_idx": int(worker_idx), "device": str(dev),
-                        "games": games, "games_per_chunk": concurrent, "num_selfplay_batches": len(stats_chunks),
-                        "saved_chunk_index": len(files), "graph_retry_off": False, "memory_anchor_mb": int(anchor_mb),
-                        "opening_random_moves": int(opening_random_moves), "search_backend": str(search_backend),
-                        "portable_mcts_backend": str(portable_mcts_backend),
-                        "portable_cpp_threads": int(portable_cpp_threads),
-                        "policy_target_temperature": policy_target_temperature,
-                        "policy_target_prior_pseudocount": float(policy_target_prior_pseudocount),
-                        "source_worker_manifest": os.path.basename(str(output_path))}
-                save_self_play_payload(path=os.path.join(chunk_dir, name), samples=slice_batch_cpu(cpu, start=a, end=b),
-                                       stats_payload={}, metadata=meta)
-                files.append(name)
-                sizes.append(int(b - a))
-            remaining -= n
-        stats = merge_self_play_stats(stats_chunks, max(1e-9, time.perf_counter() - started))
-        manifest = {
-            "payload_format": "v1_worker_chunk_manifest", "version": 1, "num_samples": int(sum(sizes)),
-            "num_shards": len(files), "shard_files": list(files), "shard_sizes": list(sizes),
-            "chunk_target_bytes": int(chunk_target_bytes), "avg_bytes_per_sample": int(bps_num // max(1, bps_den)),
-            "stats": stats.to_dict(), "value_target_summary": merge_target_summaries(val_s),
-            "soft_value_target_summary": merge_target_summaries(soft_s),
-            "mixed_value_target_summary": merge_target_summaries(mix_s),
-            "metadata": {"worker_idx": int(worker_idx), "device": str(dev), "games": games, "games_per_chunk": concurrent,
-                         "num_selfplay_batches": len(stats_chunks), "saved_chunks": len(files), "graph_retry_off": False,
-                         "memory_anchor_mb": int(anchor_mb), "opening_random_moves": int(opening_random_moves),
-                         "search_backend": str(search_backend), "portable_mcts_backend": str(portable_mcts_backend),
-                         "portable_cpp_threads": int(portable_cpp_threads),
-                         "policy_target_temperature": policy_target_temperature,
-                         "policy_target_prior_pseudocount": float(policy_target_prior_pseudocount)},
-        }
-        os.makedirs(os.path.dirname(str(output_path)) or ".", exist_ok=True)
-        torch.save(manifest, str(output_path))
-        return {"worker_idx": int(worker_idx), "device": str(dev), "games": games, "output_path": str(output_path),
-                "num_samples": int(sum(sizes)), "saved_chunks": len(files)}
+        meta_common = {"graph_retry_off": False, "memory_anchor_mb": int(anchor_mb),
+                       "opening_random_moves": int(opening_random_moves), "search_backend": str(search_backend),
+                       "portable_mcts_backend": str(portable_mcts_backend),
+                       "portable_cpp_threads": int(portable_cpp_threads),
+                       "policy_target_temperature": policy_target_temperature,
+                       "policy_target_prior_pseudocount": float(policy_target_prior_pseudocount)}
+        return write_worker_chunks(run_once, worker_idx=int(worker_idx), device=str(dev), games=games,
+                                   games_per_chunk=concurrent, soft_label_alpha=float(soft_label_alpha),
+                                   chunk_dir=chunk_dir, chunk_prefix=prefix, chunk_file_ext=str(chunk_file_ext),
+                                   output_path=str(output_path), target_samples_per_shard=int(target_samples_per_shard),
+                                   chunk_target_bytes=int(chunk_target_bytes), meta_common=meta_common)
     except Exception as exc:
         raise RuntimeError(f"v1 self-play process worker failed: worker={int(worker_idx)}, device={shard_device}, "
                            f"games={int(shard_games)}\n{traceback.format_exc()}") from exc

@@ -48,3 +48,38 @@ def test_worker_emits_chunk_manifest(tmp_path, backend, chunk_target_bytes):
         assert torch.allclose(pol.sum(1), torch.ones(n), atol=1e-4)
     assert total == payload["num_samples"]
     assert payload["stats"]["num_games"] == 3.0
+
+
+@pytest.mark.parametrize("backend", ["cuda_root", "portable"])
+def test_selfplay_stage_cli_two_worker_processes(tmp_path, backend):
+    """scripts/selfplay_stage.py end to end: two spawned worker processes (both on cuda:0 here), chunk files, the
+    sharded manifest and the stats json; the loader reads every sample back."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import json
+    import os
+    import subprocess
+    import sys
+    from liuzhou_amd.self_play_stage import load_self_play_payload, resolve_shard_specs
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = tmp_path / "selfplay_iter_001.pt"
+    stats_json = tmp_path / "stats.json"
+    cmd = [sys.executable, os.path.join(root, "scripts", "selfplay_stage.py"), "--pipeline", "v1", "--stage", "selfplay",
+           "--devices", "cuda:0,cuda:0", "--self_play_games", "10", "--mcts_simulations", "6", "--model", "b6c64",
+           "--self_play_concurrent_games", "4", "--max_game_plies", "24", "--search_backend", backend,
+           "--self_play_output", str(out), "--self_play_stats_json", str(stats_json),
+           "--self_play_iteration_seed", "2", "--train_devices", "cuda:0"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout + res.stderr
+    manifest = torch.load(out, map_location="cpu", weights_only=False)
+    assert manifest["payload_format"] == "v1_sharded_manifest" and manifest["num_shards"] >= 2
+    assert {f.split(".")[1] for f in manifest["shard_files"]} == {"w00", "w01"}
+    batch, stats, meta = load_self_play_payload(str(out))
+    assert batch.num_samples == manifest["num_samples"] == 10 * 24          # every game hits the ply cap
+    assert int(stats["num_games"]) == 10 and meta["search_backend"] == backend
+    assert torch.allclose(batch.policy_targets.sum(1), torch.ones(batch.num_samples), atol=1e-4)
+    assert bool((batch.policy_targets[~batch.legal_masks] == 0).all())
+    specs, total = resolve_shard_specs(str(out), [], 0)
+    assert total == batch.num_samples
+    js = json.load(open(stats_json))
+    assert js["num_samples"] == batch.num_samples

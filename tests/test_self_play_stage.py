@@ -1,0 +1,162 @@
+"""CPU: the self-play stage (split over devices -> worker chunk files -> sharded manifest) and the loader side,
+including round trips through the reference's own reader / writer when /root/reference is present."""
+import os
+import sys
+
+import pytest
+import torch
+
+from liuzhou_amd import self_play_stage as S
+from liuzhou_amd.distributed import split_games, worker_seed
+from tests.stage_stub import random_batch, stub_worker
+
+REF = "/root/reference"
+
+
+def _run(tmp_path, in_process, games=23, devices=("cuda:0", "cuda:1", "cuda:2")):
+    out = str(tmp_path / "selfplay_iter_001.pt")
+    stats, manifest = S.run_self_play_stage(
+        model_state={"w": torch.zeros(3)}, num_games=games, devices=list(devices), output_path=out, iteration_seed=1,
+        mcts_simulations=8, concurrent_games_per_device=5, target_samples_per_shard=20, worker_fn=stub_worker,
+        in_process=in_process, metadata_base={"iteration": 1})
+    return out, stats, manifest
+
+
+@pytest.mark.parametrize("in_process", [True, False])
+def test_stage_writes_chunks_and_manifest(tmp_path, in_process):
+    out, stats, manifest = _run(tmp_path, in_process)
+    assert manifest["payload_format"] == "v1_sharded_manifest" and manifest["version"] == 1
+    assert manifest["num_samples"] == 23 * 7 == sum(manifest["shard_sizes"]) == stats.num_positions
+    assert stats.num_games == 23 and stats.black_wins + stats.white_wins + stats.draws == 23
+    assert manifest["num_shards"] == len(manifest["shard_files"])
+    # worker order, chunk numbering per worker, files next to the manifest
+    assert manifest["shard_files"][0] == "selfplay_iter_001.w00.chunk00000.pt"
+    assert all(os.path.exists(tmp_path / f) for f in manifest["shard_files"])
+    assert [f.split(".")[1] for f in manifest["shard_files"]] == sorted(f.split(".")[1] for f in manifest["shard_files"])
+    assert manifest["metadata"]["iteration"] == 1
+    assert manifest["metadata"]["value_target_summary"]["total"] == 23 * 7
+    shard = torch.load(tmp_path / manifest["shard_files"][0], weights_only=False)
+    assert set(shard) == {"state_tensors", "legal_masks", "policy_targets", "value_targets", "soft_value_targets",
+                          "stats", "metadata"}
+    assert shard["metadata"]["payload_format"] == "v1_sharded_shard"
+    # games split / seeds as v1/train.py:129-135, :998
+    assert split_games(23, 3) == [8, 8, 7] and worker_seed(1, 2) == 1 * 10007 + 3 * 9973
+    batch, st, meta = S.load_self_play_payload(out)
+    assert batch.num_samples == 23 * 7 and meta["loaded_shard_count"] == manifest["num_shards"]
+    # deterministic content: worker 0's first chunk is the head of its first seeded batch
+    want = random_batch(5 * 7, worker_seed(1, 0) * 131 + 1)
+    n0 = manifest["shard_sizes"][0]
+    assert torch.equal(batch.policy_targets[:n0], want.policy_targets[:n0])
+    # DDP dealing: shards round-robin over ranks, every sample exactly once
+    parts = [S.load_self_play_payload(out, ddp_rank=r, ddp_world_size=2)[0].num_samples for r in range(2)]
+    assert sum(parts) == 23 * 7
+
+
+def test_shard_specs_and_replay_budget(tmp_path):
+    out, _, manifest = _run(tmp_path, True)
+    single = str(tmp_path / "old.pt")
+    b = random_batch(50, 3)
+    torch.save({k: getattr(b, k) for k in S.TENSOR_KEYS}, single)
+    specs, total = S.resolve_shard_specs(out, [single, str(tmp_path / "missing.pt")], 30)
+    assert len(specs) == manifest["num_shards"] + 1 and total == 23 * 7 + 30
+    specs_r, total_r = S.resolve_shard_specs(single, [out], 40)
+    assert total_r == 50 + 40 and sum(s.sample_budget for s in specs_r[1:]) == 40
+    assert all(s.sample_budget <= s.num_samples for s in specs_r[1:])
+    got = sum(x.num_samples for x in S.iter_shard_batches(specs_r, seed=1))
+    assert got == 90
+    assert S._spread_budget([10, 0, 30], 20) == [5, 0, 15] and S._spread_budget([3, 3], 100) == [3, 3]
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "v1")), reason="reference tree not present (GPU box)")
+def test_round_trip_through_the_reference_reader_and_writer(tmp_path):
+    """f1: the reference's loader / streaming index read our manifest, and we read the reference's sharded save."""
+    sys.path.insert(0, REF)
+    sys.dont_write_bytecode = True
+    try:
+        import v1.train as T
+        from v1.python.streaming_dataset import resolve_shard_specs as ref_specs
+        from v1.python.trajectory_buffer import TensorSelfPlayBatch as RefBatch
+        from v1.python.self_play_types import SelfPlayV1Stats as RefStats
+    except Exception as exc:   # pragma: no cover
+        pytest.skip(f"reference not importable here: {exc!r}")
+    finally:
+        sys.path.remove(REF)
+    out, stats, manifest = _run(tmp_path, True)
+    ours, _, _ = S.load_self_play_payload(out)
+    theirs, st, meta = T._load_self_play_payload(out)
+    for k in S.TENSOR_KEYS:
+        assert torch.equal(getattr(theirs, k), getattr(ours, k)), k
+    assert int(st["num_positions"]) == stats.num_positions and meta["manifest_num_shards"] == manifest["num_shards"]
+    rs, rtotal = ref_specs(out, [], 0)
+    ms, mtotal = S.resolve_shard_specs(out, [], 0)
+    assert rtotal == mtotal and [(s.path, s.num_samples, s.sample_budget) for s in rs] == \
+        [(s.path, s.num_samples, s.sample_budget) for s in ms]
+    rs, rtotal = ref_specs(out, [out], 37)
+    ms, mtotal = S.resolve_shard_specs(out, [out], 37)
+    assert rtotal == mtotal and [s.sample_budget for s in rs] == [s.sample_budget for s in ms]
+    # the other direction: written by the reference, read by us
+    b = random_batch(64, 9)
+    ref_batch = RefBatch(**{k: getattr(b, k) for k in S.TENSOR_KEYS})
+    ref_out = str(tmp_path / "ref_payload.pt")
+    T._save_self_play_payload_sharded(path=ref_out, samples=ref_batch, stats=T._self_play_stats_from_payload({}),
+                                      metadata={"who": "reference"}, num_shards=3)
+    back, _, meta2 = S.load_self_play_payload(ref_out)
+    for k in S.TENSOR_KEYS:
+        assert torch.equal(getattr(back, k), getattr(b, k)), k
+    assert meta2["who"] == "reference" and meta2["manifest_num_shards"] == 3
+    # and our sharded writer is readable by the reference
+    our_out = str(tmp_path / "our_payload.pt")
+    S.save_sharded(path=our_out, samples=b, stats_payload={}, metadata={}, num_shards=4)
+    theirs2, _, _ = T._load_self_play_payload(our_out)
+    assert torch.equal(theirs2.policy_targets, b.policy_targets)
+
+
+def test_stable_resnet_init_properties_and_reference_equality():
+    """Bootstrap init of a model without checkpoint (v1/train.py:162-217)."""
+    from liuzhou_amd.net import ChessNet, MODEL_CONFIGS, stable_resnet_init
+    torch.manual_seed(5)
+    before = torch.random.get_rng_state()
+    m = ChessNet(**MODEL_CONFIGS["b6c64"])
+    mid = torch.random.get_rng_state()
+    stable_resnet_init(m, 20260314)
+    assert torch.equal(torch.random.get_rng_state(), mid) and not torch.equal(before, mid)   # caller's stream untouched
+    assert all(float(b.bn2.weight.detach().abs().max()) == 0.0 for b in m.blocks)
+    assert float(m.policy_head.out_pos1.weight.detach().std()) < 3e-3 and float(m.value_head.fc2.weight.detach().std()) < 3e-3
+    m2 = ChessNet(**MODEL_CONFIGS["b6c64"]); stable_resnet_init(m2, 20260314)
+    assert all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), m2.state_dict().values()))
+    # zero-gamma second norms: every block is the identity at init
+    m.eval()
+    x = torch.rand(3, 11, 6, 6)
+    with torch.no_grad():
+        stem = torch.relu(m.stem_bn(m.stem_conv(x)))
+        assert torch.equal(m.blocks[0](stem), stem)
+    if not os.path.isdir(os.path.join(REF, "v1")):
+        return
+    sys.path.insert(0, REF)
+    try:
+        import v1.train as T
+        from src.neural_network import ChessNet as RefNet
+    finally:
+        sys.path.remove(REF)
+    r = RefNet(board_size=6, num_input_channels=11, trunk_channels=64, num_blocks=6)
+    T._init_model_stable_resnet(r, seed=20260314)
+    a, b = m.state_dict(), r.state_dict()
+    assert list(a) == list(b) and all(torch.equal(a[k], b[k]) for k in a)
+
+
+def test_stage_cli_parses_the_reference_command_line():
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+    import selfplay_stage as cli
+    args = cli.parse(["--pipeline", "v1", "--stage", "selfplay", "--device", "cuda:0", "--devices", "cuda:0,cuda:1",
+                      "--train_devices", "cuda:0", "--infer_devices", "cuda:0", "--self_play_games", "4096",
+                      "--mcts_simulations", "200", "--temperature_init", "1.0", "--temperature_final", "0.1",
+                      "--temperature_threshold", "10", "--exploration_weight", "1.0", "--dirichlet_alpha", "0.3",
+                      "--dirichlet_epsilon", "0.25", "--soft_value_k", "2.0", "--soft_label_alpha", "0.5",
+                      "--max_game_plies", "512", "--self_play_concurrent_games", "2048",
+                      "--self_play_opening_random_moves", "4", "--sparse_ply", "1", "--sparse_top_k", "8",
+                      "--self_play_backend", "process", "--self_play_target_samples_per_shard", "0",
+                      "--self_play_chunk_target_bytes", "268435456", "--model_init_seed", "20260314",
+                      "--checkpoint_dir", "ck", "--self_play_output", "out/sp.pt", "--self_play_iteration_seed", "3",
+                      "--self_play_stats_json", "out/sp.json", "--self_play_shard_dir", "/dev/shm/x"])
+    assert args.devices == "cuda:0,cuda:1" and args.self_play_games == 4096 and args.self_play_iteration_seed == 3
+    assert args.ignored == ["--train_devices", "cuda:0", "--infer_devices", "cuda:0"]
