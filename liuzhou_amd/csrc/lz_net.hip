@@ -203,21 +203,27 @@ __device__ __forceinline__ void load_chan_params(__amdgpu_buffer_rsrc_t rf, int 
     for (int j = 0; j < 2; ++j) v[j] = load_f4(rf, sub, float_off + chan_base + j * 16);
 }
 
-template <int C, int S, bool HAS_SCALE>
-__device__ __forceinline__ void store_act(const Acc& acc, unsigned char* lds, int tile0, int chan_base,
-                                          const f4 (&sc)[2], const f4 (&sh)[2], int lane) {
+// The store address of the lane's cell in tile i is derived from base[i] (the read address of its top-left
+// neighbour + the lane's K chunk): row(cell) = base[i] + 8*STRIDE - 16*(lane>>4), channel ch sits 2*ch bytes into
+// the row.  One per-lane delta + immediates instead of 18 independently computed (and hoisted, and spilled) addresses.
+template <int C, int S>
+__device__ __forceinline__ int store_delta(int chan_base, int lane) {
     using K = Cfg<C, S>;
-    const int sub = (lane >> 4) * 4;
+    return 8 * K::STRIDE + chan_base * 2 - (lane >> 4) * 8;     // + 2*sub - 16*(lane>>4) with sub = 4*(lane>>4)
+}
+
+template <int C, int S, bool HAS_SCALE>
+__device__ __forceinline__ void store_act(const Acc& acc, unsigned char* lds, const int (&base)[9], int chan_base,
+                                          const f4 (&sc)[2], const f4 (&sh)[2], int lane) {
+    const int delta = store_delta<C, S>(chan_base, lane);
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
-        const int n = (tile0 + i) * 16 + (lane & 15);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             f4 v = acc[i][j];
             if (HAS_SCALE) v = v * sc[j] + sh[j]; else v = v + sh[j];
             const h4 o = to_h4(fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f));
-            const int ch = chan_base + j * 16 + sub;
-            *reinterpret_cast<h4*>(lds + act_addr<C, S>(n, ch >> 3) + (ch & 7) * 2) = o;
+            *reinterpret_cast<h4*>(lds + base[i] + delta + j * 32) = o;
         }
     }
 }
@@ -279,19 +285,19 @@ __device__ __forceinline__ f4 fc_tile(__amdgpu_buffer_rsrc_t rw, int half_off, i
 
 // write one head map (64 channels wide) from a wave's 2 output tiles: channel = (tile_in_map*16) + ...
 template <int C, int S>
-__device__ __forceinline__ void store_head(const Acc& acc, unsigned char* lds, int tile0, int map_tile0,
+__device__ __forceinline__ void store_head(const Acc& acc, unsigned char* lds, const int (&base)[9], int map_tile0,
                                            __amdgpu_buffer_rsrc_t rf, int bias_off, int lane) {
-    using K = Cfg<C, S>;
     const int sub = (lane >> 4) * 4;
+    const int delta = store_delta<C, S>(map_tile0 * 16, lane);
+    f4 b[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) b[j] = load_f4(rf, sub, bias_off + (map_tile0 + j) * 16);
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
-        const int n = (tile0 + i) * 16 + (lane & 15);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int ch = (map_tile0 + j) * 16 + sub;
-            const f4 b = load_f4(rf, sub, bias_off + (map_tile0 + j) * 16);
-            const f4 v = acc[i][j] + b;
-            *reinterpret_cast<h4*>(lds + act_addr<C, S>(n, ch >> 3) + (ch & 7) * 2) =
+            const f4 v = acc[i][j] + b[j];
+            *reinterpret_cast<h4*>(lds + base[i] + delta + j * 32) =
                 to_h4(fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f));
         }
     }
@@ -344,7 +350,11 @@ __global__ __launch_bounds__(512, 2) void net_forward_kernel(NetParams P, const 
         const int nvalid = (int)((N - n0) < S ? (N - n0) : S);
         __syncthreads();
         // ---- stage the 11 input planes as fp16 rows [cell][32 ch] (ch >= 11 zero) ----
-        for (int n = tid; n < K::NPOS; n += NTHR) {
+        // (opaque copy of the thread id: the staging / head index arithmetic below is recomputed per pass instead of
+        //  being hoisted out of the pass loop and spilled around the trunk)
+        int tid_s = tid;
+        asm volatile("" : "+v"(tid_s));
+        for (int n = tid_s; n < K::NPOS; n += NTHR) {
             const int s = n / 36, p = n - s * 36;
             _Float16 row[32];
 #pragma unroll
@@ -408,7 +418,7 @@ __global__ __launch_bounds__(512, 2) void net_forward_kernel(NetParams P, const 
             load_chan_params(rf, bp + C, chan0, lane, pb);
             load_first_frags(rw, P.layer_off[1 + 2 * blk], ct0, lane, Af);
             lds_barrier();                                     // everyone finished reading the act buffer
-            store_act<C, S, true>(x, lds, tile0, chan0, pa, pb, lane);                 // t = relu(a1*x + b1)
+            store_act<C, S, true>(x, lds, base, chan0, pa, pb, lane);                 // t = relu(a1*x + b1)
             load_chan_params(rf, bp + 2 * C, chan0, lane, pb);                          // bias1, used after conv1
             lds_barrier();
 #pragma unroll
@@ -418,12 +428,15 @@ __global__ __launch_bounds__(512, 2) void net_forward_kernel(NetParams P, const 
             conv_gemm<C, S, true, false, K::CT>(acc, rw, P.layer_off[1 + 2 * blk], ct0, lds, base, lane, Af);
             load_first_frags(rw, P.layer_off[2 + 2 * blk], ct0, lane, Af);
             lds_barrier();
-            store_act<C, S, false>(acc, lds, tile0, chan0, pb, pb, lane);               // u = relu(conv1 + bias1)
+            store_act<C, S, false>(acc, lds, base, chan0, pb, pb, lane);               // u = relu(conv1 + bias1)
             lds_barrier();
             conv_gemm<C, S, true, false, K::CT>(x, rw, P.layer_off[2 + 2 * blk], ct0, lds, base, lane, Af);  // x += conv2(u)
         }
         if (P.debug_stop == 3) { if (lane == 0 && x[0][0][0] == 123.f) lp1[0] = 1.f; continue; }   // after the trunk
         // ---- trunk output h = relu(a*x + b) -> LDS; head 1x1 convs (8 output tiles: policy 0..3 | value 4..7) ----
+        int tid_h = tid;
+        asm volatile("" : "+v"(tid_h));                            // see tid_s: nothing below is live across the trunk
+        const int lane_h = tid_h & 63;
         const int wh = P.layer_off[1 + 2 * P.blocks];
         const int ht0 = cg * K::CTW;                               // head tile of acc   (0..7)
         const int ht1 = K::CG * K::CTW + cg * K::CTW;              // head tile of x     (HP == 2 only)
@@ -431,7 +444,7 @@ __global__ __launch_bounds__(512, 2) void net_forward_kernel(NetParams P, const 
         load_chan_params(rf, P.trunk_b, chan0, lane, pb);
         load_first_frags(rw, wh, ht0, lane, Af);
         lds_barrier();
-        store_act<C, S, true>(x, lds, tile0, chan0, pa, pb, lane);
+        store_act<C, S, true>(x, lds, base, chan0, pa, pb, lane);
         lds_barrier();
 #pragma unroll
         for (int i = 0; i < 9; ++i)
@@ -446,13 +459,13 @@ __global__ __launch_bounds__(512, 2) void net_forward_kernel(NetParams P, const 
         __syncthreads();
         if (P.debug_stop == 4) { if (lane == 0 && (acc[0][0][0] + x[0][0][0]) == 123.f) lp1[0] = 1.f; continue; }   // after head convs
         // ---- policy head ----
-        if (ht0 < 4) store_head<C, S>(acc, lds, tile0, ht0, rf, P.head_bias, lane);
+        if (ht0 < 4) store_head<C, S>(acc, lds, base, ht0, rf, P.head_bias, lane);
         __syncthreads();
-        gpool64<C, S>(lds, tid);
+        gpool64<C, S>(lds, tid_h);
         __syncthreads();
         if (wave < 4) {                                            // g = gpool_linear(pooled): 4 tiles x K=192
-            const f4 d = fc_tile<4, 6>(rw, P.hf_gw, wave, lds + K::POOL_OFF, K::POOL_STRIDE, lane);
-            const int s = lane & 15, ch = wave * 16 + (lane >> 4) * 4;
+            const f4 d = fc_tile<4, 6>(rw, P.hf_gw, wave, lds + K::POOL_OFF, K::POOL_STRIDE, lane_h);
+            const int s = lane_h & 15, ch = wave * 16 + (lane_h >> 4) * 4;
             *reinterpret_cast<f4*>(gvec + s * kHead + ch) = d;
         }
         __syncthreads();
@@ -464,19 +477,19 @@ __global__ __launch_bounds__(512, 2) void net_forward_kernel(NetParams P, const 
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
-                    const int ch = (kb * 4 + (lane >> 4)) * 8 + k;
+                    const int ch = (kb * 4 + (lane_h >> 4)) * 8 + k;
                     pa2[kb][k] = par[ch];
                     pb2[kb][k] = par[kHead + ch];
                 }
-            const h8 wo0 = load_wfrag(rw, lane * 16, P.hf_out * 2);
-            const h8 wo1 = load_wfrag(rw, lane * 16, P.hf_out * 2 + 1024);
+            const h8 wo0 = load_wfrag(rw, lane_h * 16, P.hf_out * 2);
+            const h8 wo1 = load_wfrag(rw, lane_h * 16, P.hf_out * 2 + 1024);
             for (int t = wave; t < K::NT; t += K::WAVES) {
                 f4 d = (f4){0.f, 0.f, 0.f, 0.f};
-                const int n = t * 16 + (lane & 15);
+                const int n = t * 16 + (lane_h & 15);
                 const int s = n / 36, p = n - s * 36;
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb) {
-                    const int chunk = kb * 4 + (lane >> 4);
+                    const int chunk = kb * 4 + (lane_h >> 4);
                     h8 v = *reinterpret_cast<const h8*>(lds + act_addr<C, S>(n, chunk));
                     const f4 g0 = *reinterpret_cast<const f4*>(gvec + s * kHead + chunk * 8);
                     const f4 g1 = *reinterpret_cast<const f4*>(gvec + s * kHead + chunk * 8 + 4);
@@ -485,7 +498,7 @@ __global__ __launch_bounds__(512, 2) void net_forward_kernel(NetParams P, const 
                         v[k] = (_Float16)fmaxf(((float)v[k] + (k < 4 ? g0[k] : g1[k - 4])) * pa2[kb][k] + pb2[kb][k], 0.f);
                     d = __builtin_amdgcn_mfma_f32_16x16x32_f16(kb == 0 ? wo0 : wo1, v, d, 0, 0, 0);
                 }
-                if (lane < 16) {
+                if (lane_h < 16) {
                     plog[(s * 3 + 0) * 36 + p] = d[0];
                     plog[(s * 3 + 1) * 36 + p] = d[1];
                     plog[(s * 3 + 2) * 36 + p] = d[2];
@@ -495,24 +508,24 @@ __global__ __launch_bounds__(512, 2) void net_forward_kernel(NetParams P, const 
         __syncthreads();
         for (int row = wave; row < S * 3; row += K::WAVES) {        // log_softmax over the 36 cells, one wave per row
             const int s = row / 3, h = row - s * 3;
-            const float v = lane < 36 ? plog[row * 36 + lane] : -INFINITY;
+            const float v = lane_h < 36 ? plog[row * 36 + lane_h] : -INFINITY;
             const float mx = lzw::wave_max(v);
-            const float e = lzw::wave_sum(lane < 36 ? expf(v - mx) : 0.f);
+            const float e = lzw::wave_sum(lane_h < 36 ? expf(v - mx) : 0.f);
             const float lse = mx + logf(e);
-            if (lane < 36 && s < nvalid) (h == 0 ? lp1 : h == 1 ? lp2 : lpm)[(n0 + s) * 36 + lane] = v - lse;
+            if (lane_h < 36 && s < nvalid) (h == 0 ? lp1 : h == 1 ? lp2 : lpm)[(n0 + s) * 36 + lane_h] = v - lse;
         }
         __syncthreads();
-        if (P.debug_stop == 5) { if (lane == 0 && x[0][0][0] == 123.f) lp1[0] = 1.f; continue; }   // after the policy head
+        if (P.debug_stop == 5) { if (lane_h == 0 && x[0][0][0] == 123.f) lp1[0] = 1.f; continue; }   // after the policy head
         // ---- value head ----
-        if (K::HP == 2) store_head<C, S>(x, lds, tile0, ht1 - 4, rf, P.head_bias + kHead, lane);
-        else if (ht0 >= 4) store_head<C, S>(acc, lds, tile0, ht0 - 4, rf, P.head_bias + kHead, lane);
+        if (K::HP == 2) store_head<C, S>(x, lds, base, ht1 - 4, rf, P.head_bias + kHead, lane);
+        else if (ht0 >= 4) store_head<C, S>(acc, lds, base, ht0 - 4, rf, P.head_bias + kHead, lane);
         __syncthreads();
-        gpool64<C, S>(lds, tid);
+        gpool64<C, S>(lds, tid_h);
         __syncthreads();
         {                                                           // fc1 + relu: 8 tiles x K=192, one per wave
-            const f4 d = fc_tile<8, 6>(rw, P.hf_w1, wave, lds + K::POOL_OFF, K::POOL_STRIDE, lane);
-            const int s = lane & 15, ch = wave * 16 + (lane >> 4) * 4;
-            const f4 b = load_f4(rf, (lane >> 4) * 4, P.v_b1 + wave * 16);
+            const f4 d = fc_tile<8, 6>(rw, P.hf_w1, wave, lds + K::POOL_OFF, K::POOL_STRIDE, lane_h);
+            const int s = lane_h & 15, ch = wave * 16 + (lane_h >> 4) * 4;
+            const f4 b = load_f4(rf, (lane_h >> 4) * 4, P.v_b1 + wave * 16);
             const f4 v = d + b;
             *reinterpret_cast<h4*>(lds + K::HID_OFF + s * K::HID_STRIDE + ch * 2) =
                 to_h4(fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f));
@@ -520,24 +533,24 @@ __global__ __launch_bounds__(512, 2) void net_forward_kernel(NetParams P, const 
         __syncthreads();
         float* vl = plog;                                           // [16][112] value logits
         if (wave < 7) {                                             // fc2: 7 tiles (101 bins padded to 112) x K=128
-            const f4 d = fc_tile<7, 4>(rw, P.hf_w2, wave, lds + K::HID_OFF, K::HID_STRIDE, lane);
-            const int s = lane & 15, o = wave * 16 + (lane >> 4) * 4;
+            const f4 d = fc_tile<7, 4>(rw, P.hf_w2, wave, lds + K::HID_OFF, K::HID_STRIDE, lane_h);
+            const int s = lane_h & 15, o = wave * 16 + (lane_h >> 4) * 4;
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 if (o + r < kBins) vl[s * K::VL_STRIDE + o + r] = d[r] + fp[P.v_b2 + o + r];
         }
         __syncthreads();
         for (int s = wave; s < nvalid; s += K::WAVES) {              // bucket expectation, one wave per sample
-            const float v0 = vl[s * K::VL_STRIDE + lane];
-            const float v1 = lane + 64 < kBins ? vl[s * K::VL_STRIDE + lane + 64] : -INFINITY;
+            const float v0 = vl[s * K::VL_STRIDE + lane_h];
+            const float v1 = lane_h + 64 < kBins ? vl[s * K::VL_STRIDE + lane_h + 64] : -INFINITY;
             const float mx = lzw::wave_max(fmaxf(v0, v1));
-            const float e0 = expf(v0 - mx), e1 = lane + 64 < kBins ? expf(v1 - mx) : 0.f;
+            const float e0 = expf(v0 - mx), e1 = lane_h + 64 < kBins ? expf(v1 - mx) : 0.f;
             const float sum = lzw::wave_sum(e0 + e1);
-            const float ex = lzw::wave_sum(e0 * (-1.0f + 0.02f * (float)lane) + e1 * (-1.0f + 0.02f * (float)(lane + 64)));
-            if (lane == 0 && value != nullptr) value[n0 + s] = ex / sum;
+            const float ex = lzw::wave_sum(e0 * (-1.0f + 0.02f * (float)lane_h) + e1 * (-1.0f + 0.02f * (float)(lane_h + 64)));
+            if (lane_h == 0 && value != nullptr) value[n0 + s] = ex / sum;
             if (vlogits != nullptr) {
-                vlogits[(n0 + s) * kBins + lane] = v0;
-                if (lane + 64 < kBins) vlogits[(n0 + s) * kBins + lane + 64] = v1;
+                vlogits[(n0 + s) * kBins + lane_h] = v0;
+                if (lane_h + 64 < kBins) vlogits[(n0 + s) * kBins + lane_h + 64] = v1;
             }
         }
     }
