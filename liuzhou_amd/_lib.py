@@ -37,11 +37,12 @@ SYMBOLS = (
 def lib() -> C.CDLL:
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB):
+        path = os.environ.get("LZ_HIP_LIB", LIB)          # kernel experiments: another build of the same HIP library
+        if not os.path.exists(path):
             raise RuntimeError(
-                f"liuzhou_amd: HIP extension {LIB} is missing. Build it with "
+                f"liuzhou_amd: HIP extension {path} is missing. Build it with "
                 "`python -m liuzhou_amd.build` (hipcc --offload-arch=gfx950); there is no CPU fallback.")
-        L = C.CDLL(LIB)
+        L = C.CDLL(path)
         L.lz_version.restype = C.c_char_p
         L.lz_status_string.restype = C.c_char_p
         L.lz_status_string.argtypes = [C.c_int]

@@ -61,11 +61,13 @@ struct NetParams {
     int stem_bias, blk0, trunk_a, trunk_b, head_bias, p_gwT, p_a2, p_b2, p_out, v_w1T, v_b1, v_w2T, v_b2;
 };
 
-template <int C, int S>
+// W = waves per workgroup.  8 waves x S samples fills a CU with ONE workgroup (LDS-limited); 4 waves x S/2 samples
+// lets TWO independent workgroups share a CU, so one's store / barrier / head phases overlap the other's MFMAs.
+template <int C, int S, int W = 8>
 struct Cfg {
     static constexpr int NPOS = S * 36;
     static constexpr int NT = NPOS / 16;
-    static constexpr int WAVES = 8;
+    static constexpr int WAVES = W;
     static constexpr int THREADS = WAVES * 64;
     static constexpr int CTW = 2;                   // 16-channel output tiles per wave
     static constexpr int PG = NT / 9;               // cell groups (4 or 2)
@@ -73,7 +75,8 @@ struct Cfg {
     static constexpr int CT = C / 16;               // 16-channel output tiles
     static constexpr int KB = C / 32;               // 32-channel K blocks
     static constexpr int KBLOG = (KB == 1) ? 0 : (KB == 2) ? 1 : 2;
-    static constexpr int STRIDE = C * 2 + 16;       // bytes per cell row (16-byte aligned, bank-skewed)
+    // bytes per cell row: an ODD number of 16-byte slots (9 or 17), part of the conflict-free operand layout below
+    static constexpr int STRIDE = C * 2 + 16;
     // Zero-bordered board: cell (r,c) of sample s sits at row 58*s + 1 + 7*(r+1) + c; one shared zero column
     // between board rows and zero rows above/below make every 3x3 tap an in-bounds read at a CONSTANT byte
     // offset from the top-left neighbour -> the tap offset is folded into the ds_read immediate, no VALU.
@@ -84,25 +87,93 @@ struct Cfg {
     static constexpr int POOL_STRIDE = kPool * 2 + 16;              // 400 B per sample row
     static constexpr int HID_STRIDE = kMlp * 2 + 16;                // 272 B per sample row
     static constexpr int VL_STRIDE = 112;                           // floats per sample (101 bins padded)
+    // Two aliased regions (lifetimes are separated by workgroup barriers): A = pooled rows | policy logits / value
+    // logits (written only after the FC layer that consumed the pooled rows), B = g vector (policy) | fc1 hidden
+    // rows (value).  Keeps a 4-wave workgroup under 80 KB so that two of them share a CU's 160 KB.
     static constexpr int POOL_OFF = ZERO_OFF + STRIDE;
-    static constexpr int G_OFF = POOL_OFF + 16 * POOL_STRIDE;
-    static constexpr int HID_OFF = G_OFF + 16 * kHead * 4;
-    static constexpr int PLOG_OFF = HID_OFF + 16 * HID_STRIDE;
+    static constexpr int PLOG_OFF = POOL_OFF;
     static constexpr int PLOG_BYTES = (S * 432 > 16 * VL_STRIDE * 4) ? S * 432 : 16 * VL_STRIDE * 4;
-    static constexpr int PAR_OFF = PLOG_OFF + PLOG_BYTES;
+    static constexpr int A_BYTES = (16 * POOL_STRIDE > PLOG_BYTES) ? 16 * POOL_STRIDE : PLOG_BYTES;
+    static constexpr int G_OFF = POOL_OFF + A_BYTES;
+    static constexpr int HID_OFF = G_OFF;
+    static constexpr int B_BYTES = (16 * kHead * 4 > 16 * HID_STRIDE) ? 16 * kHead * 4 : 16 * HID_STRIDE;
+    static constexpr int PAR_OFF = G_OFF + B_BYTES;
     static constexpr int LDS_BYTES = PAR_OFF + 5 * kHead * 4;
     static constexpr int HP = 8 / (CG * CTW);       // passes over the 8 head output tiles (2 or 1)
-    static_assert(CT == CG * CTW, "each wave owns 2 output-channel tiles");
-    static_assert(NT % 9 == 0 && PG * CG == WAVES, "8 waves per workgroup");
 };
 
-// byte address of 16-byte chunk `chunk` of board cell n (n = 36*sample + 6*r + c)
+// ---- conflict-free LDS operand layout ------------------------------------------------------------------------
+// A ds_read_b128 is served in four 16-lane groups, {0-3,12-15,20-27}, {4-11,16-19,28-31} and the same +32
+// (MI355X_MICROARCH.md, LDS): one LDS cycle per group if its 16 lanes touch 16 different 16-byte slots mod 256 B.
+// The B operand of v_mfma_f32_16x16x32_f16 puts column (lane & 15) = a board cell and K chunk (lane >> 4) on a
+// lane, so a group mixes 8 cells ("X": columns 0-3,12-15) at chunk q with 8 cells ("Y": columns 4-11) at chunk q+1.
+//   * inside a row the four 16-byte chunks of a 32-channel K block sit 32 bytes apart (two K blocks interleaved):
+//     slot(cell, q) = (STRIDE/16 * row(cell) + 2q + const) mod 16;
+//   * a tile is not 16 consecutive cells but 16 cells chosen so that X and Y each hold one cell of every row class
+//     {0,1,4,5,8,9,12,13} (or {2,3,6,7,...}) mod 16: X slots and Y slots (shifted by 2) then tile all 16 slots.
+// The S*36 rows of a workgroup contain every class equally often, so all tiles are perfect: 4 LDS cycles per read
+// instead of 12 (64 channels) / 8 (128 channels) with consecutive cells.  Rows stay where the zero-bordered board
+// puts them, so 3x3 taps remain constant offsets; only the cell <-> (tile, column) assignment is permuted, which no
+// other phase sees (accumulators keep the same assignment through all layers).
+__host__ __device__ constexpr int board_row(int n) {                // row index of board cell n = 36*sample + 6*r + c
+    const int s = n / 36, p = n - s * 36;
+    const int r = p / 6, c = p - r * 6;
+    return s * 58 + 1 + 7 * (r + 1) + c;
+}
+__host__ __device__ constexpr int chunk_pos(int chunk) {            // 16-byte position of channel chunk (8 channels)
+    return 2 * (chunk & 3) + ((chunk >> 2) & 1) + 8 * (chunk >> 3);
+}
+template <int C, int S>
+struct TileMap { unsigned short cell[S * 36 / 16][16]; };
+template <int C, int S>
+constexpr TileMap<C, S> make_tile_map() {
+    constexpr int NT = S * 36 / 16;
+    constexpr int m = ((C * 2 + 16) / 16) & 15;
+    constexpr int xcols[8] = {0, 1, 2, 3, 12, 13, 14, 15}, ycols[8] = {4, 5, 6, 7, 8, 9, 10, 11};
+    TileMap<C, S> t{};
+    int count[2][8] = {};
+    for (int n = 0; n < S * 36; ++n) {
+        const int res = (m * board_row(n)) & 15;
+        const int type = (res & 3) >> 1, idx = (res >> 2) * 2 + (res & 1);
+        const int k = count[type][idx]++;                           // every class occurs exactly NT times
+        const int tile = type * (NT / 2) + (k >> 1);
+        t.cell[tile][(k & 1) ? ycols[idx] : xcols[idx]] = (unsigned short)n;
+    }
+    return t;
+}
+template <int C, int S>
+constexpr bool tile_map_ok() {                                      // compile-time proof of the claim above
+    constexpr int NT = S * 36 / 16;
+    constexpr int m = ((C * 2 + 16) / 16) & 15;
+    const TileMap<C, S> t = make_tile_map<C, S>();
+    bool seen[S * 36] = {};
+    for (int tile = 0; tile < NT; ++tile)
+        for (int g = 0; g < 2; ++g) {                               // groups {X at q, Y at q+1} and {Y at q, X at q+1}
+            bool slot[16] = {};
+            for (int col = 0; col < 16; ++col) {
+                const bool is_x = col < 4 || col >= 12;
+                const int q = (is_x == (g == 0)) ? 0 : 1;
+                const int sl = (m * board_row(t.cell[tile][col]) + 2 * q) & 15;
+                if (slot[sl]) return false;
+                slot[sl] = true;
+                if (g == 0) { if (seen[t.cell[tile][col]]) return false; seen[t.cell[tile][col]] = true; }
+            }
+        }
+    for (int n = 0; n < S * 36; ++n) if (!seen[n]) return false;
+    return true;
+}
+static_assert(tile_map_ok<64, 16>() && tile_map_ok<128, 8>(), "operand tiles must be bank-conflict free");
+__constant__ const TileMap<64, 16> kTileMap64 = make_tile_map<64, 16>();
+__constant__ const TileMap<128, 8> kTileMap128 = make_tile_map<128, 8>();
+template <int C, int S> __device__ __forceinline__ int tile_cell(int tile, int col);
+template <> __device__ __forceinline__ int tile_cell<64, 16>(int tile, int col) { return kTileMap64.cell[tile][col]; }
+template <> __device__ __forceinline__ int tile_cell<128, 8>(int tile, int col) { return kTileMap128.cell[tile][col]; }
+
+// byte address of 16-byte channel chunk `chunk` of board cell n (n = 36*sample + 6*r + c)
 template <int C, int S>
 __device__ __forceinline__ int act_addr(int n, int chunk) {
     using K = Cfg<C, S>;
-    const int s = n / 36, p = n - s * 36;
-    const int r = p / 6, c = p - r * 6;
-    return K::ACT_OFF + (s * K::CELLS + 1 + 7 * (r + 1) + c) * K::STRIDE + (chunk << 4);
+    return K::ACT_OFF + board_row(n) * K::STRIDE + (chunk_pos(chunk) << 4);
 }
 
 // ---- the GEMM core: acc[9 cell tiles][4 channel tiles] += W(layer) * act --------------------------------
@@ -117,7 +188,7 @@ __device__ __forceinline__ constexpr int step_offset(int step) {
     using K = Cfg<C, S>;
     const int tap = !TAPS9 ? 4 : (STEM ? step : step / K::KB);
     const int kb = !TAPS9 ? step : (STEM ? 0 : step % K::KB);
-    return ((tap / 3) * 7 + (tap % 3)) * K::STRIDE + kb * 64;
+    return ((tap / 3) * 7 + (tap % 3)) * K::STRIDE + (chunk_pos(kb * 4) << 4);
 }
 
 // One K step, software-pipelined IN PLACE: tile i's activation fragment register is reloaded for the next K step
@@ -132,7 +203,9 @@ __device__ __forceinline__ void gemm_step(Acc& acc, const h8 (&A)[2], h8 (&B)[9]
     for (int i = 0; i < 9; ++i) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[j], B[i], acc[i][j], 0, 0, 0);
+#ifndef LZ_EXP_NO_BRELOAD   /* timing experiment only: without the LDS operand reloads the results are wrong */
         if (STEP + 1 < NSTEPS) B[i] = *reinterpret_cast<const h8*>(lds + base[i] + next_off);
+#endif
         __builtin_amdgcn_sched_barrier(0);
     }
 }
@@ -204,12 +277,14 @@ __device__ __forceinline__ void load_chan_params(__amdgpu_buffer_rsrc_t rf, int 
 }
 
 // The store address of the lane's cell in tile i is derived from base[i] (the read address of its top-left
-// neighbour + the lane's K chunk): row(cell) = base[i] + 8*STRIDE - 16*(lane>>4), channel ch sits 2*ch bytes into
-// the row.  One per-lane delta + immediates instead of 18 independently computed (and hoisted, and spilled) addresses.
+// neighbour + the lane's K chunk): row(cell) = base[i] + 8*STRIDE - 32*(lane>>4); the lane writes channels
+// chan_base + 16j + 4q .. +4 (q = lane>>4, chan_base a multiple of 32), i.e. chunk chan_base/8 + 2j + (q>>1), half
+// (q&1).  One per-lane delta + the immediate 64j instead of 18 independently computed (hoisted, spilled) addresses.
 template <int C, int S>
 __device__ __forceinline__ int store_delta(int chan_base, int lane) {
     using K = Cfg<C, S>;
-    return 8 * K::STRIDE + chan_base * 2 - (lane >> 4) * 8;     // + 2*sub - 16*(lane>>4) with sub = 4*(lane>>4)
+    const int q = lane >> 4;
+    return 8 * K::STRIDE - 32 * q + (chunk_pos(chan_base >> 3) << 4) + 32 * (q >> 1) + 8 * (q & 1);
 }
 
 template <int C, int S, bool HAS_SCALE>
@@ -223,7 +298,7 @@ __device__ __forceinline__ void store_act(const Acc& acc, unsigned char* lds, co
             f4 v = acc[i][j];
             if (HAS_SCALE) v = v * sc[j] + sh[j]; else v = v + sh[j];
             const h4 o = to_h4(fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f));
-            *reinterpret_cast<h4*>(lds + base[i] + delta + j * 32) = o;
+            *reinterpret_cast<h4*>(lds + base[i] + delta + j * 64) = o;
         }
     }
 }
@@ -297,19 +372,22 @@ __device__ __forceinline__ void store_head(const Acc& acc, unsigned char* lds, c
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const f4 v = acc[i][j] + b[j];
-            *reinterpret_cast<h4*>(lds + base[i] + delta + j * 32) =
+            *reinterpret_cast<h4*>(lds + base[i] + delta + j * 64) =
                 to_h4(fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f));
         }
     }
 }
 
-template <int C, int S>
-__global__ __launch_bounds__(512, 2) void net_forward_kernel(NetParams P, const float* __restrict__ planes,
+template <int C, int S, int W>
+__global__ __launch_bounds__(W * 64, 2) void net_forward_kernel(NetParams P, const float* __restrict__ planes,
                                                             const uint64_t* __restrict__ packed,
                                                             int64_t N, float* __restrict__ lp1,
                                                             float* __restrict__ lp2, float* __restrict__ lpm,
                                                             float* __restrict__ vlogits, float* __restrict__ value) {
-    using K = Cfg<C, S>;
+    using K = Cfg<C, S, W>;
+    static_assert(K::CT == K::CG * K::CTW, "each wave owns 2 output-channel tiles");
+    static_assert(K::NT % 9 == 0 && K::PG * K::CG == K::WAVES, "waves = cell groups x channel groups");
+    static_assert(S * 32 <= K::THREADS, "global pooling uses 2 lanes per (sample, 4-channel group)");
     constexpr int NTHR = K::THREADS;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x;
@@ -327,15 +405,15 @@ __global__ __launch_bounds__(512, 2) void net_forward_kernel(NetParams P, const 
     int base[9];                                         // top-left neighbour of the lane's cell, + the lane's K chunk
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
-        const int n = (tile0 + i) * 16 + (lane & 15);
-        base[i] = act_addr<C, S>(n, lane >> 4) - 8 * K::STRIDE;
+        const int n = tile_cell<C, S>(tile0 + i, lane & 15);
+        base[i] = K::ACT_OFF + board_row(n) * K::STRIDE + (lane >> 4) * 32 - 8 * K::STRIDE;
     }
     // zero the whole activation buffer once: the board borders stay zero for every layer / pass
     for (int i = tid; i < K::ZERO_OFF / 16; i += NTHR) reinterpret_cast<uint4*>(lds + K::ACT_OFF)[i] = make_uint4(0, 0, 0, 0);
     float* gvec = reinterpret_cast<float*>(lds + K::G_OFF);
     float* plog = reinterpret_cast<float*>(lds + K::PLOG_OFF);
     float* par = reinterpret_cast<float*>(lds + K::PAR_OFF);
-    for (int i = tid; i < (K::PLOG_OFF - K::POOL_OFF) / 4; i += NTHR) reinterpret_cast<uint32_t*>(lds + K::POOL_OFF)[i] = 0u;
+    for (int i = tid; i < (K::PAR_OFF - K::POOL_OFF) / 4; i += NTHR) reinterpret_cast<uint32_t*>(lds + K::POOL_OFF)[i] = 0u;
     for (int i = tid; i < 5 * kHead; i += NTHR) {
         float v;
         if (i < kHead) v = fp[P.p_a2 + i];
@@ -522,19 +600,19 @@ __global__ __launch_bounds__(512, 2) void net_forward_kernel(NetParams P, const 
         __syncthreads();
         gpool64<C, S>(lds, tid_h);
         __syncthreads();
-        {                                                           // fc1 + relu: 8 tiles x K=192, one per wave
-            const f4 d = fc_tile<8, 6>(rw, P.hf_w1, wave, lds + K::POOL_OFF, K::POOL_STRIDE, lane_h);
-            const int s = lane_h & 15, ch = wave * 16 + (lane_h >> 4) * 4;
-            const f4 b = load_f4(rf, (lane_h >> 4) * 4, P.v_b1 + wave * 16);
+        for (int ct = wave; ct < 8; ct += K::WAVES) {               // fc1 + relu: 8 tiles x K=192
+            const f4 d = fc_tile<8, 6>(rw, P.hf_w1, ct, lds + K::POOL_OFF, K::POOL_STRIDE, lane_h);
+            const int s = lane_h & 15, ch = ct * 16 + (lane_h >> 4) * 4;
+            const f4 b = load_f4(rf, (lane_h >> 4) * 4, P.v_b1 + ct * 16);
             const f4 v = d + b;
             *reinterpret_cast<h4*>(lds + K::HID_OFF + s * K::HID_STRIDE + ch * 2) =
                 to_h4(fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f));
         }
         __syncthreads();
         float* vl = plog;                                           // [16][112] value logits
-        if (wave < 7) {                                             // fc2: 7 tiles (101 bins padded to 112) x K=128
-            const f4 d = fc_tile<7, 4>(rw, P.hf_w2, wave, lds + K::HID_OFF, K::HID_STRIDE, lane_h);
-            const int s = lane_h & 15, o = wave * 16 + (lane_h >> 4) * 4;
+        for (int ct = wave; ct < 7; ct += K::WAVES) {               // fc2: 7 tiles (101 bins padded to 112) x K=128
+            const f4 d = fc_tile<7, 4>(rw, P.hf_w2, ct, lds + K::HID_OFF, K::HID_STRIDE, lane_h);
+            const int s = lane_h & 15, o = ct * 16 + (lane_h >> 4) * 4;
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 if (o + r < kBins) vl[s * K::VL_STRIDE + o + r] = d[r] + fp[P.v_b2 + o + r];
@@ -556,11 +634,11 @@ __global__ __launch_bounds__(512, 2) void net_forward_kernel(NetParams P, const 
     }
 }
 
-template <int C, int S>
+template <int C, int S, int W>
 int launch_net(const NetParams& P, const float* planes, const uint64_t* packed, int64_t N, float* lp1, float* lp2,
                float* lpm, float* vlogits, float* value, int max_blocks, hipStream_t st) {
-    using K = Cfg<C, S>;
-    auto kern = net_forward_kernel<C, S>;
+    using K = Cfg<C, S, W>;
+    auto kern = net_forward_kernel<C, S, W>;
     const int64_t n_pass = (N + S - 1) / S;
     int grid = (int)(n_pass < max_blocks ? n_pass : max_blocks);
     if (grid < 1) grid = 1;
@@ -568,10 +646,10 @@ int launch_net(const NetParams& P, const float* planes, const uint64_t* packed, 
     return hipGetLastError() == hipSuccess ? LZ_OK : LZ_ERR_LAUNCH;
 }
 
-template <int C, int S>
+template <int C, int S, int W>
 int configure_net() {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(net_forward_kernel<C, S>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, Cfg<C, S>::LDS_BYTES) == hipSuccess
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(net_forward_kernel<C, S, W>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, Cfg<C, S, W>::LDS_BYTES) == hipSuccess
                ? LZ_OK : LZ_ERR_LAUNCH;
 }
 
@@ -619,8 +697,7 @@ int lz_prof_net_summary(double* total_ms, int64_t* launches, int64_t* evals) {
 }
 
 int lz_net_configure(void) {
-    int a = configure_net<64, 16>();
-    int b = configure_net<128, 8>();
+    const int a = configure_net<64, 16, 8>(), b = configure_net<128, 8, 8>();
     return a != LZ_OK ? a : b;
 }
 
@@ -648,9 +725,11 @@ static int net_forward_impl(const LzNetDesc* d, const float* planes, const uint6
     if (d->channels != 64 && d->channels != 128) return LZ_ERR_UNSUPPORTED;
     const bool prof = g_prof.on && g_prof.used < NetProf::kMax;
     if (prof) (void)hipEventRecord(g_prof.ev[2 * g_prof.used], st);
+    // one 8-wave workgroup per CU; two 4-wave workgroups per CU (W = 4, half the samples each) measured the same: the
+    // trunk is bound by LDS operand reads + MFMA issue, not by the serialisation of its phases
     const int rc = d->channels == 64
-                       ? launch_net<64, 16>(P, planes, packed, N, lp1, lp2, lpmc, value_logits, value, max_blocks, st)
-                       : launch_net<128, 8>(P, planes, packed, N, lp1, lp2, lpmc, value_logits, value, max_blocks, st);
+                       ? launch_net<64, 16, 8>(P, planes, packed, N, lp1, lp2, lpmc, value_logits, value, max_blocks, st)
+                       : launch_net<128, 8, 8>(P, planes, packed, N, lp1, lp2, lpmc, value_logits, value, max_blocks, st);
     if (prof) { (void)hipEventRecord(g_prof.ev[2 * g_prof.used + 1], st); g_prof.used += 1; g_prof.evals += N; }
     return rc;
 }
