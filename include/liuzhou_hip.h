@@ -232,7 +232,7 @@ typedef struct LzTreeDesc {
     int32_t* root_visits;          /* [B] */
     double*  root_w;               /* [B] */
     float*   root_init_value;      /* [B] */
-    int32_t* path;                 /* [B*path_cap] */
+    int32_t* path;                 /* [B*path_cap] edge index | bit 31: the mover changes from parent to child */
     int32_t* path_len;             /* [B] */
     int32_t* leaf_kind;            /* [B] 0 inactive, 1 needs evaluation, 2 terminal (value in leaf_value),
                                       3 root kept by lz_tree_advance (no evaluation, noise mix only) */
@@ -240,6 +240,8 @@ typedef struct LzTreeDesc {
     float*   leaf_value;           /* [B] */
     uint8_t* root_terminal;        /* [B] */
     const uint8_t* active;         /* [B] or NULL (all active) */
+    int32_t* leaf_edge;            /* [B] edge the pending leaf hangs from (select -> expand hand-off) */
+    int32_t* leaf_parent;          /* [B] node that owns that edge */
 } LzTreeDesc;
 
 /* SoA batch -> packed records; packed records -> float32[B,11,6,6] model input (src/neural_network.py:15-65) */

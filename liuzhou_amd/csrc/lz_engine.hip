@@ -16,6 +16,7 @@
 // A wave owns one game: lanes enumerate legal actions with ballots + popcount prefixes, evaluate PUCT
 // scores for up to 2 children per lane and reduce with shuffles; there is no cross-wave communication.
 #include <hip/hip_runtime.h>
+#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 #include <math.h>
 #include <stdint.h>
 
@@ -70,8 +71,29 @@ struct Tree {
     int* n_nodes; int* n_edges; int* root_visits; double* root_W; float* root_init_value;
     int* path; int* path_len; int* leaf_kind; Packed* leaf_state; float* leaf_value;
     uint8_t* root_terminal; const uint8_t* active;
+    int* leaf_edge; int* leaf_parent;      // edge / node the pending leaf hangs from (written by select)
     double c_puct;
 };
+
+// Edge / node records are read with plain (L1 + L2 cached, normal retention) 16-byte loads.  This is safe next to the
+// device-scope atomics of the backup because a launch never loads an edge line before its own atomics on it have
+// completed: expand touches no edge record with a load, and a workgroup fence (= wait for the atomics' and stores'
+// L2 acknowledgement) separates it from the selection that follows.  Streaming (`nt`) loads measured 10 % slower:
+// they evict the upper tree levels from L2, which every simulation re-reads.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ Edge load_edge(const Edge* p) {
+    const u32x4* q = reinterpret_cast<const u32x4*>(p);
+    union U { u32x4 v[2]; Edge e; __device__ U() {} } u;
+    u.v[0] = q[0]; u.v[1] = q[1];
+    return u.e;
+}
+__device__ __forceinline__ Packed load_state(const Packed* p) {
+    const u32x4* q = reinterpret_cast<const u32x4*>(p);
+    union U { u32x4 v[2]; Packed s; __device__ U() {} } u;
+    u.v[0] = q[0]; u.v[1] = q[1];
+    return u.s;
+}
+constexpr uint32_t kPathFlip = 0x80000000u;    // path entry: edge index | flip bit (mover changes parent -> child)
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 __device__ __forceinline__ int wave_game() {
@@ -152,19 +174,32 @@ __global__ __launch_bounds__(kBlock) void tree_begin_kernel(Tree t) {
 
 // ---- select: one wave per game ---------------------------------------------------------------------------
 // Per level the only dependent load is the current node's edge run (32 B per lane, coalesced); the reduction is
-// DPP-based and the chosen edge is broadcast with v_readlane.  Node records are read once, for the leaf's parent.
-__device__ __forceinline__ void tree_select(const Tree& t, int g, int lane) {
+// DPP-based and the chosen edge is broadcast with v_readlane.  The chosen child's state record is fetched
+// speculatively next to the next level's edge run, so reaching the leaf costs no extra round trip.
+struct RootInfo { int ne, e0, visits, player; Packed state; };
+__device__ __forceinline__ RootInfo load_root_info(const Tree& t, int g) {
+    RootInfo r;
+    const Node* root = t.nodes + (size_t)g * t.node_cap;
+    r.state = load_state(&root->state);
+    r.ne = root->nedges; r.e0 = root->edge_begin;
+    r.visits = t.root_visits[g];
+    r.player = ((r.state.w0 >> 53) & 1) ? -1 : 1;
+    return r;
+}
+
+__device__ __forceinline__ void tree_select(const Tree& t, int g, int lane, const RootInfo& root) {
     if (t.root_terminal[g]) { if (lane == 0) t.leaf_kind[g] = kLeafInactive; return; }
     const Node* nodes = t.nodes + (size_t)g * t.node_cap;
     const Edge* edges = t.edges + (size_t)g * t.edge_cap;
     int* path = t.path + (size_t)g * t.path_cap;
     int node = 0, depth = 0;
-    int parent_n = t.root_visits[g];
-    int node_player = ((t.root_state[g].w0 >> 53) & 1) ? -1 : 1;
-    int ne = nodes[0].nedges, e0 = nodes[0].edge_begin;
+    int parent_n = root.visits;
+    int node_player = root.player;
+    int ne = root.ne, e0 = root.e0;
+    Packed node_state = root.state;
     int kind = kLeafInactive;
     float term_value = 0.f;
-    int leaf_action = 0;
+    int leaf_action = 0, leaf_edge = -1;
     while (ne > 0) {
         const double sq = sqrt((double)(parent_n > 1 ? parent_n : 1));
         double best = -INFINITY;
@@ -174,7 +209,7 @@ __device__ __forceinline__ void tree_select(const Tree& t, int g, int lane) {
         for (int r = 0; r < 2; ++r) {                          // up to 2 children per lane, ascending edge index
             const int k = r * kWave + lane;
             if (k < ne) {
-                mine[r] = edges[e0 + k];
+                mine[r] = load_edge(&edges[e0 + k]);
                 const int n = edge_n(mine[r].n_info);
                 double q = 0.0;
                 if (n > 0) {
@@ -197,8 +232,6 @@ __device__ __forceinline__ void tree_select(const Tree& t, int g, int lane) {
             chosen = kWave + __ffsll((unsigned long long)hi) - 1;
         }
         chosen = __builtin_amdgcn_readfirstlane(chosen);
-        if (lane == 0) path[depth] = e0 + chosen;
-        ++depth;
         const int src = chosen & 63;
         const bool up = chosen >= kWave;
         const uint32_t c_ni = (uint32_t)lzw::lane_bcast((int)(up ? mine[1].n_info : mine[0].n_info), src);
@@ -206,14 +239,19 @@ __device__ __forceinline__ void tree_select(const Tree& t, int g, int lane) {
         const int c_begin = lzw::lane_bcast(up ? mine[1].cbegin : mine[0].cbegin, src);
         const int c_meta = lzw::lane_bcast((int)(up ? mine[1].act : mine[0].act) | ((int)(up ? mine[1].cn : mine[0].cn) << 8), src);
         const uint8_t info = edge_info(c_ni);
+        const int child_player = (info & kInfoWhite) ? -1 : 1;
+        leaf_edge = e0 + chosen;
+        if (lane == 0) path[depth] = leaf_edge | (child_player != node_player ? (int)kPathFlip : 0);
+        ++depth;
         if (info & kInfoTerminal) {
             kind = kLeafTerminal;
             term_value = (float)((int)((info >> 2) & 3) - 1);
             break;
         }
         if (c_child < 0) { kind = kLeafExpand; leaf_action = c_meta & 0xFF; break; }
+        node_state = load_state(&nodes[c_child].state);     // in flight together with the next level's edges
         parent_n = edge_n(c_ni);
-        node_player = (info & kInfoWhite) ? -1 : 1;
+        node_player = child_player;
         node = c_child;
         e0 = c_begin;
         ne = c_meta >> 8;
@@ -223,8 +261,10 @@ __device__ __forceinline__ void tree_select(const Tree& t, int g, int lane) {
         t.path_len[g] = depth;
         t.leaf_kind[g] = kind;
         t.leaf_value[g] = term_value;
+        t.leaf_edge[g] = leaf_edge;
+        t.leaf_parent[g] = node;
         if (kind == kLeafExpand) {
-            State leaf = unpack(nodes[node].state);
+            State leaf = unpack(node_state);
             int kd, p, q2, ex;
             index_to_code(leaf.phase, leaf_action, kd, p, q2, ex);
             apply(leaf, kd, p, q2);
@@ -236,22 +276,46 @@ __device__ __forceinline__ void tree_select(const Tree& t, int g, int lane) {
 __global__ __launch_bounds__(kBlock) void tree_select_kernel(Tree t) {
     const int g = wave_game();
     if (g >= t.B) return;
-    tree_select(t, g, lane_id());
+    tree_select(t, g, lane_id(), load_root_info(t, g));
 }
 
 // ---- expand (+ backup): one wave per game -----------------------------------------------------------------
 // priors come either from the three 36-wide log-prob heads (production) or from a dense 220-d prior row
 // (injected evaluator, parity runs).  IS_ROOT: no backup, optional noise mix.
+// Every load that does not depend on another load is issued up front (leaf record, evaluator outputs, allocation
+// counters, the path, the root's statistics); the backup is fire-and-forget device atomics (N += 1 on the count
+// field, W += v in double -- one addition per edge and simulation, so bit-identical to a read-modify-write), the
+// signs come from the flip bits select left in the path entries.  Dependent round trips: 1 (was 5).
 template <bool IS_ROOT>
 __device__ __forceinline__ void tree_expand(const Tree& t, int g, int lane, const float* __restrict__ lp1,
                                             const float* __restrict__ lp2, const float* __restrict__ lpm,
                                             const float* __restrict__ priors220, const float* __restrict__ values,
-                                            const float* __restrict__ noise, int noise_stride, float epsilon) {
+                                            const float* __restrict__ noise, int noise_stride, float epsilon,
+                                            RootInfo* root_after = nullptr) {
     const int kind = t.leaf_kind[g];
-    if (kind == kLeafInactive) return;
     Node* nodes = t.nodes + (size_t)g * t.node_cap;
     Edge* edges = t.edges + (size_t)g * t.edge_cap;
     const int* path = t.path + (size_t)g * t.path_cap;
+    // ---- independent loads, all in flight together ----
+    RootInfo root{};
+    int plen_ld = 0, leaf_edge = -1, leaf_parent = 0, nn_ld = 0, ne_ld = 0, path_entry = 0;
+    double root_w = 0.0;
+    float leaf_value_ld = 0.f, value_ld = 0.f;
+    Packed leaf_packed = t.leaf_state[g];
+    if (!IS_ROOT) {
+        root = load_root_info(t, g);
+        plen_ld = t.path_len[g];
+        leaf_edge = t.leaf_edge[g];
+        leaf_parent = t.leaf_parent[g];
+        path_entry = lane < t.path_cap ? path[lane] : 0;       // first 64 entries
+        root_w = t.root_W[g];
+        leaf_value_ld = t.leaf_value[g];
+    }
+    nn_ld = t.n_nodes[g];
+    ne_ld = t.n_edges[g];
+    value_ld = values[g];
+    if (root_after != nullptr) *root_after = root;
+    if (kind == kLeafInactive) return;
     if (kind == kLeafReusedRoot) {
         // portable_mcts.py:302-317 / :617-621: a root kept by advance_root gets a fresh noise mix on its
         // existing priors, renormalised by max(sum, 1e-8); nothing else happens before the first selection.
@@ -284,13 +348,13 @@ __device__ __forceinline__ void tree_expand(const Tree& t, int g, int lane, cons
         }
         return;
     }
-    const int plen = IS_ROOT ? 0 : t.path_len[g];
+    const int plen = IS_ROOT ? 0 : plen_ld;
     double backup_value = 0.0;
 
     if (kind == kLeafTerminal) {
-        backup_value = (double)t.leaf_value[g];
+        backup_value = (double)leaf_value_ld;
     } else {
-        const State s = unpack(t.leaf_state[g]);
+        const State s = unpack(leaf_packed);
         const Legal L = legal_actions(s, /*fallback_forced=*/0);     // python semantics (move_generator.py:24-70)
         const int n = legal_count(L);
         if (n == 0) {
@@ -298,11 +362,7 @@ __device__ __forceinline__ void tree_expand(const Tree& t, int g, int lane, cons
             backup_value = -1.0;
             if (lane == 0) {
                 if (IS_ROOT) { nodes[0].nedges = 0; t.root_terminal[g] = 1; t.root_init_value[g] = -1.f; }
-                else {
-                    Edge& e = edges[path[plen - 1]];
-                    const uint32_t info = (edge_info(e.n_info) & kInfoWhite) | kInfoTerminal | (0u << 2);
-                    e.n_info = (e.n_info & 0xFFFFFFu) | (info << 24);
-                }
+                else atomicOr(&edges[leaf_edge].n_info, (uint32_t)kInfoTerminal << 24);   // value bits stay 0 (= -1)
             }
         } else {
             // gather per-lane logits / priors of the legal actions in ascending index order
@@ -311,6 +371,12 @@ __device__ __forceinline__ void tree_expand(const Tree& t, int g, int lane, cons
             if (heads && lane < kCells) {
                 h1 = lp1[(size_t)g * 36 + lane]; h2 = lp2[(size_t)g * 36 + lane]; hm = lpm[(size_t)g * 36 + lane];
             }
+            // Phase A, per 64 action indices (skipped when none of them is legal): legality, compact slot, logit.
+            // The legal actions are then compacted through LDS so that Phase B (child state, terminal test, edge
+            // record -- the expensive per-action work) runs once over min(n, 64) lanes instead of four times.
+            __shared__ float s_val[kWavesPerBlock][80];
+            __shared__ int s_act[kWavesPerBlock][80];
+            const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
             float val[4]; int slot[4]; bool lg[4];
             int base = 0;
             float mx = -INFINITY;
@@ -318,7 +384,9 @@ __device__ __forceinline__ void tree_expand(const Tree& t, int g, int lane, cons
             for (int it = 0; it < 4; ++it) {
                 const int a = it * kWave + lane;
                 lg[it] = a < 217 && legal_bit(L, a);
+                val[it] = 0.f; slot[it] = 0;
                 const uint64_t bal = __ballot(lg[it]);
+                if (bal == 0) continue;                         // wave-uniform
                 slot[it] = base + __popcll(bal & ((1ull << lane) - 1ull));
                 base += __popcll(bal);
                 int from = 0, dest = 0, cell = 0;
@@ -345,48 +413,55 @@ __device__ __forceinline__ void tree_expand(const Tree& t, int g, int lane, cons
 #pragma unroll
                 for (int it = 0; it < 4; ++it) val[it] = val[it] / sum;
             }
-            // root noise mix (portable_mcts.py:451-459), then renormalise with a sequential fp32 sum
+            // root noise mix (portable_mcts.py:451-459)
             if (IS_ROOT && noise != nullptr && n > 1) {
                 const float keep = (float)(1.0 - (double)epsilon);
 #pragma unroll
                 for (int it = 0; it < 4; ++it)
                     if (lg[it]) val[it] = keep * val[it] + epsilon * noise[(size_t)g * noise_stride + slot[it]];
             }
-            // sequential fp32 sum in ascending action order (== the oracle's order), kept in scalar control flow:
-            // readlane of each legal lane's value, no LDS round trip
-            float psum = 0.f;
+            // compaction: lane k (and k + 64) takes over the k-th legal action in ascending index order
 #pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                uint64_t m = __ballot(lg[it]);
-                while (m) {                                     // scalar loop: s_ff1 + v_readlane + one add
-                    const int l = __builtin_amdgcn_readfirstlane(__ffsll((unsigned long long)m) - 1);
-                    psum += lzw::lane_bcast(val[it], l);
-                    m &= m - 1;
-                }
+            for (int it = 0; it < 4; ++it)
+                if (lg[it]) { s_val[wv][slot[it]] = val[it]; s_act[wv][slot[it]] = it * kWave + lane; }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            float cval[2]; int cact[2];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int k = r * kWave + lane;
+                cval[r] = k < n ? s_val[wv][k] : 0.f;
+                cact[r] = k < n ? s_act[wv][k] : 0;
             }
+            // renormalise with a sequential fp32 sum in ascending action order (== the oracle's order): scalar loop
+            // of v_readlane + add, no further LDS round trip
+            float psum = 0.f;
+            for (int k = 0; k < n; ++k) psum += lzw::lane_bcast(k < kWave ? cval[0] : cval[1], k & 63);
             const bool bad = !(psum > 0.f) || !isfinite(psum);
             // node + edge allocation (per-game bump counters, worst-case sized regions)
             int node_id = 0, e0 = 0;
             if (lane == 0) {
-                if (IS_ROOT) { node_id = 0; e0 = t.n_edges[g]; t.n_edges[g] = e0 + n; }
+                if (IS_ROOT) { node_id = 0; e0 = ne_ld; t.n_edges[g] = e0 + n; }
                 else {
-                    node_id = t.n_nodes[g]; t.n_nodes[g] = node_id + 1;
-                    e0 = t.n_edges[g]; t.n_edges[g] = e0 + n;
-                    Edge& in = edges[path[plen - 1]];
+                    node_id = nn_ld; t.n_nodes[g] = node_id + 1;
+                    e0 = ne_ld; t.n_edges[g] = e0 + n;
+                    Edge& in = edges[leaf_edge];
                     in.child = node_id; in.cbegin = e0; in.cn = (uint8_t)n;
-                    nodes[node_id].state = t.leaf_state[g];
-                    nodes[node_id].parent = (int)in.owner;
+                    nodes[node_id].state = leaf_packed;
+                    nodes[node_id].parent = leaf_parent;
                 }
                 nodes[node_id].edge_begin = e0;
                 nodes[node_id].nedges = n;
-                if (IS_ROOT) t.root_init_value[g] = values[g];
+                if (IS_ROOT) t.root_init_value[g] = value_ld;
             }
             e0 = __builtin_amdgcn_readfirstlane(e0);
             node_id = __builtin_amdgcn_readfirstlane(node_id);
-#pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                if (!lg[it]) continue;
-                const int a = it * kWave + lane;
+            // Phase B: one pass (two only when a movement position has more than 64 legal moves)
+            for (int r = 0; r < (n > kWave ? 2 : 1); ++r) {
+                const int k = r * kWave + lane;
+                if (k >= n) continue;
+                const int a = r == 0 ? cact[0] : cact[1];
                 State c = s;
                 int kd, p, q2, ex;
                 index_to_code(s.phase, a, kd, p, q2, ex);
@@ -398,7 +473,7 @@ __device__ __forceinline__ void tree_expand(const Tree& t, int g, int lane, cons
                 }
                 Edge rec;
                 rec.W = 0.0;
-                rec.P = bad ? (1.0f / (float)n) : (val[it] / psum);
+                rec.P = bad ? (1.0f / (float)n) : ((r == 0 ? cval[0] : cval[1]) / psum);
                 rec.n_info = (uint32_t)info << 24;
                 rec.child = -1;
                 rec.cbegin = 0;
@@ -406,41 +481,37 @@ __device__ __forceinline__ void tree_expand(const Tree& t, int g, int lane, cons
                 rec.cn = 0;
                 rec.owner = (uint16_t)node_id;
                 rec.pad[0] = rec.pad[1] = rec.pad[2] = rec.pad[3] = 0;
-                edges[e0 + slot[it]] = rec;
+                edges[e0 + k] = rec;
             }
-            backup_value = (double)values[g];
+            backup_value = (double)value_ld;
         }
     }
     if (IS_ROOT) return;
-    __threadfence_block();   // lane 0's edge / node stores above are visible to the other lanes' loads below
     // ---- backup along the path (portable_mcts.py:123-138), one lane per path entry ----
     // value added at offset j = v0 * (-1)^(#mover changes at offsets > j); the root gets the fully flipped value.
     if (plen > 0) {
-        const int root_player = ((nodes[0].state.w0 >> 53) & 1) ? -1 : 1;
         int flips_above = 0;                                    // mover changes at offsets above the current chunk
         for (int hi = plen; hi > 0; hi -= kWave) {
             const int lo = hi > kWave ? hi - kWave : 0;
             const int j = lo + lane;
             const bool in = j < hi;
-            Edge* e = in ? &edges[path[j]] : nullptr;
-            uint32_t ni = in ? e->n_info : 0u;
-            const int child_player = (edge_info(ni) & kInfoWhite) ? -1 : 1;
-            int parent_player = root_player;
-            if (in && j > 0) parent_player = (edge_info(edges[path[j - 1]].n_info) & kInfoWhite) ? -1 : 1;
-            const bool flip = in && parent_player != child_player;
-            const uint64_t F = __ballot(flip);
+            const uint32_t pe = !in ? 0u : (lo == 0 ? (uint32_t)path_entry : (uint32_t)path[j]);
+            const uint64_t F = __ballot(in && (pe & kPathFlip) != 0u);
             const int above = in ? __popcll(F >> (lane + 1)) : 0;   // flips at offsets > j inside the chunk
             if (in) {
+                Edge* e = &edges[pe & ~kPathFlip];
                 const double v = ((above + flips_above) & 1) ? -backup_value : backup_value;
-                e->n_info = ni + 1u;
-                e->W += v;
+                atomicAdd(&e->n_info, 1u);
+                unsafeAtomicAdd(&e->W, v);
             }
             flips_above += __popcll(F);
         }
+        root.visits += 1;
         if (lane == 0) {
-            t.root_visits[g] += 1;
-            t.root_W[g] += (flips_above & 1) ? -backup_value : backup_value;
+            t.root_visits[g] = root.visits;
+            t.root_W[g] = root_w + ((flips_above & 1) ? -backup_value : backup_value);
         }
+        if (root_after != nullptr) root_after->visits = root.visits;
     }
 }
 
@@ -469,9 +540,11 @@ __global__ __launch_bounds__(kBlock) void tree_expand_select_kernel(Tree t, cons
     const int g = wave_game();
     if (g >= t.B) return;
     const int lane = lane_id();
-    tree_expand<IS_ROOT>(t, g, lane, lp1, lp2, lpm, nullptr, values, noise, noise_stride, epsilon);
+    RootInfo root;
+    tree_expand<IS_ROOT>(t, g, lane, lp1, lp2, lpm, nullptr, values, noise, noise_stride, epsilon, &root);
     __threadfence_block();
-    tree_select(t, g, lane);
+    if (IS_ROOT) root = load_root_info(t, g);                  // the root record itself was just written
+    tree_select(t, g, lane, root);
 }
 
 // ---- advance (a21): promote the played child to root, keep its subtree ---------------------------------------
@@ -787,6 +860,7 @@ Tree make_tree(const LzTreeDesc* d) {
     t.path = d->path; t.path_len = d->path_len; t.leaf_kind = d->leaf_kind;
     t.leaf_state = reinterpret_cast<Packed*>(d->leaf_state); t.leaf_value = d->leaf_value;
     t.root_terminal = d->root_terminal; t.active = d->active;
+    t.leaf_edge = d->leaf_edge; t.leaf_parent = d->leaf_parent;
     t.c_puct = d->exploration_weight;
     return t;
 }
@@ -794,7 +868,7 @@ bool tree_ok(const LzTreeDesc* d) {
     return d && d->num_games >= 0 && d->node_cap >= 2 && d->edge_cap >= kMaxChildren && d->path_cap >= 3 &&
            d->root_state && d->nodes && d->edges && d->n_nodes && d->n_edges &&
            d->root_visits && d->root_w && d->root_init_value && d->path && d->path_len && d->leaf_kind &&
-           d->leaf_state && d->leaf_value && d->root_terminal;
+           d->leaf_state && d->leaf_value && d->root_terminal && d->leaf_edge && d->leaf_parent;
 }
 inline unsigned gw(int64_t n) { return (unsigned)((n + kWavesPerBlock - 1) / kWavesPerBlock); }
 inline unsigned gt(int64_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }

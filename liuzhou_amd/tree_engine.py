@@ -36,7 +36,7 @@ class LzTreeDesc(C.Structure):
                [(n, C.c_void_p) for n in (
                    "root_state", "nodes", "edges", "n_nodes", "n_edges", "root_visits", "root_w",
                    "root_init_value", "path", "path_len", "leaf_kind", "leaf_state", "leaf_value", "root_terminal",
-                   "active")]
+                   "active", "leaf_edge", "leaf_parent")]
 
 
 REUSE_EDGES_PER_NODE = 40      # arena sizing for kept subtrees (average fan-out is ~25; overflow drops the subtree)
@@ -67,6 +67,7 @@ class TreeEngine:
             "path": z((B * self.path_cap,), torch.int32), "path_len": z((B,), torch.int32),
             "leaf_kind": z((B,), torch.int32), "leaf_state": z((B, 4), torch.int64), "leaf_value": z((B,), torch.float32),
             "root_terminal": z((B,), torch.uint8), "active": torch.ones((B,), dtype=torch.uint8, device=dev),
+            "leaf_edge": z((B,), torch.int32), "leaf_parent": z((B,), torch.int32),
         }
         d = LzTreeDesc()
         d.num_games, d.node_cap, d.edge_cap, d.path_cap = B, self.node_cap, self.edge_cap, self.path_cap
