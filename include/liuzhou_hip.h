@@ -291,6 +291,26 @@ LZ_API int lz_tree_search_continue(const LzTreeDesc* tree, const LzNetDesc* net,
                                    float* log_p1, float* log_p2, float* log_pmc, float* values, const float* noise,
                                    int64_t noise_stride, float epsilon, void* stream);
 
+/* ---- training loss (the step right after the path) --------------------- */
+
+/* Fused forward + backward of the reference's training loss (v1/python/train_bridge.py:330-375):
+ *   policy: build_combined_logits -> masked_log_softmax -> batched_policy_loss (src/policy_batch.py:95-189),
+ *   value : two-hot bucket cross entropy on clamp((1-alpha)*value + alpha*soft, -1, 1) (src/neural_network.py:176-198),
+ *   WDL auxiliary term reported only (its weight is 0 in the reference).
+ * Inputs float32: head outputs log_p1/log_p2/log_pmc [B,36], value_logits [B,101]; legal_mask uint8 [B,220];
+ * policy_target [B,220]; value_target / soft_value_target [B]; policy_weight_sum = device scalar
+ * sum_b (|value_b| < 1e-8 ? policy_draw_weight : 1).
+ * Outputs: terms [B,4] = {KL_b, weight_b, bucket CE_b, WDL aux_b}  (loss = sum(KL*w)/(sum(w)+1e-8) + mean(CE));
+ * gradients of grad_scale * loss with respect to the four head outputs (same shapes as the inputs). */
+LZ_API int lz_policy_value_loss_fwd_bwd(const float* log_p1, const float* log_p2, const float* log_pmc,
+                                        const float* value_logits, const uint8_t* legal_mask,
+                                        const float* policy_target, const float* value_target,
+                                        const float* soft_value_target, int64_t batch, float soft_label_alpha,
+                                        float anti_draw_penalty, float policy_draw_weight,
+                                        const float* policy_weight_sum, float grad_scale, float* terms,
+                                        float* grad_log_p1, float* grad_log_p2, float* grad_log_pmc,
+                                        float* grad_value_logits, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

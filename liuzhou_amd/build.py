@@ -8,7 +8,7 @@ import subprocess
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libliuzhou_hip.so")
-SOURCES = ("lz_ops.hip", "lz_engine.hip", "lz_net.hip")
+SOURCES = ("lz_ops.hip", "lz_engine.hip", "lz_net.hip", "lz_train.hip")
 HEADERS = ("lz_rules.h", "lz_soa.h", os.path.join("..", "..", "include", "liuzhou_hip.h"))
 
 

@@ -17,6 +17,7 @@ Fixture groups:
   g6_root_puct.npz  root bandit allocation
   g7_ops.npz        pack / finalize / self-play-step / trajectory-finalize op vectors
   g8_selfplay.npz   4-game root-PUCT self-play trace of the reference v1 runner (CPU)
+  g11_loss.npz      training-loss values and head gradients from the reference's own loss functions
   g10_tree_selfplay.npz  full-tree self-play traces of the reference portable runner (subtree reuse on every move)
   g9_net.npz        network outputs for seeded weights (tiny / 6x64 / 10x128)
 """
@@ -603,6 +604,56 @@ def gen_tree_selfplay():
 
 
 # --------------------------------------------------------------------------------------------
+# G11: training loss (values + autograd gradients of the reference's functions)
+# --------------------------------------------------------------------------------------------
+def gen_loss():
+    from src.policy_batch import build_combined_logits, masked_log_softmax, batched_policy_loss
+    from src.neural_network import scalar_to_bucket_twohot, scalar_to_wdl
+    from v1.python.train_bridge import _bucket_logits_to_wdl_probs
+    g = torch.Generator().manual_seed(41)
+    B = 48
+    raw1 = torch.randn((B, 36), generator=g); raw2 = torch.randn((B, 36), generator=g); raw3 = torch.randn((B, 36), generator=g)
+    vlog = torch.randn((B, 101), generator=g) * 2
+    mask = torch.rand((B, 220), generator=g) < 0.12
+    comb_valid = torch.isfinite(build_combined_logits(raw1, raw2, raw3, 6))
+    mask &= comb_valid
+    mask[:, 0] = True
+    mask[5] = False                       # a row without any legal action
+    mask[6] = False; mask[6, 216] = True  # only the auxiliary action
+    target = torch.rand((B, 220), generator=g) * mask
+    target = target / target.sum(1, keepdim=True).clamp_min(1e-8)
+    target[7] = 0                          # empty target row
+    value = torch.randint(-1, 2, (B,), generator=g).float()
+    value[8] = 0.37; value[9] = -0.81      # non-integer values (soft-value mixing inputs)
+    soft = torch.rand((B,), generator=g) * 2 - 1
+    out = dict(raw1=raw1.numpy(), raw2=raw2.numpy(), raw3=raw3.numpy(), value_logits=vlog.numpy(),
+               mask=mask.numpy(), target=target.numpy(), value=value.numpy(), soft=soft.numpy())
+    for tag, alpha, anti, dw in (("a", 0.0, 0.0, 1.0), ("b", 0.35, -0.15, 0.4)):
+        l1 = torch.log_softmax(raw1, 1).requires_grad_(True); l2 = torch.log_softmax(raw2, 1).requires_grad_(True)
+        l3 = torch.log_softmax(raw3, 1).requires_grad_(True); vl = vlog.clone().requires_grad_(True)
+        raw_v = value.view(-1, 1); bv = raw_v
+        draw = raw_v.abs().lt(1e-8)
+        if abs(anti) > 1e-9:
+            bv = bv.clone(); bv[draw] = anti
+        mixed = torch.clamp((1.0 - alpha) * bv + alpha * soft.view(-1, 1), -1.0, 1.0)
+        tgt = scalar_to_bucket_twohot(mixed, num_bins=101).float()
+        vlp = torch.log_softmax(vl.float(), dim=-1)
+        bucket = -(tgt * vlp).sum(-1).mean()
+        wdl_aux = -(scalar_to_wdl(raw_v).float() * torch.log(_bucket_logits_to_wdl_probs(vl).clamp_min(1e-8))).sum(-1)
+        comb = build_combined_logits(l1, l2, l3, board_size=6)
+        logp = masked_log_softmax(comb, mask, dim=1)
+        pol = batched_policy_loss(logp, target, mask, raw_v, dw)
+        loss = pol + bucket
+        loss.backward()
+        out.update({f"{tag}_params": np.array([alpha, anti, dw], np.float32), f"{tag}_loss": loss.detach().numpy(),
+                    f"{tag}_policy_loss": pol.detach().numpy(), f"{tag}_bucket_loss": bucket.detach().numpy(),
+                    f"{tag}_wdl_aux": wdl_aux.detach().numpy(), f"{tag}_g1": l1.grad.numpy(), f"{tag}_g2": l2.grad.numpy(),
+                    f"{tag}_g3": l3.grad.numpy(), f"{tag}_gv": vl.grad.numpy()})
+        print(f"[g11/{tag}] loss={float(loss):.6f} policy={float(pol):.6f} bucket={float(bucket):.6f}")
+    np.savez_compressed(os.path.join(OUT, "g11_loss.npz"), **out)
+
+
+# --------------------------------------------------------------------------------------------
 # G9: network
 # --------------------------------------------------------------------------------------------
 def gen_net(chosen):
@@ -659,6 +710,8 @@ def main():
         gen_net(chosen)
     if not which or "g10" in which:
         gen_tree_selfplay()
+    if not which or "g11" in which:
+        gen_loss()
     for f in sorted(os.listdir(OUT)):
         print(f"  {f}: {os.path.getsize(os.path.join(OUT, f)) / 1024:.1f} KiB")
 

@@ -1,0 +1,101 @@
+"""GPU: fused training-loss kernel vs the oracle / the reference's golden values, and the trainer step."""
+import numpy as np
+import pytest
+import torch
+
+from tests.golden_utils import load
+from tests.test_oracle_loss import _inputs
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+
+
+def test_fused_loss_matches_reference_golden_values_and_gradients():
+    _need_gpu()
+    from liuzhou_amd.train_loss import fused_policy_value_loss
+    z = load("g11_loss.npz")
+    for tag in ("a", "b"):
+        alpha, anti, dw = (float(x) for x in z[f"{tag}_params"])
+        l1, l2, l3, vl, mask, target, value, soft = _inputs(z)
+        d = [x.detach().to(DEV).requires_grad_(True) for x in (l1, l2, l3, vl)]
+        loss, parts = fused_policy_value_loss(*d, mask.to(DEV), target.to(DEV), value.to(DEV), soft.to(DEV),
+                                              soft_label_alpha=alpha, anti_draw_penalty=anti, policy_draw_weight=dw)
+        (loss * 3.0).backward()                       # an upstream factor, like the AMP loss scale
+        np.testing.assert_allclose(loss.item(), z[f"{tag}_loss"], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(parts["policy_loss"].item(), z[f"{tag}_policy_loss"], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(parts["bucket_value_loss"].item(), z[f"{tag}_bucket_loss"], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(parts["wdl_aux_loss"].item(), z[f"{tag}_wdl_aux"].mean(), rtol=1e-5, atol=1e-5)
+        for g, key in zip(d, ("g1", "g2", "g3", "gv")):
+            np.testing.assert_allclose(g.grad.cpu().numpy() / 3.0, z[f"{tag}_{key}"], rtol=1e-4, atol=1e-6)
+
+
+def test_fused_loss_matches_oracle_on_a_large_random_batch_in_half_precision_inputs():
+    _need_gpu()
+    from liuzhou_amd.train_loss import fused_policy_value_loss
+    from oracle.loss_oracle import policy_value_loss, combined_logits
+    g = torch.Generator().manual_seed(5)
+    B = 1537                                           # not a multiple of the 4 samples per workgroup
+    raws = [torch.randn((B, 36), generator=g) for _ in range(3)]
+    heads = [torch.log_softmax(r, 1) for r in raws]
+    vl = (torch.randn((B, 101), generator=g) * 3).half().float()       # exactly representable in fp16
+    mask = (torch.rand((B, 220), generator=g) < 0.15) & torch.isfinite(combined_logits(*heads))
+    mask[:, 216] |= torch.rand(B, generator=g) < 0.1
+    target = torch.rand((B, 220), generator=g) * mask
+    target = target / target.sum(1, keepdim=True).clamp_min(1e-8)
+    value = torch.randint(-1, 2, (B,), generator=g).float()
+    soft = torch.rand(B, generator=g) * 2 - 1
+    cpu = [h.clone().requires_grad_(True) for h in heads] + [vl.clone().requires_grad_(True)]
+    want = policy_value_loss(*cpu, mask, target, value, soft, soft_label_alpha=0.25, anti_draw_penalty=0.0,
+                             policy_draw_weight=0.5)
+    want["loss"].backward()
+    dev = [h.to(DEV).requires_grad_(True) for h in heads] + [vl.to(DEV).half().requires_grad_(True)]
+    loss, parts = fused_policy_value_loss(*dev, mask.to(DEV), target.to(DEV), value.to(DEV), soft.to(DEV),
+                                          soft_label_alpha=0.25, policy_draw_weight=0.5)
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), want["loss"].item(), rtol=2e-5)
+    assert dev[3].grad.dtype == torch.float16
+    for a, b in zip(dev[:3], cpu[:3]):
+        np.testing.assert_allclose(a.grad.cpu().numpy(), b.grad.numpy(), rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(dev[3].grad.float().cpu().numpy(), cpu[3].grad.numpy(), rtol=2e-3, atol=1e-7)
+
+
+def test_trainer_step_learns_and_reports_the_reference_metrics(tmp_path):
+    _need_gpu()
+    from liuzhou_amd.net import ChessNet, MODEL_CONFIGS, stable_resnet_init
+    from liuzhou_amd.train_bridge import train_network_from_tensors
+    from liuzhou_amd.self_play_gpu_runner import self_play_v1_gpu
+    torch.manual_seed(0)
+    model = ChessNet(**MODEL_CONFIGS["b6c64"])
+    stable_resnet_init(model, 20260314)
+    model.to(DEV).eval()
+    from liuzhou_amd.net_hip import FusedNet
+    batch, stats = self_play_v1_gpu(FusedNet(model), num_games=64, mcts_simulations=16, temperature_init=1.0,
+                                    temperature_final=0.1, temperature_threshold=10, exploration_weight=1.0,
+                                    device=DEV, max_game_plies=40, concurrent_games=64)
+    assert batch.state_tensors.is_cuda                 # trained where it was produced: no CPU round trip
+    opt_path = str(tmp_path / "adam.pt")
+    model, m1 = train_network_from_tensors(model, batch, batch_size=256, epochs=2, lr=2e-3, device=DEV, use_amp=True,
+                                           warmup_steps=4, soft_label_alpha=0.3, policy_draw_weight=0.5,
+                                           optimizer_state_path=opt_path)
+    assert [e["epoch"] for e in m1["epoch_stats"]] == [1, 2]
+    e1, e2 = m1["epoch_stats"]
+    assert e2["avg_loss"] < e1["avg_loss"]
+    # batches whose scaled gradients overflow while the AMP scale settles are skipped and not counted, as in the reference
+    assert e1["samples"] + 256 * e1["skipped_non_finite_grad_batches"] == batch.num_samples == 64 * 40
+    assert e2["skipped_non_finite_grad_batches"] <= e1["skipped_non_finite_grad_batches"]
+    for key in ("avg_policy_loss", "avg_value_loss", "avg_value_bucket_loss", "avg_wdl_aux_loss", "valid_policy_samples",
+                "policy_weight_sum", "soft_alpha", "avg_soft_abs", "avg_mix_abs", "synced_batch_count",
+                "skipped_non_finite_loss_batches", "skipped_non_finite_grad_batches", "filtered_non_finite_samples"):
+        assert key in e1
+    for key in ("num_samples", "num_samples_after_filter", "optimizer_loaded", "optimizer_lr_start", "optimizer_lr_final",
+                "warmup_steps", "total_train_steps", "timing", "wdl_aux_loss_weight"):
+        assert key in m1
+    assert m1["optimizer_loaded"] is False and m1["warmup_steps"] == 4
+    model, m2 = train_network_from_tensors(model, batch, batch_size=256, epochs=1, lr=1e-3, device=DEV,
+                                           optimizer_state_path=opt_path)
+    assert m2["optimizer_loaded"] is True and m2["epoch_stats"][0]["avg_loss"] < e1["avg_loss"]
