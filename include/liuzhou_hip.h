@@ -311,6 +311,22 @@ LZ_API int lz_policy_value_loss_fwd_bwd(const float* log_p1, const float* log_p2
                                         float* grad_log_p1, float* grad_log_p2, float* grad_log_pmc,
                                         float* grad_value_logits, void* stream);
 
+/* ---- compact trajectory records: wire format of the per-iteration gather ---- */
+
+/* A row of the 5-tensor trajectory contract (v1/python/trajectory_buffer.py:11-33; 2 692 B) as an exact 360-byte
+ * record: u64[4] {own | phase<<36, opp, own-marked, opp-marked}, u32[7] legal bits, f32[72] policy of the legal
+ * actions in ascending index order, f32 value, f32 soft value, 4 B pad.  unpack(pack(x)) reproduces every byte.
+ * `not_representable` (device int32, add-only) counts rows whose planes are not 0/1, whose policy is non-zero off the
+ * legal set, or that have more than 72 legal actions -- never the case for self-play output. */
+#define LZ_TRAJECTORY_RECORD_BYTES 360
+LZ_API int lz_pack_trajectory_rows(const float* state_tensors, const uint8_t* legal_masks,
+                                   const float* policy_targets, const float* value_targets,
+                                   const float* soft_value_targets, int64_t rows, void* records,
+                                   int32_t* not_representable, void* stream);
+LZ_API int lz_unpack_trajectory_rows(const void* records, int64_t rows, float* state_tensors, uint8_t* legal_masks,
+                                     float* policy_targets, float* value_targets, float* soft_value_targets,
+                                     void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -189,3 +189,137 @@ extern "C" int lz_policy_value_loss_fwd_bwd(const float* log_p1, const float* lo
                        grad_value_logits);
     return hipGetLastError() == hipSuccess ? LZ_OK : LZ_ERR_LAUNCH;
 }
+
+// ---- compact trajectory records (wire format of the per-iteration gather) ----------------
+// A trajectory row of the reference contract is 2 692 B (f32[11,6,6] planes + bool[220] + f32[220] + 2 f32); its
+// information content is far smaller: the planes are 0/1 (4 bitboards + a phase), the policy is non-zero only on the
+// <= 72 legal entries.  Record = 360 B, exact (pack -> unpack reproduces every byte of the five tensors):
+//   u64 w[4]   own | phase << 36, opp, own-marked, opp-marked        (planes 0..3 as bits, planes 4..10 one-hot)
+//   u32 m[7]   legal mask bits 0..219
+//   f32 p[72]  policy of the legal actions in ascending index order
+//   f32 v[2]   value target, soft value target            (+ 4 B pad)
+namespace {
+constexpr int kRecBytes = 360;
+
+__global__ __launch_bounds__(kWave * kWavesPerBlock) void pack_rows_kernel(
+    const float* __restrict__ planes, const uint8_t* __restrict__ legal, const float* __restrict__ policy,
+    const float* __restrict__ value, const float* __restrict__ soft, int64_t n, uint8_t* __restrict__ out,
+    int* __restrict__ bad) {
+    const int lane = threadIdx.x & 63;
+    const int64_t s = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (s >= n) return;
+    uint8_t* rec = out + s * kRecBytes;
+    const float* pl = planes + s * 396;
+    uint64_t w[4];
+    bool ok = true;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const float x = lane < 36 ? pl[p * 36 + lane] : 0.f;
+        ok = ok && (x == 0.f || x == 1.f);
+        w[p] = __ballot(x != 0.f);
+    }
+    int phase = 0;
+#pragma unroll
+    for (int ph = 1; ph <= 7; ++ph) {
+        const float x = lane < 36 ? pl[(3 + ph) * 36 + lane] : 0.f;
+        const uint64_t b = __ballot(lane < 36 && x != 0.f);
+        ok = ok && (x == 0.f || x == 1.f) && (b == 0 || b == 0xFFFFFFFFFull);
+        if (b) { ok = ok && phase == 0; phase = ph; }
+    }
+    uint32_t mw[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int base = 0;
+    float* pv = reinterpret_cast<float*>(rec + 60);
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int a = it * kWave + lane;
+        const bool in = a < kTotal;
+        const bool lg = in && legal[s * kTotal + (in ? a : 0)] != 0;
+        const float p = in ? policy[s * kTotal + a] : 0.f;
+        ok = ok && (lg || p == 0.f);
+        const uint64_t bal = __ballot(lg);
+        mw[2 * it] = (uint32_t)bal; mw[2 * it + 1] = (uint32_t)(bal >> 32);
+        const int slot = base + __popcll(bal & ((1ull << lane) - 1ull));
+        if (lg && slot < 72) pv[slot] = p;
+        base += __popcll(bal);
+    }
+    ok = ok && base <= 72;
+    for (int k = base + lane; k < 72; k += kWave) pv[k] = 0.f;
+    if (lane == 0) {
+        uint64_t* wq = reinterpret_cast<uint64_t*>(rec);
+        wq[0] = w[0] | ((uint64_t)phase << 36); wq[1] = w[1]; wq[2] = w[2]; wq[3] = w[3];
+        uint32_t* mq = reinterpret_cast<uint32_t*>(rec + 32);
+#pragma unroll
+        for (int k = 0; k < 7; ++k) mq[k] = mw[k];
+        float* vq = reinterpret_cast<float*>(rec + 348);
+        vq[0] = value[s]; vq[1] = soft[s]; vq[2] = 0.f;
+    }
+    if (__ballot(!ok) != 0 && lane == 0) atomicAdd(bad, 1);     // row not representable (never for self-play output)
+}
+
+__global__ __launch_bounds__(kWave * kWavesPerBlock) void unpack_rows_kernel(
+    const uint8_t* __restrict__ in, int64_t n, float* __restrict__ planes, uint8_t* __restrict__ legal,
+    float* __restrict__ policy, float* __restrict__ value, float* __restrict__ soft) {
+    const int lane = threadIdx.x & 63;
+    const int64_t s = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (s >= n) return;
+    const uint8_t* rec = in + s * kRecBytes;
+    const uint64_t* wq = reinterpret_cast<const uint64_t*>(rec);
+    const uint32_t* mq = reinterpret_cast<const uint32_t*>(rec + 32);
+    const float* pv = reinterpret_cast<const float*>(rec + 60);
+    const uint64_t w0 = wq[0];
+    const int phase = (int)((w0 >> 36) & 7);
+    float* pl = planes + s * 396;
+    for (int j = lane; j < 396; j += kWave) {
+        const int p = j / 36, c = j - p * 36;
+        const bool bit = p < 4 ? ((p == 0 ? w0 : wq[p]) >> c) & 1 : (phase == p - 3);
+        pl[j] = bit ? 1.f : 0.f;
+    }
+    int base = 0;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int a = it * kWave + lane;
+        const uint64_t bal = (uint64_t)mq[2 * it] | ((2 * it + 1 < 7) ? ((uint64_t)mq[2 * it + 1] << 32) : 0ull);
+        const bool lg = (bal >> lane) & 1;
+        const int slot = base + __popcll(bal & ((1ull << lane) - 1ull));
+        if (a < kTotal) {
+            legal[s * kTotal + a] = lg ? 1 : 0;
+            policy[s * kTotal + a] = lg ? pv[slot] : 0.f;
+        }
+        base += __popcll(bal);
+    }
+    if (lane == 0) {
+        const float* vq = reinterpret_cast<const float*>(rec + 348);
+        value[s] = vq[0]; soft[s] = vq[1];
+    }
+}
+}  // namespace
+
+extern "C" int lz_pack_trajectory_rows(const float* state_tensors, const uint8_t* legal_masks,
+                                       const float* policy_targets, const float* value_targets,
+                                       const float* soft_value_targets, int64_t rows, void* records,
+                                       int32_t* not_representable, void* stream) {
+    if (rows < 0) return LZ_ERR_ARG;
+    if (rows == 0) return LZ_OK;
+    if (!state_tensors || !legal_masks || !policy_targets || !value_targets || !soft_value_targets || !records ||
+        !not_representable)
+        return LZ_ERR_ARG;
+    const unsigned grid = (unsigned)((rows + kWavesPerBlock - 1) / kWavesPerBlock);
+    hipLaunchKernelGGL(pack_rows_kernel, dim3(grid), dim3(kWave * kWavesPerBlock), 0,
+                       reinterpret_cast<hipStream_t>(stream), state_tensors, legal_masks, policy_targets, value_targets,
+                       soft_value_targets, rows, reinterpret_cast<uint8_t*>(records), not_representable);
+    return hipGetLastError() == hipSuccess ? LZ_OK : LZ_ERR_LAUNCH;
+}
+
+extern "C" int lz_unpack_trajectory_rows(const void* records, int64_t rows, float* state_tensors, uint8_t* legal_masks,
+                                         float* policy_targets, float* value_targets, float* soft_value_targets,
+                                         void* stream) {
+    if (rows < 0) return LZ_ERR_ARG;
+    if (rows == 0) return LZ_OK;
+    if (!records || !state_tensors || !legal_masks || !policy_targets || !value_targets || !soft_value_targets)
+        return LZ_ERR_ARG;
+    const unsigned grid = (unsigned)((rows + kWavesPerBlock - 1) / kWavesPerBlock);
+    hipLaunchKernelGGL(unpack_rows_kernel, dim3(grid), dim3(kWave * kWavesPerBlock), 0,
+                       reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const uint8_t*>(records), rows,
+                       state_tensors, legal_masks, policy_targets, value_targets, soft_value_targets);
+    return hipGetLastError() == hipSuccess ? LZ_OK : LZ_ERR_LAUNCH;
+}

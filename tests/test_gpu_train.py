@@ -99,3 +99,36 @@ def test_trainer_step_learns_and_reports_the_reference_metrics(tmp_path):
     model, m2 = train_network_from_tensors(model, batch, batch_size=256, epochs=1, lr=1e-3, device=DEV,
                                            optimizer_state_path=opt_path)
     assert m2["optimizer_loaded"] is True and m2["epoch_stats"][0]["avg_loss"] < e1["avg_loss"]
+
+
+def test_compact_trajectory_records_round_trip_exactly():
+    """Wire format of the trajectory gather: 360-byte records reproduce the 5 tensors bit for bit."""
+    _need_gpu()
+    from liuzhou_amd.net import ChessNet, MODEL_CONFIGS
+    from liuzhou_amd.net_hip import FusedNet
+    from liuzhou_amd.self_play_gpu_runner import self_play_v1_gpu
+    from liuzhou_amd.trajectory_codec import RECORD_BYTES, pack_batch, unpack_records
+    from liuzhou_amd.trajectory_buffer import TensorSelfPlayBatch
+    torch.manual_seed(1)
+    net = FusedNet(ChessNet(**MODEL_CONFIGS["b6c64"]).eval().to(DEV))
+    batch, _ = self_play_v1_gpu(net, num_games=96, mcts_simulations=8, temperature_init=1.0, temperature_final=0.1,
+                                temperature_threshold=10, exploration_weight=1.0, device=DEV, max_game_plies=150,
+                                concurrent_games=96)
+    assert batch.num_samples > 5000 and int(batch.state_tensors[:, 4:].sum(dim=(2, 3)).amax()) == 36
+    phases = batch.state_tensors[:, 4:, 0, 0].argmax(1)
+    assert len(torch.unique(phases)) >= 4                      # placement, movement, selections ... all occur
+    rec = pack_batch(batch)
+    assert rec.shape == (batch.num_samples, RECORD_BYTES) and rec.dtype == torch.uint8
+    back = unpack_records(rec)
+    for k in ("state_tensors", "legal_masks", "policy_targets", "value_targets", "soft_value_targets"):
+        a, b = getattr(batch, k), getattr(back, k)
+        assert a.dtype == b.dtype and a.shape == b.shape
+        assert torch.equal(a.view(torch.uint8) if a.dtype == torch.bool else a.view(torch.int32),
+                           b.view(torch.uint8) if b.dtype == torch.bool else b.view(torch.int32)), k
+    # rows that cannot be represented are refused loudly
+    broken = TensorSelfPlayBatch(batch.state_tensors[:4] * 0.5, batch.legal_masks[:4], batch.policy_targets[:4],
+                                 batch.value_targets[:4], batch.soft_value_targets[:4])
+    with pytest.raises(RuntimeError, match="not representable"):
+        pack_batch(broken)
+    assert pack_batch(TensorSelfPlayBatch(batch.state_tensors[:0], batch.legal_masks[:0], batch.policy_targets[:0],
+                                          batch.value_targets[:0], batch.soft_value_targets[:0])).shape == (0, RECORD_BYTES)
