@@ -501,26 +501,45 @@ __global__ __launch_bounds__(W * 64, 2) void net_forward_kernel(NetParams P, con
         }
         if (P.debug_stop == 2) { if (lane == 0 && x[0][0][0] == 123.f) lp1[0] = 1.f; continue; }   // after the stem
         // ---- residual blocks: every global load (weights, parameters) is issued one phase ahead ----
+#ifdef LZ_EXP_STAMPS   /* timing experiment: s_memtime stamps of one wave through block 2 */
+#define LZ_STAMP(k) if (blk == 2) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); stamps[k] = __builtin_readcyclecounter(); }
+        uint64_t stamps[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#else
+#define LZ_STAMP(k)
+#endif
         for (int blk = 0; blk < P.blocks; ++blk) {
             const int bp = P.blk0 + blk * 3 * C;               // float offsets: a1 | b1 | bias1
             load_chan_params(rf, bp, chan0, lane, pa);
             load_chan_params(rf, bp + C, chan0, lane, pb);
             load_first_frags(rw, P.layer_off[1 + 2 * blk], ct0, lane, Af);
+            LZ_STAMP(0)
             lds_barrier();                                     // everyone finished reading the act buffer
+            LZ_STAMP(1)
             store_act<C, S, true>(x, lds, base, chan0, pa, pb, lane);                 // t = relu(a1*x + b1)
             load_chan_params(rf, bp + 2 * C, chan0, lane, pb);                          // bias1, used after conv1
+            LZ_STAMP(2)
             lds_barrier();
+            LZ_STAMP(3)
 #pragma unroll
             for (int i = 0; i < 9; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
             conv_gemm<C, S, true, false, K::CT>(acc, rw, P.layer_off[1 + 2 * blk], ct0, lds, base, lane, Af);
             load_first_frags(rw, P.layer_off[2 + 2 * blk], ct0, lane, Af);
+            LZ_STAMP(4)
             lds_barrier();
+            LZ_STAMP(5)
             store_act<C, S, false>(acc, lds, base, chan0, pb, pb, lane);               // u = relu(conv1 + bias1)
+            LZ_STAMP(6)
             lds_barrier();
+            LZ_STAMP(7)
             conv_gemm<C, S, true, false, K::CT>(x, rw, P.layer_off[2 + 2 * blk], ct0, lds, base, lane, Af);  // x += conv2(u)
+            LZ_STAMP(8)
         }
+#ifdef LZ_EXP_STAMPS
+        if (blockIdx.x == 7 && (tid & 63) == 0 && vlogits != nullptr)
+            for (int k = 0; k < 9; ++k) vlogits[wave * 16 + k] = (float)(stamps[k] - stamps[0]);
+#endif
         if (P.debug_stop == 3) { if (lane == 0 && x[0][0][0] == 123.f) lp1[0] = 1.f; continue; }   // after the trunk
         // ---- trunk output h = relu(a*x + b) -> LDS; head 1x1 convs (8 output tiles: policy 0..3 | value 4..7) ----
         int tid_h = tid;
@@ -740,7 +759,8 @@ static int net_forward_impl(const LzNetDesc* d, const float* planes, const uint6
     if (d->channels != 64 && d->channels != 128) return LZ_ERR_UNSUPPORTED;
     const bool prof = g_prof.on && g_prof.used < NetProf::kMax;
     if (prof) (void)hipEventRecord(g_prof.ev[2 * g_prof.used], st);
-    // (two 4-wave workgroups per CU, <64,8,4>, measured within 1 % of this in the self-play loop: not instantiated)
+    // Two 4-wave workgroups of 8 samples per CU (<64,8,4>) were measured, also staggered by half a layer: 9 % fewer
+    // shader cycles per pass, but the chip then holds 1.87 GHz instead of 2.05 GHz -- the same wall time.
     const int rc = d->channels == 64
                        ? launch_net<64, 16, 8>(P, planes, packed, N, lp1, lp2, lpmc, value_logits, value, max_blocks, st)
                        : launch_net<128, 8, 8>(P, planes, packed, N, lp1, lp2, lpmc, value_logits, value, max_blocks, st);
