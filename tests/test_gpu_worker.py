@@ -83,3 +83,22 @@ def test_selfplay_stage_cli_two_worker_processes(tmp_path, backend):
     assert total == batch.num_samples
     js = json.load(open(stats_json))
     assert js["num_samples"] == batch.num_samples
+
+
+def test_staged_loop_single_process(tmp_path):
+    """C5 staged loop (self-play -> gather -> train -> checkpoint hand-off), one process = one GPU doing both roles."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, os.path.join(root, "scripts", "staged_loop.py"), "--iterations", "2",
+                          "--games-per-gpu", "64", "--sims", "8", "--max-game-plies", "40", "--batch-size", "512"],
+                         capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout + res.stderr
+    out = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+    assert len(out["iterations"]) == 2 and out["iterations"][0]["positions"] == 64 * 40
+    assert out["iterations"][1]["train_samples"] > 0 and out["steady_state_positions_per_sec"] > 0
+    assert out["iterations"][1]["avg_loss"] is not None
