@@ -1,7 +1,14 @@
 """Experiment: per-phase s_memtime stamps of the network kernel's residual block 2 (build_exp/lib_stamps.so)."""
-import os, sys
-os.environ["LZ_HIP_LIB"] = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "build_exp", "lib_stamps.so")
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "build_exp", "lib_stamps.so")
+if not os.path.exists(LIB):                      # the production library is built without the stamps
+    os.makedirs(os.path.dirname(LIB), exist_ok=True)
+    src = [os.path.join(ROOT, "liuzhou_amd", "csrc", f) for f in ("lz_ops.hip", "lz_engine.hip", "lz_net.hip", "lz_train.hip")]
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
+                           "-shared", "-fvisibility=hidden", "-DLZ_EXP_STAMPS", "-o", LIB] + src)
+os.environ["LZ_HIP_LIB"] = LIB
+sys.path.insert(0, ROOT)
 import torch
 from liuzhou_amd.net import ChessNet, MODEL_CONFIGS
 from liuzhou_amd.net_hip import FusedNet
