@@ -181,6 +181,9 @@ typedef struct LzNetDesc {
     int32_t head_frag_offsets[4]; /* halfs: gpool_linear [64x192], fc1 [128x192], fc2 [112x128], out convs [16x64] */
     int32_t off_stem_bias, off_block0 /* a1|b1|bias1 per block, 3*C floats each */, off_trunk_a, off_trunk_b,
             off_head_bias, off_p_gwT, off_p_a2, off_p_b2, off_p_out, off_v_w1T, off_v_b1, off_v_w2T, off_v_b2;
+    int32_t flags;               /* bit 0 (64 channels): 4-wave workgroups of 8 samples, two per CU (default grid 512):
+                                    a half-size batch then still covers every CU -- for two half-batches evaluated
+                                    concurrently on two streams */
 } LzNetDesc;
 
 /* ChessNet.forward (src/neural_network.py:213-259) + bucket_logits_to_scalar (:201-210), fused:
@@ -202,6 +205,8 @@ LZ_API int lz_net_configure(void);
  * its own stream; after synchronising, lz_prof_net_summary returns the summed kernel time. */
 LZ_API int lz_prof_enable(int on);
 LZ_API int lz_prof_net_summary(double* total_ms, int64_t* launches, int64_t* evals);
+/* launches on several streams may overlap: time during which at least one bracketed launch was running */
+LZ_API int lz_prof_net_busy(double* busy_ms);
 
 /* ---- device-resident tree search (variant P) --------------------------------------------------- */
 

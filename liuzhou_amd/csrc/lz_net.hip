@@ -16,6 +16,9 @@
 // Reference architecture: src/neural_network.py:67-259 (ChessNet.forward).  fp16 operands, fp32
 // accumulate -- the counterpart of the reference's autocast-fp16 inference (v1/python/mcts_gpu.py:640-646).
 #include <hip/hip_runtime.h>
+#include <algorithm>
+#include <utility>
+#include <vector>
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -162,12 +165,15 @@ constexpr bool tile_map_ok() {                                      // compile-t
     for (int n = 0; n < S * 36; ++n) if (!seen[n]) return false;
     return true;
 }
-static_assert(tile_map_ok<64, 16>() && tile_map_ok<128, 8>(), "operand tiles must be bank-conflict free");
+static_assert(tile_map_ok<64, 16>() && tile_map_ok<128, 8>() && tile_map_ok<64, 8>(),
+              "operand tiles must be bank-conflict free");
+__constant__ const TileMap<64, 8> kTileMap64h = make_tile_map<64, 8>();
 __constant__ const TileMap<64, 16> kTileMap64 = make_tile_map<64, 16>();
 __constant__ const TileMap<128, 8> kTileMap128 = make_tile_map<128, 8>();
 template <int C, int S> __device__ __forceinline__ int tile_cell(int tile, int col);
 template <> __device__ __forceinline__ int tile_cell<64, 16>(int tile, int col) { return kTileMap64.cell[tile][col]; }
 template <> __device__ __forceinline__ int tile_cell<128, 8>(int tile, int col) { return kTileMap128.cell[tile][col]; }
+template <> __device__ __forceinline__ int tile_cell<64, 8>(int tile, int col) { return kTileMap64h.cell[tile][col]; }
 
 // byte address of 16-byte channel chunk `chunk` of board cell n (n = 36*sample + 6*r + c)
 template <int C, int S>
@@ -730,9 +736,36 @@ int lz_prof_net_summary(double* total_ms, int64_t* launches, int64_t* evals) {
     return LZ_OK;
 }
 
+/* Launches bracketed on several streams may overlap: `busy_ms` is the length of the union of their [start, end]
+ * intervals (event times relative to the first recorded event), i.e. the time during which at least one network
+ * kernel was running; equal to total_ms when everything ran on one stream. */
+int lz_prof_net_busy(double* busy_ms) {
+    if (!busy_ms) return LZ_ERR_ARG;
+    *busy_ms = 0.0;
+    const int n = g_prof.used;
+    if (n == 0) return LZ_OK;
+    std::vector<std::pair<float, float>> iv((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        float a = 0.f, b = 0.f;
+        if (hipEventElapsedTime(&a, g_prof.ev[0], g_prof.ev[2 * i]) != hipSuccess ||
+            hipEventElapsedTime(&b, g_prof.ev[0], g_prof.ev[2 * i + 1]) != hipSuccess)
+            return LZ_ERR_LAUNCH;
+        iv[(size_t)i] = {a, b};
+    }
+    std::sort(iv.begin(), iv.end());
+    double busy = 0.0;
+    float lo = iv[0].first, hi = iv[0].second;
+    for (int i = 1; i < n; ++i) {
+        if (iv[(size_t)i].first > hi) { busy += (double)(hi - lo); lo = iv[(size_t)i].first; hi = iv[(size_t)i].second; }
+        else if (iv[(size_t)i].second > hi) hi = iv[(size_t)i].second;
+    }
+    *busy_ms = busy + (double)(hi - lo);
+    return LZ_OK;
+}
+
 int lz_net_configure(void) {
-    const int a = configure_net<64, 16, 8>(), b = configure_net<128, 8, 8>();
-    return a != LZ_OK ? a : b;
+    const int a = configure_net<64, 16, 8>(), b = configure_net<128, 8, 8>(), c = configure_net<64, 8, 4>();
+    return a != LZ_OK ? a : (b != LZ_OK ? b : c);
 }
 
 static int net_forward_impl(const LzNetDesc* d, const float* planes, const uint64_t* packed, int64_t N, float* lp1,
@@ -754,7 +787,10 @@ static int net_forward_impl(const LzNetDesc* d, const float* planes, const uint6
     P.stem_bias = d->off_stem_bias; P.blk0 = d->off_block0; P.trunk_a = d->off_trunk_a; P.trunk_b = d->off_trunk_b;
     P.head_bias = d->off_head_bias; P.p_gwT = d->off_p_gwT; P.p_a2 = d->off_p_a2; P.p_b2 = d->off_p_b2;
     P.p_out = d->off_p_out; P.v_w1T = d->off_v_w1T; P.v_b1 = d->off_v_b1; P.v_w2T = d->off_v_w2T; P.v_b2 = d->off_v_b2;
-    const int max_blocks = d->max_blocks > 0 ? d->max_blocks : 256;
+    // flags bit 0 (64 channels): 4-wave workgroups of 8 samples, two per CU -- twice as many workgroups per batch, so
+    // that a half-size batch still covers every CU when two of them are evaluated concurrently on two streams
+    const bool half_wg = d->channels == 64 && (d->flags & 1);
+    const int max_blocks = d->max_blocks > 0 ? d->max_blocks : (half_wg ? 512 : 256);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (d->channels != 64 && d->channels != 128) return LZ_ERR_UNSUPPORTED;
     const bool prof = g_prof.on && g_prof.used < NetProf::kMax;
@@ -762,7 +798,9 @@ static int net_forward_impl(const LzNetDesc* d, const float* planes, const uint6
     // Two 4-wave workgroups of 8 samples per CU (<64,8,4>) were measured, also staggered by half a layer: 9 % fewer
     // shader cycles per pass, but the chip then holds 1.87 GHz instead of 2.05 GHz -- the same wall time.
     const int rc = d->channels == 64
-                       ? launch_net<64, 16, 8>(P, planes, packed, N, lp1, lp2, lpmc, value_logits, value, max_blocks, st)
+                       ? (half_wg
+                              ? launch_net<64, 8, 4>(P, planes, packed, N, lp1, lp2, lpmc, value_logits, value, max_blocks, st)
+                              : launch_net<64, 16, 8>(P, planes, packed, N, lp1, lp2, lpmc, value_logits, value, max_blocks, st))
                        : launch_net<128, 8, 8>(P, planes, packed, N, lp1, lp2, lpmc, value_logits, value, max_blocks, st);
     if (prof) { (void)hipEventRecord(g_prof.ev[2 * g_prof.used + 1], st); g_prof.used += 1; g_prof.evals += N; }
     return rc;

@@ -24,14 +24,15 @@ class LzNetDesc(C.Structure):
                 ("head_frag_offsets", C.c_int32 * 4)] + \
                [(n, C.c_int32) for n in ("off_stem_bias", "off_block0", "off_trunk_a", "off_trunk_b", "off_head_bias",
                                          "off_p_gwT", "off_p_a2", "off_p_b2", "off_p_out", "off_v_w1T", "off_v_b1",
-                                         "off_v_w2T", "off_v_b2")]
+                                         "off_v_w2T", "off_v_b2", "flags")]
 
 
 _configured = False
 
 
 class FusedNet:
-    def __init__(self, model, device=None, max_blocks: int = 0) -> None:
+    def __init__(self, model, device=None, max_blocks: int = 0, half_workgroups: bool = False) -> None:
+        """`half_workgroups` (64 channels): 4-wave workgroups of 8 samples, two per CU (LzNetDesc.flags bit 0)."""
         global _configured
         dev = torch.device(device) if device is not None else next(model.parameters()).device
         if dev.type != "cuda":
@@ -44,6 +45,7 @@ class FusedNet:
         d.channels, d.blocks = self.pack.channels, self.pack.blocks
         d.num_layers = len(self.pack.layer_offsets)
         d.max_blocks = int(max_blocks)
+        d.flags = 1 if (half_workgroups and self.pack.channels == 64) else 0
         d.wfrag, d.fparams = self.pack.wfrag.data_ptr(), self.pack.fparams.data_ptr()
         d.wfrag_bytes = int(self.pack.wfrag.numel()) * 2
         d.fparams_bytes = int(self.pack.fparams.numel()) * 4
@@ -66,6 +68,17 @@ class FusedNet:
 
     def eval(self):
         return self
+
+    def variant(self, half_workgroups: bool) -> "FusedNet":
+        """Same packed weights, other kernel configuration (a second descriptor over the same buffers)."""
+        import copy
+        other = copy.copy(self)
+        d = LzNetDesc()
+        C.memmove(C.byref(d), C.byref(self.desc), C.sizeof(LzNetDesc))
+        d.flags = 1 if (half_workgroups and self.pack.channels == 64) else 0
+        other.desc = d
+        other.last_value = None
+        return other
 
     def forward_into(self, planes: torch.Tensor, lp1, lp2, lpm, vlogits, value) -> None:
         N = int(planes.shape[0])

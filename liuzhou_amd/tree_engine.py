@@ -271,13 +271,76 @@ class PortableTreeMCTS:
             chosen_action_codes=e.chosen_code, chosen_valid_mask=e.chosen_valid)
 
 
+class DualStreamTreeMCTS:
+    """Two half-size searches on two HIP streams, same interface as PortableTreeMCTS.
+
+    Within one game the simulation chain (select -> evaluate -> expand) is strictly sequential, and the tree kernel
+    is latency-bound: while it runs, the matrix pipes idle.  With the games split in two halves, each with its own
+    engine, hipGraph and stream, one half's tree kernel overlaps the other half's network kernel.  The network runs
+    4-wave workgroups of 8 samples (two per CU, `FusedNet(half_workgroups=True)`), so that a half batch alone still
+    covers every CU.  Results are identical to one engine over all games (games are independent)."""
+
+    def __init__(self, model, num_games: int, num_simulations: int, device, **kw) -> None:
+        dev = torch.device(device)
+        self.B = int(num_games)
+        self.h = (self.B + 1) // 2
+        self.device = dev
+        self.streams = (torch.cuda.Stream(dev), torch.cuda.Stream(dev))
+        self.parts = []
+        for n in (self.h, self.B - self.h):
+            base = model if isinstance(model, FusedNet) else FusedNet(model, dev)
+            self.parts.append(PortableTreeMCTS(base.variant(half_workgroups=True), n, num_simulations, dev, **kw))
+        self.sims = int(num_simulations)
+        self.serialize = False        # measurement aid: run the halves one after the other on the caller's stream
+
+    @property
+    def leaf_evals(self) -> int:
+        return sum(p.leaf_evals for p in self.parts)
+
+    @property
+    def use_graph(self) -> bool:
+        return self.parts[0].use_graph
+
+    @use_graph.setter
+    def use_graph(self, v: bool) -> None:
+        for p in self.parts:
+            p.use_graph = bool(v)
+
+    def reset_trees(self) -> None:
+        for p in self.parts:
+            p.reset_trees()
+
+    def search_batch(self, state: GpuStateBatch, *, temperatures: torch.Tensor, active: Optional[torch.Tensor] = None,
+                     add_dirichlet_noise: Optional[bool] = None, reset: Optional[torch.Tensor] = None,
+                     played_action: Optional[torch.Tensor] = None,
+                     force_uniform_random_mask: Optional[torch.Tensor] = None) -> RootSearchBatchOutput:
+        main = torch.cuda.current_stream(self.device)
+        cut = lambda t, a, b: None if t is None else t[a:b]
+        outs = []
+        for (a, b), part, st in zip(((0, self.h), (self.h, self.B)), self.parts,
+                                    (main, main) if self.serialize else self.streams):
+            st.wait_stream(main)
+            with torch.cuda.stream(st):
+                outs.append(part.search_batch(state._map(lambda t, a=a, b=b: t[a:b]), temperatures=temperatures[a:b],
+                                              active=cut(active, a, b),
+                                              add_dirichlet_noise=add_dirichlet_noise, reset=cut(reset, a, b),
+                                              played_action=cut(played_action, a, b),
+                                              force_uniform_random_mask=cut(force_uniform_random_mask, a, b)))
+        if not self.serialize:
+            for st in self.streams:
+                main.wait_stream(st)
+        return RootSearchBatchOutput(*(torch.cat([getattr(o, f) for o in outs], dim=0)
+                                       for f in ("model_input", "legal_mask", "policy_dense", "root_value", "terminal_mask",
+                                                 "chosen_action_indices", "chosen_action_codes", "chosen_valid_mask")))
+
+
 class SteadyStateTreeSelfPlay:
     """B games, always full (finished games are re-seated); one step = one searched move for every game."""
 
     def __init__(self, model, num_games: int, sims: int, device, dtype: str = "float16", seed: int = 12345,
                  temperature_init: float = 1.0, temperature_final: float = 0.1, temperature_threshold: int = 10,
                  max_game_plies: int = 512, exploration_weight: float = 1.0, reuse_tree: bool = False,
-                 reuse_factor: float = 3.0) -> None:
+                 reuse_factor: float = 3.0, dual_stream: bool = False) -> None:
         from .steady_state import SteadyStateRootSelfPlay
         from .mcts_gpu import V1RootMCTSConfig
         dev = torch.device(device)
@@ -287,8 +350,13 @@ class SteadyStateTreeSelfPlay:
         self.pop = SteadyStateRootSelfPlay(self.net, num_games, V1RootMCTSConfig(num_simulations=1), dev, seed=seed,
                                            temperature_init=temperature_init, temperature_final=temperature_final,
                                            temperature_threshold=temperature_threshold, max_game_plies=max_game_plies)
-        self.mcts = PortableTreeMCTS(self.net, num_games, sims, dev, exploration_weight, reuse_tree=reuse_tree,
-                                     reuse_factor=reuse_factor)
+        self.dual_stream = bool(dual_stream and self.net.pack.channels == 64 and int(num_games) >= 2)
+        if self.dual_stream:
+            self.mcts = DualStreamTreeMCTS(self.net, num_games, sims, dev, exploration_weight=exploration_weight,
+                                           reuse_tree=reuse_tree, reuse_factor=reuse_factor)
+        else:
+            self.mcts = PortableTreeMCTS(self.net, num_games, sims, dev, exploration_weight, reuse_tree=reuse_tree,
+                                         reuse_factor=reuse_factor)
         self._reseated = torch.zeros((self.B,), dtype=torch.uint8, device=dev)
         self.positions = 0
         self._nn_events = []

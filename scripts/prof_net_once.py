@@ -7,8 +7,9 @@ from liuzhou_amd.net_hip import FusedNet
 dev = torch.device("cuda:0")
 name = sys.argv[1] if len(sys.argv) > 1 else "b6c64"
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
+half = len(sys.argv) > 3 and sys.argv[3] == "half"          # 4-wave / 8-sample workgroups (dual-stream search)
 torch.manual_seed(20260314)
-f = FusedNet(ChessNet(**MODEL_CONFIGS[name]).eval().to(dev))
+f = FusedNet(ChessNet(**MODEL_CONFIGS[name]).eval().to(dev), half_workgroups=half)
 x = (torch.rand(N, 11, 6, 6, device=dev) < 0.3).float()
 for _ in range(20):
     f(x, want_logits=False)

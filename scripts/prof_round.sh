@@ -12,4 +12,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/bench" -- python3 
 tail -1 "$OUT/bench.log" | cut -c1-300
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch" -- python3 "$GRAFT_REPO_ROOT/scripts/prof_net_once.py" > "$OUT/pmc_fetch.log" 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_write" -- python3 "$GRAFT_REPO_ROOT/scripts/prof_net_once.py" > "$OUT/pmc_write.log" 2>&1
+# the launch shape of the dual-stream search: 2048 evaluations, 4-wave workgroups
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch_half" -- python3 "$GRAFT_REPO_ROOT/scripts/prof_net_once.py" b6c64 2048 half > "$OUT/pmc_fetch_half.log" 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_write_half" -- python3 "$GRAFT_REPO_ROOT/scripts/prof_net_once.py" b6c64 2048 half > "$OUT/pmc_write_half.log" 2>&1
 find "$OUT" -name "*.csv" | head -20

@@ -21,8 +21,11 @@ def _planes(n, seed=0):
                                          t("phase", np.int64), t("current_player", np.int64))
 
 
-@pytest.mark.parametrize("name,n", [("b6c64", 16), ("b6c64", 1000), ("b6c64", 4099), ("b10c128", 8), ("b10c128", 777)])
-def test_fused_net_matches_fp32_model(name, n):
+@pytest.mark.parametrize("name,n,half", [("b6c64", 16, False), ("b6c64", 1000, False), ("b6c64", 4099, False),
+                                         ("b10c128", 8, False), ("b10c128", 777, False),
+                                         ("b6c64", 5, True), ("b6c64", 2049, True)])
+def test_fused_net_matches_fp32_model(name, n, half):
+    """`half`: the 4-wave / 8-sample workgroup configuration used by the dual-stream search."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     from liuzhou_amd.net import ChessNet, MODEL_CONFIGS, bucket_logits_to_scalar
@@ -38,7 +41,7 @@ def test_fused_net_matches_fp32_model(name, n):
             mod.bias.data.copy_(torch.randn(mod.bias.shape, generator=g) * 0.1)
     m = m.to(DEV)
     x = _planes(n, seed=n)
-    fused = FusedNet(m)
+    fused = FusedNet(m, half_workgroups=half)
     lp1, lp2, lpm, vl = fused(x)
     val = fused.last_value
     with torch.inference_mode():

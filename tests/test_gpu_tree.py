@@ -266,3 +266,41 @@ def test_fused_search_with_subtree_reuse_accumulates_visits():
                                            out.terminal_mask, out.chosen_valid_mask, 512, 2.0)
         assert int(mcts.engine.reuse_dropped.item()) == 0
         assert prev_child_visits.max() > 1
+
+
+def test_dual_stream_search_equals_single_engine_search():
+    """Two half-size engines on two streams (tree kernel of one half overlapping the network of the other) give
+    exactly the results of one engine over all games with the same network kernel configuration."""
+    _need_gpu()
+    from liuzhou_amd.net import ChessNet, MODEL_CONFIGS
+    from liuzhou_amd.net_hip import FusedNet
+    from liuzhou_amd.tree_engine import DualStreamTreeMCTS, PortableTreeMCTS
+    torch.manual_seed(20260314)
+    net = FusedNet(ChessNet(**MODEL_CONFIGS["b6c64"]).eval().to(DEV))
+    z = load("g1_rules.npz")
+    st = states(z, "s")
+    B, sims = 257, 40                                            # odd: unequal halves
+    idx = np.random.default_rng(4).integers(0, st["board"].shape[0], B)
+    batch = to_gpu_batch({f: np.ascontiguousarray(np.asarray(st[f])[idx]) for f in FIELDS}, DEV)
+    temps = torch.full((B,), 0.1, device=DEV)
+    kw = dict(add_dirichlet_noise=False, sample_moves=False, reuse_tree=True)
+    single = PortableTreeMCTS(net.variant(half_workgroups=True), B, sims, DEV, **kw)
+    dual = DualStreamTreeMCTS(net, B, sims, DEV, **kw)
+    for use_graph in (False, True):
+        single.use_graph = dual.use_graph = use_graph
+        single.reset_trees(); dual.reset_trees()
+        a = single.search_batch(batch, temperatures=temps)
+        b = dual.search_batch(batch, temperatures=temps)
+        assert torch.equal(a.chosen_action_indices, b.chosen_action_indices)
+        assert torch.equal(a.policy_dense, b.policy_dense) and torch.equal(a.root_value, b.root_value)
+        assert torch.equal(a.terminal_mask, b.terminal_mask) and torch.equal(a.legal_mask, b.legal_mask)
+        # second move with subtree reuse on both
+        from liuzhou_amd import v0_core
+        nxt = batch._map(lambda t: t.clone())
+        plies = torch.zeros(B, dtype=torch.int64, device=DEV); done = torch.zeros(B, dtype=torch.bool, device=DEV)
+        v0_core.self_play_step_inplace(*nxt.tensors(), plies, done, torch.arange(B, device=DEV), a.chosen_action_codes,
+                                       a.terminal_mask, a.chosen_valid_mask, 512, 2.0)
+        a2 = single.search_batch(nxt, temperatures=temps, active=~done)
+        b2 = dual.search_batch(nxt, temperatures=temps, active=~done)
+        assert torch.equal(a2.chosen_action_indices, b2.chosen_action_indices) and torch.equal(a2.policy_dense, b2.policy_dense)
+    assert dual.leaf_evals == single.leaf_evals
