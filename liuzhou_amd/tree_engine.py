@@ -396,16 +396,22 @@ def self_play_tree_gpu(model, num_games: int, mcts_simulations: int, temperature
                        sample_moves: bool = True, concurrent_games: int = 8, verbose: bool = False,
                        policy_target_temperature: Optional[float] = None,
                        policy_target_prior_pseudocount: float = 0.0, reuse_tree: bool = True,
-                       reuse_factor: float = 3.0) -> Tuple[TensorSelfPlayBatch, SelfPlayV1Stats]:
+                       reuse_factor: float = 3.0, dual_stream: Optional[bool] = None
+                       ) -> Tuple[TensorSelfPlayBatch, SelfPlayV1Stats]:
     """Tree-search twin of self_play_v1_gpu (same outputs); mirrors v1/python/portable_self_play.py:82-284,
     including the subtree reuse it performs on every move (:191, `reuse_tree`)."""
     dev = torch.device(device)
     net = model if isinstance(model, FusedNet) else FusedNet(model, dev)
     wave = max(1, min(int(concurrent_games), int(num_games)))
-    mcts = PortableTreeMCTS(net, wave, mcts_simulations, dev, exploration_weight, add_dirichlet_noise, dirichlet_alpha,
-                            dirichlet_epsilon, sample_moves, reuse_tree=reuse_tree, reuse_factor=reuse_factor,
-                            policy_target_temperature=policy_target_temperature,
-                            policy_target_prior_pseudocount=policy_target_prior_pseudocount)
+    # two half-batches on two streams (see DualStreamTreeMCTS) once a wave is large enough to fill the chip twice over
+    if dual_stream is None:
+        dual_stream = net.pack.channels == 64 and wave >= 1024
+    cls = DualStreamTreeMCTS if (dual_stream and net.pack.channels == 64 and wave >= 2) else PortableTreeMCTS
+    mcts = cls(net, wave, mcts_simulations, dev, exploration_weight=exploration_weight,
+               add_dirichlet_noise=add_dirichlet_noise, dirichlet_alpha=dirichlet_alpha,
+               dirichlet_epsilon=dirichlet_epsilon, sample_moves=sample_moves, reuse_tree=reuse_tree,
+               reuse_factor=reuse_factor, policy_target_temperature=policy_target_temperature,
+               policy_target_prior_pseudocount=policy_target_prior_pseudocount)
     buffer = TensorTrajectoryBuffer(dev, TOTAL_ACTION_DIM, max_steps_hint=max_game_plies, concurrent_games_hint=wave)
     outcome = torch.zeros((3,), dtype=torch.int64, device=dev)
     lengths = torch.zeros((int(num_games),), dtype=torch.int64, device=dev)

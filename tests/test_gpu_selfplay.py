@@ -59,3 +59,23 @@ def test_gpu_selfplay_sampled_contract():
     assert bool((pol[~samples.legal_masks] == 0).all())
     assert bool(torch.isfinite(samples.value_targets).all()) and bool(torch.isfinite(samples.soft_value_targets).all())
     assert bool((samples.value_targets.abs() <= 1).all())
+
+
+def test_tree_self_play_runner_dual_stream_matches_contract():
+    """self_play_tree_gpu with the two-stream search: same tensor contract, every game played to the ply cap."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from liuzhou_amd.net import ChessNet, MODEL_CONFIGS
+    from liuzhou_amd.net_hip import FusedNet
+    from liuzhou_amd.tree_engine import self_play_tree_gpu
+    torch.manual_seed(2)
+    net = FusedNet(ChessNet(**MODEL_CONFIGS["b6c64"]).eval().to("cuda:0"))
+    for dual in (True, False):
+        batch, stats = self_play_tree_gpu(net, num_games=65, mcts_simulations=12, temperature_init=1.0,
+                                          temperature_final=0.1, temperature_threshold=10, exploration_weight=1.0,
+                                          device="cuda:0", max_game_plies=30, concurrent_games=65, dual_stream=dual)
+        assert batch.num_samples == 65 * 30 == stats.num_positions
+        assert torch.allclose(batch.policy_targets.sum(1), torch.ones(batch.num_samples, device="cuda:0"), atol=1e-4)
+        assert bool((batch.policy_targets[~batch.legal_masks] == 0).all())
+        assert bool(torch.isfinite(batch.value_targets).all())
+        assert stats.mcts_counters["leaf_eval_count"] == 65 * 13 * 30
