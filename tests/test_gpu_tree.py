@@ -304,3 +304,42 @@ def test_dual_stream_search_equals_single_engine_search():
         b2 = dual.search_batch(nxt, temperatures=temps, active=~done)
         assert torch.equal(a2.chosen_action_indices, b2.chosen_action_indices) and torch.equal(a2.policy_dense, b2.policy_dense)
     assert dual.leaf_evals == single.leaf_evals
+
+
+def test_tree_engine_degenerate_sizes():
+    """One game / one simulation, two games on two streams, zero games through the C ABI: nothing faults, visits add up."""
+    _need_gpu()
+    import ctypes as C
+    from liuzhou_amd import _lib as L
+    from liuzhou_amd.mcts_gpu import GpuStateBatch
+    from liuzhou_amd.net import ChessNet, MODEL_CONFIGS
+    from liuzhou_amd.net_hip import FusedNet
+    from liuzhou_amd.tree_engine import DualStreamTreeMCTS, LzTreeDesc, PortableTreeMCTS, TreeEngine
+    torch.manual_seed(1)
+    net = FusedNet(ChessNet(**MODEL_CONFIGS["b6c64"]).eval().to(DEV))
+    for cls, B, sims in ((PortableTreeMCTS, 1, 1), (PortableTreeMCTS, 3, 2), (DualStreamTreeMCTS, 2, 1), (DualStreamTreeMCTS, 5, 3)):
+        m = cls(net, B, sims, DEV, sample_moves=False, add_dirichlet_noise=False, reuse_tree=True)
+        st = GpuStateBatch.initial(DEV, B)
+        plies = torch.zeros(B, dtype=torch.int64, device=DEV); done = torch.zeros(B, dtype=torch.bool, device=DEV)
+        from liuzhou_amd import v0_core
+        for mv in range(3):
+            out = m.search_batch(st, temperatures=torch.ones(B, device=DEV))
+            assert bool(out.chosen_valid_mask.all()) and torch.allclose(out.policy_dense.sum(1), torch.ones(B, device=DEV), atol=1e-5)
+            v0_core.self_play_step_inplace(*st.tensors(), plies, done, torch.arange(B, device=DEV), out.chosen_action_codes,
+                                           out.terminal_mask, out.chosen_valid_mask, 512, 2.0)
+    # zero games: every entry point is a no-op that reports success
+    eng = TreeEngine(1, 4, DEV)
+    d = LzTreeDesc()
+    C.memmove(C.byref(d), C.byref(eng.desc), C.sizeof(LzTreeDesc))
+    d.num_games = 0
+    z = torch.zeros(8, device=DEV)
+    assert L.lib().lz_tree_begin(C.byref(d), None) == 0 and L.lib().lz_tree_select(C.byref(d), None) == 0
+    assert L.lib().lz_tree_advance(C.byref(d), None, None, L.i64(4), None, None) == 0
+    assert L.lib().lz_tree_expand(C.byref(d), C.c_int(1), None, None, None, L.ptr(z), L.ptr(z), None, L.i64(0), C.c_float(0.25), None) == 0
+    # invalid descriptors are refused, not launched
+    d.num_games = 1
+    d.nodes = None
+    assert L.lib().lz_tree_begin(C.byref(d), None) == -1
+    d.nodes = eng.desc.nodes
+    d.node_cap = 70000
+    assert L.lib().lz_tree_advance(C.byref(d), None, None, L.i64(4), None, None) == -1      # 16-bit owner ids
