@@ -31,15 +31,101 @@ def _all_ranks_true(flag: bool, ddp: bool, device: torch.device) -> bool:
     return bool(int(t.item()) == 1)
 
 
-def train_network_from_tensors(model, samples: TensorSelfPlayBatch, *, batch_size: int = 512, epochs: int = 1,
-                               lr: float = 1e-3, weight_decay: float = 1e-4, soft_label_alpha: float = 0.0,
-                               anti_draw_penalty: float = 0.0, policy_draw_weight: float = 1.0, device: str = "cuda:0",
-                               use_amp: bool = True, grad_clip_norm: float = 1.0, warmup_steps: int = 0,
-                               parallel_devices: Optional[List[str]] = None, parallel_strategy: str = "none",
-                               ddp_pre_sharded: bool = False, optimizer_state_path: Optional[str] = None
-                               ) -> Tuple[Any, Dict[str, Any]]:
-    if samples.num_samples <= 0:
-        return model, {"epoch_stats": [], "num_samples": 0}
+class _Stepper:
+    """One optimisation step on a batch (forward under AMP, fused loss, backward, finite checks, clip, Adam) and the
+    running sums of an epoch -- shared by the in-memory and the streaming trainer."""
+
+    def __init__(self, model, train_model, optimizer, scheduler, scaler, *, amp: bool, alpha: float, anti_draw: float,
+                 draw_w: float, grad_clip_norm: float, ddp: bool, dev: torch.device) -> None:
+        self.model, self.train_model, self.optimizer, self.scheduler, self.scaler = model, train_model, optimizer, scheduler, scaler
+        self.amp, self.alpha, self.anti_draw, self.draw_w = amp, alpha, anti_draw, draw_w
+        self.clip, self.ddp, self.dev = float(grad_clip_norm), ddp, dev
+        self.reset()
+
+    def reset(self) -> None:
+        # loss, policy*w, value, bucket, aux, seen, wsum, valid, |soft|
+        self.acc = torch.zeros(9, dtype=torch.float64, device=self.dev)
+        self.mix_abs_sum, self.batches, self.skip_loss, self.skip_grad = 0.0, 0, 0, 0
+
+    def step(self, b_states, b_masks, b_policy, b_values, b_soft) -> bool:
+        opt, scaler, dev = self.optimizer, self.scaler, self.dev
+        opt.zero_grad(set_to_none=True)
+        with (torch.amp.autocast("cuda", enabled=True) if self.amp else nullcontext()):
+            lp1, lp2, lpm, vlogits = self.train_model(b_states)
+        loss, parts = fused_policy_value_loss(lp1, lp2, lpm, vlogits, b_masks, b_policy, b_values, b_soft,
+                                              soft_label_alpha=self.alpha, anti_draw_penalty=self.anti_draw,
+                                              policy_draw_weight=self.draw_w)
+        if not _all_ranks_true(bool(torch.isfinite(loss).item()), self.ddp, dev):
+            self.skip_loss += 1
+            opt.zero_grad(set_to_none=True)
+            return False
+        if scaler is not None:
+            scaler.scale(loss).backward()
+            scaler.unscale_(opt)
+        else:
+            loss.backward()
+        grads_ok = all(p.grad is None or bool(torch.isfinite(p.grad).all().item()) for p in self.model.parameters())
+        if not _all_ranks_true(grads_ok, self.ddp, dev):
+            self.skip_grad += 1
+            opt.zero_grad(set_to_none=True)
+            if scaler is not None:
+                scaler.update()
+            return False
+        torch.nn.utils.clip_grad_norm_(self.model.parameters(), max_norm=self.clip)
+        if scaler is not None:
+            scaler.step(opt)
+            scaler.update()
+        else:
+            opt.step()
+        self.scheduler.step()
+        cnt = float(b_values.numel())
+        draw = b_values.abs() < 1e-8
+        wsum = torch.where(draw, self.draw_w, 1.0).sum()
+        v_used = (torch.where(draw, torch.full_like(b_values, self.anti_draw), b_values)
+                  if abs(self.anti_draw) > 1e-9 else b_values)
+        mixed = ((1.0 - self.alpha) * v_used + self.alpha * b_soft).clamp(-1.0, 1.0)
+        self.acc += torch.stack([loss.detach() * cnt, parts["policy_loss"] * wsum, parts["bucket_value_loss"] * cnt,
+                                 parts["bucket_value_loss"] * cnt, parts["wdl_aux_loss"] * cnt,
+                                 torch.tensor(cnt, device=dev), wsum, (b_policy.sum(dim=1) > 1e-8).sum(),
+                                 b_soft.abs().mean()]).to(torch.float64)
+        self.mix_abs_sum += float(mixed.abs().mean().item())
+        self.batches += 1
+        return True
+
+    def epoch_stats(self, epoch: int, extra: Dict[str, Any], more_sums: Optional[List[float]] = None):
+        red = torch.cat([self.acc, torch.tensor([self.mix_abs_sum, float(self.batches), float(self.skip_loss),
+                                                 float(self.skip_grad)] + list(more_sums or []),
+                                                dtype=torch.float64, device=self.dev)])
+        if self.ddp:
+            dist.all_reduce(red, op=dist.ReduceOp.SUM)
+        r = red.tolist()
+        seen = int(round(r[5]))
+        stats = {"epoch": epoch, "avg_loss": r[0] / max(1, seen), "avg_policy_loss": r[1] / max(1e-8, r[6]),
+                 "avg_value_loss": r[2] / max(1, seen), "avg_value_bucket_loss": r[3] / max(1, seen),
+                 "avg_wdl_aux_loss": r[4] / max(1, seen), "samples": seen, "valid_policy_samples": int(round(r[7])),
+                 "policy_weight_sum": r[6], "soft_alpha": self.alpha, "avg_soft_abs": r[8] / max(1, int(round(r[10]))),
+                 "avg_mix_abs": r[9] / max(1, int(round(r[10]))),
+                 "skipped_non_finite_loss_batches": int(round(r[11])), "skipped_non_finite_grad_batches": int(round(r[12]))}
+        stats.update(extra)
+        return stats, r[13:]
+
+
+def _make_optimizer(model, lr, weight_decay, optimizer_state_path, dev):
+    optimizer = optim.Adam(model.parameters(), lr=lr, weight_decay=weight_decay)
+    loaded, err = False, None
+    if optimizer_state_path and os.path.exists(optimizer_state_path):
+        try:
+            optimizer.load_state_dict(torch.load(optimizer_state_path, map_location=dev))
+            for pg in optimizer.param_groups:
+                pg["lr"] = float(lr)
+                pg["initial_lr"] = float(lr)
+            loaded = True
+        except Exception as exc:   # fresh Adam, like the reference
+            err = repr(exc)
+    return optimizer, loaded, err
+
+
+def _resolve_strategy(parallel_strategy: str, device: str):
     strategy = {"dp": "none", "data_parallel": "none", "none": "none", "single": "none", "ddp": "ddp"}.get(
         str(parallel_strategy).strip().lower())
     if strategy is None:
@@ -54,12 +140,29 @@ def train_network_from_tensors(model, samples: TensorSelfPlayBatch, *, batch_siz
         dev = torch.device(f"cuda:{int(os.environ.get('LOCAL_RANK', '0'))}")
         torch.cuda.set_device(dev)
         rank, world = int(dist.get_rank()), int(dist.get_world_size())
+    return strategy, dev, rank, world
+
+
+def _wrap(model, strategy, dev):
     model.to(dev)
     model.train()
-    train_model: nn.Module = model
     if strategy == "ddp":
-        train_model = nn.parallel.DistributedDataParallel(model, device_ids=[dev.index], output_device=dev.index,
-                                                          broadcast_buffers=False, find_unused_parameters=False)
+        return nn.parallel.DistributedDataParallel(model, device_ids=[dev.index], output_device=dev.index,
+                                                   broadcast_buffers=False, find_unused_parameters=False)
+    return model
+
+
+def train_network_from_tensors(model, samples: TensorSelfPlayBatch, *, batch_size: int = 512, epochs: int = 1,
+                               lr: float = 1e-3, weight_decay: float = 1e-4, soft_label_alpha: float = 0.0,
+                               anti_draw_penalty: float = 0.0, policy_draw_weight: float = 1.0, device: str = "cuda:0",
+                               use_amp: bool = True, grad_clip_norm: float = 1.0, warmup_steps: int = 0,
+                               parallel_devices: Optional[List[str]] = None, parallel_strategy: str = "none",
+                               ddp_pre_sharded: bool = False, optimizer_state_path: Optional[str] = None
+                               ) -> Tuple[Any, Dict[str, Any]]:
+    if samples.num_samples <= 0:
+        return model, {"epoch_stats": [], "num_samples": 0}
+    strategy, dev, rank, world = _resolve_strategy(parallel_strategy, device)
+    train_model = _wrap(model, strategy, dev)
     global_n = int(samples.num_samples)
     t0 = time.perf_counter()
     sl = slice(rank, None, world) if (strategy == "ddp" and world > 1 and not ddp_pre_sharded) else slice(None)
@@ -86,17 +189,7 @@ def train_network_from_tensors(model, samples: TensorSelfPlayBatch, *, batch_siz
             raise RuntimeError("DDP received no local samples on one rank. Increase self-play samples or reduce world size.")
         return model, {"epoch_stats": [], "num_samples": 0}
 
-    optimizer = optim.Adam(model.parameters(), lr=lr, weight_decay=weight_decay)
-    opt_loaded, opt_err = False, None
-    if optimizer_state_path and os.path.exists(optimizer_state_path):
-        try:
-            optimizer.load_state_dict(torch.load(optimizer_state_path, map_location=dev))
-            for pg in optimizer.param_groups:
-                pg["lr"] = float(lr)
-                pg["initial_lr"] = float(lr)
-            opt_loaded = True
-        except Exception as exc:   # fresh Adam, like the reference
-            opt_err = repr(exc)
+    optimizer, opt_loaded, opt_err = _make_optimizer(model, lr, weight_decay, optimizer_state_path, dev)
     amp = bool(use_amp)
     scaler = torch.amp.GradScaler("cuda", enabled=True) if amp else None
     alpha = float(max(0.0, min(1.0, soft_label_alpha)))
@@ -117,76 +210,27 @@ def train_network_from_tensors(model, samples: TensorSelfPlayBatch, *, batch_siz
     lr_start = float(optimizer.param_groups[0]["lr"])
     epoch_stats: List[Dict[str, Any]] = []
     first_batch_sec, first_done = 0.0, False
+    stepper = _Stepper(model, train_model, optimizer, scheduler, scaler, amp=amp, alpha=alpha,
+                       anti_draw=float(anti_draw_penalty), draw_w=draw_w, grad_clip_norm=grad_clip_norm,
+                       ddp=strategy == "ddp", dev=dev)
     for epoch in range(n_epochs):
         perm = torch.randperm(n, device=dev)
-        acc = torch.zeros(9, dtype=torch.float64, device=dev)   # loss, policy*w, value, bucket, aux, seen, wsum, valid, |soft|
-        mix_abs_sum, batches, skip_loss, skip_grad = 0.0, 0, 0, 0
+        stepper.reset()
         for step_idx in range(synced):
             start = step_idx * bsz
             if start >= n:
                 break
             tb = time.perf_counter()
             idx = perm[start:min(start + bsz, n)]
-            b_states, b_masks, b_policy = states.index_select(0, idx), masks.index_select(0, idx), policy.index_select(0, idx)
-            b_values, b_soft = values.index_select(0, idx), soft.index_select(0, idx)
-            optimizer.zero_grad(set_to_none=True)
-            with (torch.amp.autocast("cuda", enabled=True) if amp else nullcontext()):
-                lp1, lp2, lpm, vlogits = train_model(b_states)
-            loss, parts = fused_policy_value_loss(lp1, lp2, lpm, vlogits, b_masks, b_policy, b_values, b_soft,
-                                                  soft_label_alpha=alpha, anti_draw_penalty=float(anti_draw_penalty),
-                                                  policy_draw_weight=draw_w)
-            if not _all_ranks_true(bool(torch.isfinite(loss).item()), strategy == "ddp", dev):
-                skip_loss += 1
-                optimizer.zero_grad(set_to_none=True)
-                continue
-            if scaler is not None:
-                scaler.scale(loss).backward()
-                scaler.unscale_(optimizer)
-            else:
-                loss.backward()
-            grads_ok = all(p.grad is None or bool(torch.isfinite(p.grad).all().item()) for p in model.parameters())
-            if not _all_ranks_true(grads_ok, strategy == "ddp", dev):
-                skip_grad += 1
-                optimizer.zero_grad(set_to_none=True)
-                if scaler is not None:
-                    scaler.update()
-                continue
-            torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=float(grad_clip_norm))
-            if scaler is not None:
-                scaler.step(optimizer)
-                scaler.update()
-            else:
-                optimizer.step()
-            scheduler.step()
-            cnt = float(idx.numel())
-            draw = b_values.abs() < 1e-8
-            wsum = torch.where(draw, draw_w, 1.0).sum()
-            v_used = (torch.where(draw, torch.full_like(b_values, float(anti_draw_penalty)), b_values)
-                      if abs(float(anti_draw_penalty)) > 1e-9 else b_values)
-            mixed = ((1.0 - alpha) * v_used + alpha * b_soft).clamp(-1.0, 1.0)
-            acc += torch.stack([loss.detach() * cnt, parts["policy_loss"] * wsum,
-                                parts["bucket_value_loss"] * cnt, parts["bucket_value_loss"] * cnt,
-                                parts["wdl_aux_loss"] * cnt, torch.tensor(cnt, device=dev), wsum,
-                                (b_policy.sum(dim=1) > 1e-8).sum(), b_soft.abs().mean()]).to(torch.float64)
-            mix_abs_sum += float(mixed.abs().mean().item())
-            batches += 1
+            stepper.step(states.index_select(0, idx), masks.index_select(0, idx), policy.index_select(0, idx),
+                         values.index_select(0, idx), soft.index_select(0, idx))
             if not first_done:
                 first_batch_sec, first_done = time.perf_counter() - tb, True
-        red = torch.cat([acc, torch.tensor([mix_abs_sum, float(batches), float(skip_loss), float(skip_grad)],
-                                           dtype=torch.float64, device=dev)])
-        if strategy == "ddp":
-            dist.all_reduce(red, op=dist.ReduceOp.SUM)
-        r = red.tolist()
-        seen = int(round(r[5]))
-        epoch_stats.append({
-            "epoch": epoch + 1, "avg_loss": r[0] / max(1, seen), "avg_policy_loss": r[1] / max(1e-8, r[6]),
-            "avg_value_loss": r[2] / max(1, seen), "avg_value_bucket_loss": r[3] / max(1, seen),
-            "avg_wdl_aux_loss": r[4] / max(1, seen), "samples": seen, "valid_policy_samples": int(round(r[7])),
-            "policy_weight_sum": r[6], "soft_alpha": alpha, "avg_soft_abs": r[8] / max(1, int(round(r[10]))),
-            "avg_mix_abs": r[9] / max(1, int(round(r[10]))), "parallel_strategy": strategy, "ddp_world_size": world,
-            "local_batch_count": int(local_batches), "synced_batch_count": int(synced),
-            "dropped_samples_for_sync": int(dropped), "skipped_non_finite_loss_batches": int(round(r[11])),
-            "skipped_non_finite_grad_batches": int(round(r[12])), "filtered_non_finite_samples": filtered})
+        st, _ = stepper.epoch_stats(epoch + 1, {"parallel_strategy": strategy, "ddp_world_size": world,
+                                                "local_batch_count": int(local_batches), "synced_batch_count": int(synced),
+                                                "dropped_samples_for_sync": int(dropped),
+                                                "filtered_non_finite_samples": filtered})
+        epoch_stats.append(st)
     lr_final = float(optimizer.param_groups[0]["lr"])
     if optimizer_state_path and (strategy != "ddp" or rank == 0):
         try:
@@ -203,3 +247,97 @@ def train_network_from_tensors(model, samples: TensorSelfPlayBatch, *, batch_siz
         "wdl_aux_loss_weight": 0.0, "warmup_steps": int(warm), "total_train_steps": int(total_steps),
         "timing": {"cpu_shard_sec": float(shard_sec), "h2d_copy_sec": float(copy_sec),
                    "first_batch_sec": float(first_batch_sec), "ddp_pre_sharded": bool(ddp_pre_sharded)}}
+
+
+def train_network_streaming(model, dataloader, *, total_samples: int, batch_size: int = 512, epochs: int = 1,
+                            lr: float = 1e-3, weight_decay: float = 1e-4, soft_label_alpha: float = 0.0,
+                            anti_draw_penalty: float = 0.0, policy_draw_weight: float = 1.0, device: str = "cuda:0",
+                            use_amp: bool = True, grad_clip_norm: float = 1.0, warmup_steps: int = 0,
+                            parallel_devices: Optional[List[str]] = None, parallel_strategy: str = "none",
+                            optimizer_state_path: Optional[str] = None, streaming_workers: int = 8
+                            ) -> Tuple[Any, Dict[str, Any]]:
+    """Train from an iterable of (states, masks, policy, values, soft) batches -- `streaming.build_streaming_dataloader`
+    over the shards of a self-play manifest -- mirroring `v1/python/train_bridge.py:547-900`: the number of steps per
+    epoch is fixed up front from `total_samples` (synchronised with MIN over DDP ranks), an exhausted loader turns the
+    remaining steps into no-ops that still take part in the rank votes, non-finite rows are dropped per batch."""
+    strategy, dev, rank, world = _resolve_strategy(parallel_strategy, device)
+    train_model = _wrap(model, strategy, dev)
+    bsz = max(1, int(batch_size))
+    est = max(1, (int(total_samples) + bsz - 1) // bsz)
+    if strategy == "ddp" and world > 1:
+        tok = torch.tensor([est], dtype=torch.int64, device=dev)
+        dist.all_reduce(tok, op=dist.ReduceOp.MIN)
+        est = max(1, int(tok.item()))
+    n_epochs = max(1, int(epochs))
+    total_steps = est * n_epochs
+    warm = min(max(0, int(warmup_steps)), total_steps // 2)
+    optimizer, opt_loaded, opt_err = _make_optimizer(model, lr, weight_decay, optimizer_state_path, dev)
+    amp = bool(use_amp)
+    scaler = torch.amp.GradScaler("cuda", enabled=True) if amp else None
+    scheduler = torch.optim.lr_scheduler.LambdaLR(
+        optimizer, lambda step: (step + 1) / max(1, warm) if (warm > 0 and step < warm) else 1.0)
+    lr_start = float(optimizer.param_groups[0]["lr"])
+    alpha = float(max(0.0, min(1.0, soft_label_alpha)))
+    stepper = _Stepper(model, train_model, optimizer, scheduler, scaler, amp=amp, alpha=alpha,
+                       anti_draw=float(anti_draw_penalty), draw_w=float(max(0.0, policy_draw_weight)),
+                       grad_clip_norm=grad_clip_norm, ddp=strategy == "ddp", dev=dev)
+    epoch_stats: List[Dict[str, Any]] = []
+    first_batch_sec, first_done = 0.0, False
+    total_filtered, seen_all = 0, 0
+    for epoch in range(n_epochs):
+        stepper.reset()
+        it = iter(dataloader)
+        exhausted, exhausted_steps, batches = False, 0, 0
+        for _ in range(est):
+            tb = time.perf_counter()
+            batch = None
+            if not exhausted:
+                try:
+                    batch = next(it)
+                except StopIteration:
+                    exhausted = True
+            if batch is None:
+                exhausted_steps += 1
+                _all_ranks_true(False, strategy == "ddp", dev)          # keep the rank votes aligned
+                batches += 1
+                continue
+            b_states = batch[0].to(dev, non_blocking=True).float()
+            b_masks = batch[1].to(dev, non_blocking=True).bool()
+            b_policy = batch[2].to(dev, non_blocking=True).float()
+            b_values = batch[3].to(dev, non_blocking=True).float().view(-1)
+            b_soft = batch[4].to(dev, non_blocking=True).float().view(-1)
+            finite = torch.isfinite(b_values) & torch.isfinite(b_soft) & torch.isfinite(b_policy).all(dim=1) & \
+                torch.isfinite(b_states.view(b_states.size(0), -1)).all(dim=1)
+            n_bad = int((~finite).sum().item())
+            if n_bad:
+                total_filtered += n_bad
+                keep = torch.nonzero(finite).view(-1)
+                if int(keep.numel()) == 0:
+                    _all_ranks_true(False, strategy == "ddp", dev)
+                    batches += 1
+                    continue
+                b_states, b_masks, b_policy, b_values, b_soft = (t.index_select(0, keep) for t in
+                                                                 (b_states, b_masks, b_policy, b_values, b_soft))
+            stepper.step(b_states, b_masks, b_policy, b_values, b_soft)
+            batches += 1
+            if not first_done:
+                first_batch_sec, first_done = time.perf_counter() - tb, True
+        st, more = stepper.epoch_stats(epoch + 1, {"parallel_strategy": strategy, "ddp_world_size": world,
+                                                   "batches_this_epoch": int(batches)}, [float(exhausted_steps)])
+        st["dataloader_exhausted_steps"] = int(round(more[0])) if more else int(exhausted_steps)
+        seen_all += st["samples"]
+        epoch_stats.append(st)
+    lr_final = float(optimizer.param_groups[0]["lr"])
+    if optimizer_state_path and (strategy != "ddp" or rank == 0):
+        try:
+            torch.save(optimizer.state_dict(), optimizer_state_path)
+        except Exception:
+            pass
+    return model, {
+        "epoch_stats": epoch_stats, "num_samples": int(total_samples), "num_samples_seen": int(seen_all),
+        "filtered_non_finite_samples": int(total_filtered), "parallel_strategy": strategy, "ddp_world_size": world,
+        "est_batches_per_epoch": int(est), "optimizer_loaded": opt_loaded, "optimizer_load_error": opt_err,
+        "optimizer_lr_start": lr_start, "optimizer_lr_final": lr_final, "device": str(dev), "device_fallback_count": 0,
+        "device_fallback_reasons": [], "anti_draw_penalty": float(anti_draw_penalty), "wdl_aux_loss_weight": 0.0,
+        "warmup_steps": int(warm), "total_train_steps": int(total_steps), "streaming": True,
+        "streaming_workers": int(streaming_workers), "timing": {"first_batch_sec": float(first_batch_sec)}}

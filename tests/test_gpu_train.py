@@ -132,3 +132,34 @@ def test_compact_trajectory_records_round_trip_exactly():
         pack_batch(broken)
     assert pack_batch(TensorSelfPlayBatch(batch.state_tensors[:0], batch.legal_masks[:0], batch.policy_targets[:0],
                                           batch.value_targets[:0], batch.soft_value_targets[:0])).shape == (0, RECORD_BYTES)
+
+
+def test_streaming_trainer_from_shard_files(tmp_path):
+    """Self-play stage output on disk -> resolve_shard_specs -> streaming DataLoader -> train_network_streaming."""
+    _need_gpu()
+    from liuzhou_amd import self_play_stage as S
+    from liuzhou_amd.net import ChessNet, MODEL_CONFIGS, stable_resnet_init
+    from liuzhou_amd.net_hip import FusedNet
+    from liuzhou_amd.self_play_gpu_runner import self_play_v1_gpu
+    from liuzhou_amd.streaming import build_streaming_dataloader
+    from liuzhou_amd.train_bridge import train_network_streaming
+    torch.manual_seed(0)
+    model = ChessNet(**MODEL_CONFIGS["b6c64"])
+    stable_resnet_init(model, 20260314)
+    model.to(DEV).eval()
+    batch, _ = self_play_v1_gpu(FusedNet(model), num_games=48, mcts_simulations=8, temperature_init=1.0,
+                                temperature_final=0.1, temperature_threshold=10, exploration_weight=1.0, device=DEV,
+                                max_game_plies=40, concurrent_games=48)
+    path = str(tmp_path / "selfplay_iter_001.pt")
+    S.save_sharded(path=path, samples=batch, stats_payload={}, metadata={}, num_shards=3)
+    specs, total = S.resolve_shard_specs(path, [], 0)
+    assert total == batch.num_samples == 48 * 40
+    dl = build_streaming_dataloader(specs, batch_size=256, num_workers=0, pin_memory=False)
+    model, m = train_network_streaming(model, dl, total_samples=total, batch_size=256, epochs=3, lr=2e-3, device=DEV,
+                                       warmup_steps=2, soft_label_alpha=0.2)
+    es = m["epoch_stats"]
+    assert len(es) == 3 and es[-1]["avg_loss"] < es[0]["avg_loss"]
+    assert m["streaming"] is True and m["est_batches_per_epoch"] == (total + 255) // 256
+    # shards end on partial batches, so the loader yields more (smaller) batches than the estimate: no step is a no-op
+    assert all(e["dataloader_exhausted_steps"] == 0 for e in es)
+    assert es[0]["samples"] + 0 <= total

@@ -160,3 +160,24 @@ def test_stage_cli_parses_the_reference_command_line():
                       "--self_play_stats_json", "out/sp.json", "--self_play_shard_dir", "/dev/shm/x"])
     assert args.devices == "cuda:0,cuda:1" and args.self_play_games == 4096 and args.self_play_iteration_seed == 3
     assert args.ignored == ["--train_devices", "cuda:0", "--infer_devices", "cuda:0"]
+
+
+def test_streaming_dataset_covers_every_sample_and_honours_budgets(tmp_path):
+    from liuzhou_amd.streaming import StreamingSelfPlayDataset, build_streaming_dataloader
+    out, _, manifest = _run(tmp_path, True)
+    specs, total = S.resolve_shard_specs(out, [], 0)
+    ds = StreamingSelfPlayDataset(specs, batch_size=16, epoch_seed=3)
+    seen = [b for b in ds]
+    assert sum(int(b[0].shape[0]) for b in seen) == total == 23 * 7
+    assert all(b[0].shape[1:] == (11, 6, 6) and b[1].dtype == torch.bool and b[2].shape[1] == 220 for b in seen)
+    want, _, _ = S.load_self_play_payload(out)
+    got = torch.cat([b[2] for b in seen]).sum(1).sort().values
+    assert torch.allclose(got, want.policy_targets.sum(1).sort().values)       # same multiset of rows
+    second = [b for b in ds]                                                    # next epoch: reshuffled, cached shards
+    assert sum(int(b[0].shape[0]) for b in second) == total
+    # replay budget: the old payload contributes at most 40 of its samples
+    specs_r, total_r = S.resolve_shard_specs(out, [out], 40)
+    n = sum(int(b[0].shape[0]) for b in StreamingSelfPlayDataset(specs_r, batch_size=32))
+    assert n == total_r == 23 * 7 + 40
+    dl = build_streaming_dataloader(specs, batch_size=64, num_workers=2, pin_memory=False)
+    assert sum(int(b[0].shape[0]) for b in dl) == total
