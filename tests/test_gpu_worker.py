@@ -102,3 +102,39 @@ def test_staged_loop_single_process(tmp_path):
     assert len(out["iterations"]) == 2 and out["iterations"][0]["positions"] == 64 * 40
     assert out["iterations"][1]["train_samples"] > 0 and out["steady_state_positions_per_sec"] > 0
     assert out["iterations"][1]["avg_loss"] is not None
+
+
+def test_one_full_iteration_selfplay_train_eval_through_the_clis(tmp_path):
+    """selfplay_stage.py -> train_stage.py (streaming) -> eval_arena.py: the three stages of one big_train_v1 iteration."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    run = lambda *cmd: subprocess.run([sys.executable, *cmd], capture_output=True, text=True, timeout=600)
+    sp = tmp_path / "selfplay_iter_001.pt"
+    r = run(os.path.join(root, "scripts", "selfplay_stage.py"), "--devices", "cuda:0", "--self_play_games", "48",
+            "--mcts_simulations", "8", "--model", "b6c64", "--self_play_concurrent_games", "48", "--max_game_plies", "40",
+            "--self_play_output", str(sp), "--self_play_chunk_target_bytes", "2000000")
+    assert r.returncode == 0, r.stdout + r.stderr
+    ck_dir = tmp_path / "ck"
+    metrics = tmp_path / "train.json"
+    r = run(os.path.join(root, "scripts", "train_stage.py"), "--stage", "train", "--self_play_input", str(sp),
+            "--streaming_load", "1", "--streaming_workers", "2", "--batch_size", "256", "--epochs", "2", "--lr", "0.002",
+            "--model", "b6c64", "--checkpoint_dir", str(ck_dir), "--checkpoint_name", "model_iter_001.pt",
+            "--metrics_output", str(metrics), "--optimizer_state_path", str(tmp_path / "adam.pt"), "--train_devices", "cuda:0")
+    assert r.returncode == 0, r.stdout + r.stderr
+    m = json.load(open(metrics))[0]
+    assert m["streaming"] is True and m["train_avg_loss"] is not None and os.path.exists(m["checkpoint"])
+    es = m["train_bridge"]["epoch_stats"]
+    assert es[-1]["avg_loss"] < es[0]["avg_loss"] and es[0]["samples"] > 0
+    ck = torch.load(ck_dir / "model_iter_001.pt", map_location="cpu", weights_only=False)
+    assert "model_state_dict" in ck and os.path.exists(tmp_path / "adam.pt")
+    ev = tmp_path / "eval.json"
+    r = run(os.path.join(root, "scripts", "eval_arena.py"), "--challenger_checkpoint", str(ck_dir / "model_iter_001.pt"),
+            "--eval_games_vs_random", "16", "--mcts_simulations", "8", "--output_json", str(ev), "--seed", "1")
+    assert r.returncode == 0, r.stdout + r.stderr
+    e = json.load(open(ev))
+    assert e["vs_random"]["total_games"] == 16
