@@ -199,6 +199,12 @@ LZ_API int lz_net_forward_f16(const LzNetDesc* net, const float* planes, int64_t
 LZ_API int lz_net_forward_packed_f16(const LzNetDesc* net, const void* packed_states, int64_t batch,
                                      float* log_p1, float* log_p2, float* log_pmc,
                                      float* value_logits, float* value, void* stream);
+/* In both entry points log_p1 / log_p2 / log_pmc may all be NULL (values only: the policy head is skipped; `value`
+ * is then required).  The `_counted` form takes the batch size from device memory (`*count`, clamped to `capacity`),
+ * so that a producer kernel can size the batch without a host round trip (fused root search, lz_root_prepare). */
+LZ_API int lz_net_forward_packed_counted_f16(const LzNetDesc* net, const void* packed_states, int64_t capacity,
+                                             const int64_t* count, float* log_p1, float* log_p2, float* log_pmc,
+                                             float* value_logits, float* value, void* stream);
 /* one-time kernel attribute setup (dynamic LDS size); call once per process before graph capture */
 LZ_API int lz_net_configure(void);
 /* measurement aid (bench.py): when enabled every lz_net_forward_f16 launch is bracketed by HIP events on
@@ -282,6 +288,27 @@ LZ_API int lz_tree_finish(const LzTreeDesc* tree, const float* temperatures, con
 LZ_API int lz_tree_search(const LzTreeDesc* tree, const LzNetDesc* net, int64_t sims, float* planes /*[B,11,36]*/,
                           float* log_p1, float* log_p2, float* log_pmc, float* values, const float* noise,
                           int64_t noise_stride, float epsilon, void* stream);
+/* ---- fused root-PUCT search (variant R) on packed states -------------------------------------------------
+ * The host chain of v1/python/mcts_gpu.py:1249-1457 (encode -> project -> root_pack -> noise -> apply -> evaluate
+ * children -> perspective / terminal / soft value -> leaf matrix) as two fixed-shape kernels around the network
+ * launches; afterwards lz_root_puct_allocate_visits / lz_root_finalize_from_visits run on the padded [B,72] rows
+ * (valid_root_indices = 0..B-1).  No host synchronisation anywhere: the whole search is graph-capturable.
+ *   lz_root_prepare: per root -- legal set (tensor semantics), masked softmax of the combined head logits, rows packed
+ *     left to 72 slots (legal_index_mat int64, priors_mat renormalised, action_code_mat int32x4, valid_mask, counts,
+ *     terminal_mask = no legal action), optional Dirichlet mix (noise float32[B,72], per-row normalised, weight
+ *     epsilon, rows with > 1 action), leaf_mat zeroed, child states appended to child_states (packed records) with
+ *     child_ref = root*72 + slot; *n_children (device uint64, reset by the call) = number of children.
+ *   lz_root_collect: child values (network, child mover's view) -> leaf_mat in the parent's view; children whose
+ *     game is over get tanh(k * (black - white) / 18) from the parent's side instead. */
+LZ_API int lz_root_prepare(const void* root_states, int64_t batch, const float* log_p1, const float* log_p2,
+                           const float* log_pmc, const float* noise, float epsilon, int64_t* legal_index_mat,
+                           float* priors_mat, int32_t* action_code_mat, uint8_t* valid_mask, int32_t* counts,
+                           uint8_t* terminal_mask, float* leaf_mat, void* child_states, int32_t* child_ref,
+                           uint64_t* n_children, void* stream);
+LZ_API int lz_root_collect(const void* root_states, const void* child_states, const int32_t* child_ref,
+                           const float* child_values, const uint64_t* n_children, int64_t capacity,
+                           float soft_value_k, float* leaf_mat, void* stream);
+
 /* AdvanceRoots (src/mcts.py:577-592, portable_mcts.py:74-87, portable_mcts.cpp:739-769): after the host has
  * played `played_action[g]` (220-d index, -1: none) and refreshed root_state, promote that child to root and keep
  * its subtree (compacted in place) with its statistics.  Games with reset[g] != 0, inactive games, children that

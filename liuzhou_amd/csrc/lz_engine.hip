@@ -846,6 +846,146 @@ __global__ __launch_bounds__(kBlock) void tree_finish_kernel(Tree t, const float
     }
 }
 
+// =================================================================================================================
+// Fused root-PUCT search (variant R, v1/python/mcts_gpu.py:1249-1457) on packed states: the host op chain
+// encode -> project -> root_pack -> noise -> batch_apply_moves -> ... with data-dependent shapes and two host syncs
+// becomes two fixed-shape kernels around the network launches; rows are padded to 72 actions, children are appended
+// to one device-counted list that the network kernel consumes without a host round trip.
+// =================================================================================================================
+constexpr int kRootCap = 72;
+// butterfly sum in the order of the stand-alone operators (lz_ops.hip), so that the fused path reproduces
+// project_policy_logits_fast + root_pack_rows bit for bit
+__device__ __forceinline__ float bfly_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// one wave per root: legal set (tensor semantics, fast_legal_mask.cpp:134-418), masked softmax of the combined head
+// logits (project_policy_logits_fast.cpp:16-164), left-packed rows with renormalised priors (module.cpp:247-363),
+// optional Dirichlet mix (mcts_gpu.py:1329-1339), child states (fast_apply_moves semantics)
+__global__ __launch_bounds__(kBlock) void root_prepare_kernel(
+    const Packed* __restrict__ roots, int64_t B, const float* __restrict__ lp1, const float* __restrict__ lp2,
+    const float* __restrict__ lpm, const float* __restrict__ noise, float epsilon, int64_t* __restrict__ legal_index,
+    float* __restrict__ priors, int4* __restrict__ codes, uint8_t* __restrict__ valid, int32_t* __restrict__ counts,
+    uint8_t* __restrict__ terminal, float* __restrict__ leaf, Packed* __restrict__ child_states,
+    int32_t* __restrict__ child_ref, unsigned long long* __restrict__ n_children) {
+    const int lane = lane_id();
+    const int64_t g = (int64_t)blockIdx.x * kWavesPerBlock + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (g >= B) return;
+    const State s = unpack(roots[g]);
+    const Legal L = legal_actions(s, /*fallback_forced=*/1);
+    const int n = legal_count(L);
+    float h1 = 0.f, h2 = 0.f, hm = 0.f;
+    if (lane < kCells) { h1 = lp1[g * 36 + lane]; h2 = lp2[g * 36 + lane]; hm = lpm[g * 36 + lane]; }
+    float v[4]; bool lg[4]; int slot[4];
+    float mx = -INFINITY;
+    int base = 0;
+    bool fin = false;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int a = it * kWave + lane;
+        int from = 0, dest = 0, cell = 0;
+        bool dest_ok = false;
+        if (a >= 36 && a < 180) {
+            from = (a - 36) >> 2;
+            const int d = move_dest(from, (a - 36) & 3);
+            dest_ok = d >= 0;
+            dest = dest_ok ? d : 0;
+        } else if (a >= 180 && a < 216) cell = a - 180;
+        else if (a < 36) cell = a;
+        const float p1d = __shfl(h1, dest), p2f = __shfl(h2, from), p1c = __shfl(h1, cell), pmc = __shfl(hm, cell);
+        const float x = a < 36 ? p1c : a < 180 ? (dest_ok ? p2f + p1d : -INFINITY) : a < 216 ? pmc : 0.f;
+        lg[it] = a < 220 && legal_bit(L, a);
+        v[it] = lg[it] ? x : -INFINITY;
+        if (v[it] > mx) mx = v[it];
+        fin = fin || isfinite(v[it]);
+        const uint64_t bal = __ballot(lg[it]);
+        slot[it] = base + __popcll(bal & ((1ull << lane) - 1ull));
+        base += __popcll(bal);
+    }
+    const bool do_softmax = n > 0 && __ballot(fin) != 0ull;
+    mx = lzw::wave_max(mx);
+    float e[4], sum = 0.f;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) { e[it] = (v[it] == -INFINITY) ? 0.f : expf(v[it] - mx); sum += e[it]; }
+    sum = bfly_sum(sum);
+    float pr[4], part = 0.f;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) { pr[it] = do_softmax ? e[it] / sum : 0.f; if (lg[it]) part += pr[it]; }
+    const float denom = fmaxf(bfly_sum(part), 1e-8f);
+    float nz[4], nsum = 0.f;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        pr[it] = pr[it] / denom;
+        nz[it] = (noise != nullptr && lg[it] && slot[it] < kRootCap) ? noise[g * kRootCap + slot[it]] : 0.f;
+        nsum += nz[it];
+    }
+    if (noise != nullptr && n > 1) {
+        nsum = fmaxf(bfly_sum(nsum), 1e-8f);
+        const float keep = 1.0f - epsilon;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) pr[it] = keep * pr[it] + epsilon * (nz[it] / nsum);
+    }
+    // row padding, then the packed entries
+    for (int j = lane; j < kRootCap; j += kWave) {
+        legal_index[g * kRootCap + j] = -1;
+        priors[g * kRootCap + j] = 0.f;
+        codes[g * kRootCap + j] = make_int4(0, 0, 0, 0);
+        valid[g * kRootCap + j] = 0;
+        leaf[g * kRootCap + j] = 0.f;
+    }
+    unsigned long long cbase = 0;
+    if (lane == 0) {
+        counts[g] = n;
+        terminal[g] = n == 0 ? 1 : 0;
+        if (n > 0) cbase = atomicAdd(n_children, (unsigned long long)n);
+    }
+    cbase = ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(cbase >> 32)) << 32) |
+            (unsigned int)__builtin_amdgcn_readfirstlane((int)(cbase & 0xFFFFFFFFull));
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // padding stores precede the entry stores of other lanes
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        if (!lg[it] || slot[it] >= kRootCap) continue;
+        const int a = it * kWave + lane;
+        int kd, p, q2, ex;
+        index_to_code(s.phase, a, kd, p, q2, ex);
+        const int64_t o = g * kRootCap + slot[it];
+        legal_index[o] = a;
+        priors[o] = pr[it];
+        codes[o] = make_int4(kd, p, q2, ex);
+        valid[o] = 1;
+        State c = s;
+        apply(c, kd, p, q2);
+        child_states[cbase + slot[it]] = pack(c);
+        child_ref[cbase + slot[it]] = (int32_t)o;
+    }
+}
+
+// one lane per child: value from the parent's perspective, terminal children replaced by the soft material value
+// (mcts_gpu.py:1352-1380: _child_values_to_parent_perspective, _terminal_mask_from_next_state, _soft_tanh_from_board_black)
+__global__ __launch_bounds__(kBlock) void root_collect_kernel(const Packed* __restrict__ roots,
+                                                              const Packed* __restrict__ child_states,
+                                                              const int32_t* __restrict__ child_ref,
+                                                              const float* __restrict__ child_values,
+                                                              const unsigned long long* __restrict__ n_children,
+                                                              int64_t capacity, float soft_k, float* __restrict__ leaf) {
+    const int64_t n = (int64_t)(*n_children < (unsigned long long)capacity ? *n_children : (unsigned long long)capacity);
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        const int32_t ref = child_ref[i];
+        const State c = unpack(child_states[i]);
+        const int parent_player = ((roots[ref / kRootCap].w0 >> 53) & 1) ? -1 : 1;
+        float val = child_values[i];
+        if (c.player != parent_player) val = -val;
+        if (game_status(c) != 0) {
+            const float delta = (float)(popc(c.black) - popc(c.white)) / 18.0f;
+            val = tanhf(delta * soft_k) * (parent_player >= 0 ? 1.0f : -1.0f);
+        }
+        leaf[ref] = val;
+    }
+}
+
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 inline int st() { return hipGetLastError() == hipSuccess ? LZ_OK : LZ_ERR_LAUNCH; }
 
@@ -987,6 +1127,38 @@ static int tree_search_impl(const LzTreeDesc* d, const LzNetDesc* net, int64_t s
                                lp2, lpmc, values, nullptr, 0, 0.f);
         }
     }
+    return st();
+}
+
+int lz_root_prepare(const void* root_states, int64_t B, const float* lp1, const float* lp2, const float* lpmc,
+                    const float* noise, float epsilon, int64_t* legal_index_mat, float* priors_mat,
+                    int32_t* action_code_mat, uint8_t* valid_mask, int32_t* counts, uint8_t* terminal_mask,
+                    float* leaf_mat, void* child_states, int32_t* child_ref, uint64_t* n_children, void* stream) {
+    if (B < 0) return LZ_ERR_ARG;
+    if (B == 0) return LZ_OK;
+    if (!root_states || !lp1 || !lp2 || !lpmc || !legal_index_mat || !priors_mat || !action_code_mat || !valid_mask ||
+        !counts || !terminal_mask || !leaf_mat || !child_states || !child_ref || !n_children)
+        return LZ_ERR_ARG;
+    if (reinterpret_cast<uintptr_t>(action_code_mat) & 15) return LZ_ERR_ALIGN;
+    if (hipMemsetAsync(n_children, 0, sizeof(uint64_t), as_stream(stream)) != hipSuccess) return LZ_ERR_LAUNCH;
+    hipLaunchKernelGGL(root_prepare_kernel, dim3(gw(B)), dim3(kBlock), 0, as_stream(stream),
+                       reinterpret_cast<const Packed*>(root_states), B, lp1, lp2, lpmc, noise, epsilon, legal_index_mat,
+                       priors_mat, reinterpret_cast<int4*>(action_code_mat), valid_mask, counts, terminal_mask, leaf_mat,
+                       reinterpret_cast<Packed*>(child_states), child_ref,
+                       reinterpret_cast<unsigned long long*>(n_children));
+    return st();
+}
+
+int lz_root_collect(const void* root_states, const void* child_states, const int32_t* child_ref,
+                    const float* child_values, const uint64_t* n_children, int64_t capacity, float soft_value_k,
+                    float* leaf_mat, void* stream) {
+    if (capacity < 0) return LZ_ERR_ARG;
+    if (capacity == 0) return LZ_OK;
+    if (!root_states || !child_states || !child_ref || !child_values || !n_children || !leaf_mat) return LZ_ERR_ARG;
+    hipLaunchKernelGGL(root_collect_kernel, dim3(1024), dim3(kBlock), 0, as_stream(stream),
+                       reinterpret_cast<const Packed*>(root_states), reinterpret_cast<const Packed*>(child_states),
+                       child_ref, child_values, reinterpret_cast<const unsigned long long*>(n_children), capacity,
+                       soft_value_k, leaf_mat);
     return st();
 }
 

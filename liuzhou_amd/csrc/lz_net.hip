@@ -59,6 +59,7 @@ struct NetParams {
     int hf_gw, hf_w1, hf_w2, hf_out;   // offsets in halfs of the head FC fragments (gpool_linear, fc1, fc2, 3 out convs)
     int wfrag_bytes, fparams_bytes;
     int debug_stop;             // diagnostic builds only: leave the pass after phase k (0 = run everything)
+    const long long* n_dev;     // optional device-side batch size (<= the host-side capacity N)
     int blocks;
     // float-parameter offsets
     int stem_bias, blk0, trunk_a, trunk_b, head_bias, p_gwT, p_a2, p_b2, p_out, v_w1T, v_b1, v_w2T, v_b2;
@@ -399,6 +400,7 @@ __global__ __launch_bounds__(W * 64, 2) void net_forward_kernel(NetParams P, con
                                                             float* __restrict__ lp2, float* __restrict__ lpm,
                                                             float* __restrict__ vlogits, float* __restrict__ value) {
     using K = Cfg<C, S, W>;
+    if (P.n_dev != nullptr) { const long long nd = *P.n_dev; N = nd < N ? nd : N; }   // count produced on the device
     static_assert(K::CT == K::CG * K::CTW, "each wave owns 2 output-channel tiles");
     static_assert(K::NT % 9 == 0 && K::PG * K::CG == K::WAVES, "waves = cell groups x channel groups");
     static_assert(S * 32 <= K::THREADS, "global pooling uses 2 lanes per (sample, 4-channel group)");
@@ -572,7 +574,8 @@ __global__ __launch_bounds__(W * 64, 2) void net_forward_kernel(NetParams P, con
         }
         __syncthreads();
         if (P.debug_stop == 4) { if (lane == 0 && (acc[0][0][0] + x[0][0][0]) == 123.f) lp1[0] = 1.f; continue; }   // after head convs
-        // ---- policy head ----
+        // ---- policy head (skipped when the caller only wants values: lp1 == nullptr) ----
+        if (lp1 != nullptr) {
         if (ht0 < 4) store_head<C, S>(acc, lds, base, ht0, rf, P.head_bias, lane);
         __syncthreads();
         gpool64<C, S>(lds, tid_h);
@@ -629,6 +632,7 @@ __global__ __launch_bounds__(W * 64, 2) void net_forward_kernel(NetParams P, con
             if (lane_h < 36 && s < nvalid) (h == 0 ? lp1 : h == 1 ? lp2 : lpm)[(n0 + s) * 36 + lane_h] = v - lse;
         }
         __syncthreads();
+        }
         if (P.debug_stop == 5) { if (lane_h == 0 && x[0][0][0] == 123.f) lp1[0] = 1.f; continue; }   // after the policy head
         // ---- value head ----
         if (K::HP == 2) store_head<C, S>(x, lds, base, ht1 - 4, rf, P.head_bias + kHead, lane);
@@ -769,10 +773,13 @@ int lz_net_configure(void) {
 }
 
 static int net_forward_impl(const LzNetDesc* d, const float* planes, const uint64_t* packed, int64_t N, float* lp1,
-                            float* lp2, float* lpmc, float* value_logits, float* value, void* stream) {
+                            float* lp2, float* lpmc, float* value_logits, float* value, void* stream,
+                            const int64_t* n_dev = nullptr) {
     if (!d || N < 0) return LZ_ERR_ARG;
     if (N == 0) return LZ_OK;
-    if (!d->wfrag || !d->fparams || (!planes && !packed) || !lp1 || !lp2 || !lpmc) return LZ_ERR_ARG;
+    if (!d->wfrag || !d->fparams || (!planes && !packed)) return LZ_ERR_ARG;
+    const bool heads = lp1 && lp2 && lpmc;
+    if (!heads && (lp1 || lp2 || lpmc || !value)) return LZ_ERR_ARG;     // all three policy outputs, or values only
     if (d->blocks < 0 || d->blocks > 15 || d->num_layers != 2 + 2 * d->blocks) return LZ_ERR_ARG;
     if ((reinterpret_cast<uintptr_t>(d->wfrag) & 15) || (reinterpret_cast<uintptr_t>(d->fparams) & 15)) return LZ_ERR_ALIGN;
     NetParams P;
@@ -780,6 +787,7 @@ static int net_forward_impl(const LzNetDesc* d, const float* planes, const uint6
     P.fp = d->fparams;
     for (int i = 0; i < d->num_layers; ++i) P.layer_off[i] = d->layer_offsets[i];
     P.blocks = d->blocks;
+    P.n_dev = reinterpret_cast<const long long*>(n_dev);
     P.wfrag_bytes = (int)d->wfrag_bytes; P.fparams_bytes = (int)d->fparams_bytes;
     P.debug_stop = getenv("LZ_NET_DEBUG_STOP") ? atoi(getenv("LZ_NET_DEBUG_STOP")) : 0;
     P.hf_gw = d->head_frag_offsets[0]; P.hf_w1 = d->head_frag_offsets[1]; P.hf_w2 = d->head_frag_offsets[2];
@@ -815,6 +823,14 @@ int lz_net_forward_packed_f16(const LzNetDesc* d, const void* packed_states, int
                               float* lpmc, float* value_logits, float* value, void* stream) {
     return net_forward_impl(d, nullptr, reinterpret_cast<const uint64_t*>(packed_states), N, lp1, lp2, lpmc,
                             value_logits, value, stream);
+}
+
+int lz_net_forward_packed_counted_f16(const LzNetDesc* d, const void* packed_states, int64_t capacity,
+                                      const int64_t* count, float* lp1, float* lp2, float* lpmc, float* value_logits,
+                                      float* value, void* stream) {
+    if (!count) return LZ_ERR_ARG;
+    return net_forward_impl(d, nullptr, reinterpret_cast<const uint64_t*>(packed_states), capacity, lp1, lp2, lpmc,
+                            value_logits, value, stream, count);
 }
 
 }  // extern "C"

@@ -541,6 +541,13 @@ __global__ __launch_bounds__(kBlock) void root_finalize_kernel(
         sv += v;
         sw += w;
     }
+    {   // a row without any valid action (a terminal root in the padded layout of the fused search) keeps the fill
+        // kernel's defaults: zero policy, index -1, not valid
+        bool any = false;
+#pragma unroll
+        for (int j = 0; j < SLOTS; ++j) any = any || ok[j];
+        if (__ballot(any) == 0ull) return;
+    }
     psum = fmaxf(wave_sum(psum), 1e-8f);
     sv = wave_sum(sv);
     sw = wave_sum(sw);

@@ -1,0 +1,135 @@
+"""Fused root-PUCT search (variant R): the whole of `V1RootMCTS.search_batch` as a fixed-shape, sync-free sequence of
+launches on packed states -- pack, network (roots), `lz_root_prepare`, network (children, batch size read on the
+device, values only), `lz_root_collect`, `lz_root_puct_allocate_visits`, `lz_root_finalize_from_visits` -- captured in
+one hipGraph.  Same outputs as `V1RootMCTS.search_batch` (asserted against it in tests/test_gpu_selfplay.py)."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib as L
+from .mcts_gpu import GpuStateBatch, RootSearchBatchOutput, TOTAL_ACTION_DIM, encode_actions_fast, states_to_model_input
+from .net_hip import FusedNet
+
+CAP = 72
+
+
+class FusedRootSearch:
+    def __init__(self, net: FusedNet, num_games: int, num_simulations: int, device, exploration_weight: float = 1.0,
+                 add_dirichlet_noise: bool = True, dirichlet_alpha: float = 0.3, dirichlet_epsilon: float = 0.25,
+                 sample_moves: bool = True, soft_value_k: float = 2.0, use_graph: bool = True) -> None:
+        dev = torch.device(device)
+        if dev.type != "cuda":
+            raise RuntimeError("FusedRootSearch needs a HIP device (no CPU path)")
+        self.net, self.B, self.sims, self.device = net, int(num_games), max(1, int(num_simulations)), dev
+        self.c, self.add_noise = float(exploration_weight), bool(add_dirichlet_noise)
+        self.alpha, self.eps, self.sample_moves, self.soft_k = float(dirichlet_alpha), float(dirichlet_epsilon), bool(sample_moves), float(soft_value_k)
+        self.use_graph = bool(use_graph)
+        B = self.B
+        z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)
+        self.root_packed = z((B, 4), torch.int64)
+        self.lp1, self.lp2, self.lpm = (z((B, 36), torch.float32) for _ in range(3))
+        self.values = z((B,), torch.float32)
+        self.legal_index = z((B, CAP), torch.int64)
+        self.priors = z((B, CAP), torch.float32)
+        self.codes = z((B, CAP, 4), torch.int32)
+        self.valid = z((B, CAP), torch.uint8)
+        self.counts = z((B,), torch.int32)
+        self.terminal = z((B,), torch.uint8)
+        self.leaf = z((B, CAP), torch.float32)
+        self.child_states = z((B * CAP, 4), torch.int64)
+        self.child_ref = z((B * CAP,), torch.int32)
+        self.child_values = z((B * CAP,), torch.float32)
+        self.n_children = z((1,), torch.int64)
+        self.visits, self.value_sum = z((B, CAP), torch.float32), z((B, CAP), torch.float32)
+        self.puct_root_values = z((B,), torch.float32)
+        self.roots = torch.arange(B, dtype=torch.int64, device=dev)
+        self.temps = z((B,), torch.float32)
+        self.noise = z((B, CAP), torch.float32)
+        self.uniforms = z((B,), torch.float32)
+        self.policy_dense = z((B, TOTAL_ACTION_DIM), torch.float32)
+        self.chosen_idx = z((B,), torch.int64)
+        self.chosen_codes = z((B, 4), torch.int32)
+        self.chosen_valid = z((B,), torch.uint8)
+        self.root_value_vec = z((B,), torch.float32)
+        self._graphs = {}
+        self._evals_dev = z((1,), torch.int64)              # network evaluations so far, kept on the device
+
+    def _launch(self, add_noise: bool, sample: bool) -> None:
+        lib, st, B, p = L.lib(), L.stream_ptr(self.device), self.B, L.ptr
+        ck = L.check
+        ck(lib.lz_net_forward_packed_f16(C.byref(self.net.desc), p(self.root_packed), L.i64(B), p(self.lp1), p(self.lp2),
+                                         p(self.lpm), None, p(self.values), st), "net_forward_packed")
+        ck(lib.lz_root_prepare(p(self.root_packed), L.i64(B), p(self.lp1), p(self.lp2), p(self.lpm),
+                               p(self.noise) if add_noise else None, C.c_float(self.eps), p(self.legal_index), p(self.priors),
+                               p(self.codes), p(self.valid), p(self.counts), p(self.terminal), p(self.leaf),
+                               p(self.child_states), p(self.child_ref), p(self.n_children), st), "root_prepare")
+        ck(lib.lz_net_forward_packed_counted_f16(C.byref(self.net.desc), p(self.child_states), L.i64(B * CAP),
+                                                 p(self.n_children), None, None, None, None, p(self.child_values), st),
+           "net_forward_packed_counted")
+        ck(lib.lz_root_collect(p(self.root_packed), p(self.child_states), p(self.child_ref), p(self.child_values),
+                               p(self.n_children), L.i64(B * CAP), C.c_float(self.soft_k), p(self.leaf), st), "root_collect")
+        ck(lib.lz_root_puct_allocate_visits(p(self.priors), p(self.leaf), p(self.valid), L.i64(B), L.i64(CAP),
+                                            L.i64(self.sims), C.c_float(self.c), p(self.visits), p(self.value_sum),
+                                            p(self.puct_root_values), st), "root_puct")
+        ck(lib.lz_root_finalize_from_visits(p(self.legal_index), p(self.codes), p(self.valid), p(self.visits),
+                                            p(self.value_sum), p(self.roots), L.i64(B), L.i64(CAP), L.i64(B),
+                                            L.i64(TOTAL_ACTION_DIM), p(self.temps), p(self.uniforms) if sample else None,
+                                            p(self.policy_dense), p(self.chosen_idx), p(self.chosen_codes),
+                                            p(self.chosen_valid), p(self.root_value_vec), st), "root_finalize")
+
+    def search_batch(self, state: GpuStateBatch, *, temperatures: torch.Tensor, add_dirichlet_noise: Optional[bool] = None,
+                     injected_noise: Optional[torch.Tensor] = None, injected_uniforms: Optional[torch.Tensor] = None
+                     ) -> RootSearchBatchOutput:
+        B, dev = self.B, self.device
+        if int(state.batch_size) != B:
+            raise ValueError(f"FusedRootSearch was built for {B} games, got {int(state.batch_size)}")
+        add_noise = self.add_noise if add_dirichlet_noise is None else bool(add_dirichlet_noise)
+        ts = [t if t.is_contiguous() else t.contiguous() for t in state.tensors()]
+        with torch.cuda.device(dev):
+            L.check(L.lib().lz_pack_states(C.byref(L.soa(ts)), L.i64(B), L.ptr(self.root_packed), L.stream_ptr(dev)), "pack_states")
+        self.temps.copy_(temperatures.to(torch.float32).reshape(-1))
+        if add_noise:
+            if injected_noise is not None:
+                self.noise.zero_()
+                self.noise[:, : injected_noise.shape[1]].copy_(injected_noise.to(torch.float32))
+            else:
+                self.noise.copy_(torch._standard_gamma(torch.full((B, CAP), self.alpha, dtype=torch.float32, device=dev)))
+        sample = self.sample_moves
+        if sample:
+            self.uniforms.copy_(injected_uniforms.to(torch.float32) if injected_uniforms is not None
+                                else torch.rand((B,), dtype=torch.float32, device=dev))
+        key = (add_noise, sample)
+        with torch.cuda.device(dev):
+            if not self.use_graph:
+                self._launch(add_noise, sample)
+            else:
+                g = self._graphs.get(key)
+                if g is None:
+                    self._launch(add_noise, sample)                  # warm-up (idempotent: every buffer is rewritten)
+                    torch.cuda.synchronize(dev)
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        self._launch(add_noise, sample)
+                    self._graphs[key] = g
+                g.replay()
+        self._evals_dev.add_(self.n_children).add_(B)
+        has_root = self.counts > 0
+        root_values = torch.where(has_root, self.root_value_vec, self.values)
+        model_input = states_to_model_input(state)
+        legal_mask, _ = encode_actions_fast(state)
+        return RootSearchBatchOutput(
+            model_input=model_input, legal_mask=legal_mask, policy_dense=self.policy_dense, root_value=root_values,
+            terminal_mask=self.terminal.view(torch.bool), chosen_action_indices=self.chosen_idx,
+            chosen_action_codes=self.chosen_codes, chosen_valid_mask=self.chosen_valid.view(torch.bool))
+
+    @property
+    def leaf_evals(self) -> int:
+        """Root + child evaluations of all searches so far (one host read)."""
+        return int(self._evals_dev.item())
+
+    def children_evaluated(self) -> int:
+        """Number of child evaluations of the last search (host read: not for the hot loop)."""
+        return int(self.n_children.item())

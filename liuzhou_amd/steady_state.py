@@ -16,11 +16,21 @@ from .trajectory_buffer import TensorTrajectoryBuffer
 class SteadyStateRootSelfPlay:
     def __init__(self, model, num_games: int, config: V1RootMCTSConfig, device, *, temperature_init: float = 1.0,
                  temperature_final: float = 0.1, temperature_threshold: int = 10, max_game_plies: int = 512,
-                 arena_rows: Optional[int] = None, seed: int = 12345) -> None:
+                 arena_rows: Optional[int] = None, seed: int = 12345, fused_search: bool = True) -> None:
         self.dev = torch.device(device)
         self.B = int(num_games)
         self.cfg = config
         self.mcts = V1RootMCTS(model, config, self.dev)
+        # fixed population + fused network: the whole search as one captured, sync-free launch sequence
+        self.fused = None
+        if fused_search and hasattr(model, "desc") and config.child_eval_mode == "value_only" and int(config.sparse_ply) <= 1:
+            from .root_search_fused import FusedRootSearch
+            self.fused = FusedRootSearch(model, self.B, config.num_simulations, self.dev,
+                                         exploration_weight=config.exploration_weight,
+                                         add_dirichlet_noise=config.add_dirichlet_noise,
+                                         dirichlet_alpha=config.dirichlet_alpha,
+                                         dirichlet_epsilon=config.dirichlet_epsilon, sample_moves=config.sample_moves,
+                                         soft_value_k=config.soft_value_k)
         self.t_init, self.t_final, self.t_thr = float(temperature_init), float(temperature_final), int(temperature_threshold)
         self.max_plies = int(max_game_plies)
         self.states = GpuStateBatch.initial(self.dev, self.B)
@@ -36,6 +46,10 @@ class SteadyStateRootSelfPlay:
         self.games_finished = 0
         self.positions = 0
         self.outcome = torch.zeros((3,), dtype=torch.int64, device=self.dev)
+
+    @property
+    def leaf_evals(self) -> int:
+        return self.fused.leaf_evals if self.fused is not None else int(self.mcts._leaf_evals)
 
     def _reset_slots(self, slots: torch.Tensor) -> None:
         s = self.states
@@ -69,7 +83,7 @@ class SteadyStateRootSelfPlay:
 
     def step(self) -> None:
         temps = torch.where(self.plies < self.t_thr, self.t_init, self.t_final).to(torch.float32)
-        search = self.mcts.search_batch(self.states, temperatures=temps)
+        search = (self.fused or self.mcts).search_batch(self.states, temperatures=temps)
         rows = self.buffer.append_steps(search.model_input, search.legal_mask, search.policy_dense,
                                         self.states.current_player)
         self.step_index[self.all_idx, self.step_counts] = rows

@@ -357,7 +357,8 @@ class SteadyStateTreeSelfPlay:
         # reuse the population bookkeeping (states, plies, trajectory arena, preroll, reset)
         self.pop = SteadyStateRootSelfPlay(self.net, num_games, V1RootMCTSConfig(num_simulations=1), dev, seed=seed,
                                            temperature_init=temperature_init, temperature_final=temperature_final,
-                                           temperature_threshold=temperature_threshold, max_game_plies=max_game_plies)
+                                           temperature_threshold=temperature_threshold, max_game_plies=max_game_plies,
+                                           fused_search=False)
         self.dual_stream = bool(dual_stream and self.net.pack.channels == 64 and int(num_games) >= 2)
         if self.dual_stream:
             self.mcts = DualStreamTreeMCTS(self.net, num_games, sims, dev, exploration_weight=exploration_weight,

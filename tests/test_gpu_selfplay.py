@@ -79,3 +79,71 @@ def test_tree_self_play_runner_dual_stream_matches_contract():
         assert bool((batch.policy_targets[~batch.legal_masks] == 0).all())
         assert bool(torch.isfinite(batch.value_targets).all())
         assert stats.mcts_counters["leaf_eval_count"] == 65 * 13 * 30
+
+
+@pytest.mark.parametrize("sims,use_graph", [(1, False), (64, False), (200, True)])
+def test_fused_root_search_equals_operator_chain(sims, use_graph):
+    """FusedRootSearch (two fixed-shape kernels around the network launches, no host sync) == V1RootMCTS.search_batch
+    (the reference's operator chain) on mid-game and terminal positions: same policy, picks, masks, values."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from liuzhou_amd.mcts_gpu import V1RootMCTS, V1RootMCTSConfig
+    from liuzhou_amd.net import ChessNet, MODEL_CONFIGS
+    from liuzhou_amd.net_hip import FusedNet
+    from liuzhou_amd.root_search_fused import FusedRootSearch
+    from tests.golden_utils import states, FIELDS
+    from tests.tree_parity import to_gpu_batch
+    dev = "cuda:0"
+    torch.manual_seed(20260314)
+    net = FusedNet(ChessNet(**MODEL_CONFIGS["b6c64"]).eval().to(dev))
+    z = load("g1_rules.npz"); z2 = load("g2_edges.npz")
+    st = states(z, "s")
+    B = 700
+    idx = np.random.default_rng(sims).integers(0, st["board"].shape[0], B)
+    sub = {f: np.ascontiguousarray(np.asarray(st[f])[idx]) for f in FIELDS}
+    batch = to_gpu_batch(sub, dev)
+    # a few roots without any legal action (mark selection with nothing left to mark): terminal rows of the search
+    batch.phase[:5] = 2; batch.pending_marks_remaining[:5] = 0
+    cfg = V1RootMCTSConfig(num_simulations=sims, exploration_weight=1.25, add_dirichlet_noise=False, sample_moves=False)
+    ref = V1RootMCTS(model=net, config=cfg, device=torch.device(dev))
+    temps = torch.where(torch.arange(B, device=dev) % 2 == 0, 1.0, 0.1)
+    a = ref.search_batch(batch, temperatures=temps)
+    fused = FusedRootSearch(net, B, sims, dev, exploration_weight=1.25, add_dirichlet_noise=False, sample_moves=False,
+                            use_graph=use_graph)
+    for rep in range(2):                                   # second call replays the graph
+        b = fused.search_batch(batch, temperatures=temps)
+        assert torch.equal(a.terminal_mask, b.terminal_mask) and bool(a.terminal_mask[:5].all())
+        assert torch.equal(a.chosen_valid_mask, b.chosen_valid_mask)
+        assert torch.equal(a.chosen_action_indices, b.chosen_action_indices)
+        assert torch.equal(a.chosen_action_codes, b.chosen_action_codes)
+        assert torch.equal(a.policy_dense, b.policy_dense)
+        assert torch.allclose(a.root_value, b.root_value, atol=1e-6)
+        assert torch.equal(a.legal_mask, b.legal_mask) and torch.equal(a.model_input, b.model_input)
+    assert fused.children_evaluated() == int(a.legal_mask.sum().item())
+
+
+def test_steady_state_root_population_fused_equals_operator_chain():
+    """The steady-state root-PUCT driver gives the same trajectory rows with the fused search as with the operator chain."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from liuzhou_amd.mcts_gpu import V1RootMCTSConfig
+    from liuzhou_amd.net import ChessNet, MODEL_CONFIGS
+    from liuzhou_amd.net_hip import FusedNet
+    from liuzhou_amd.steady_state import SteadyStateRootSelfPlay
+    dev = "cuda:0"
+    torch.manual_seed(20260314)
+    net = FusedNet(ChessNet(**MODEL_CONFIGS["b6c64"]).eval().to(dev))
+    cfg = V1RootMCTSConfig(num_simulations=32, add_dirichlet_noise=False, sample_moves=False)
+    pops = [SteadyStateRootSelfPlay(net, 300, cfg, dev, seed=5, max_game_plies=40, fused_search=f) for f in (True, False)]
+    assert pops[0].fused is not None and pops[1].fused is None
+    for p in pops:
+        p.preroll(30)
+        for _ in range(25):
+            p.step()
+    a, b = pops[0].buffer.build(), pops[1].buffer.build()
+    assert a.num_samples == b.num_samples == 300 * 25
+    assert torch.equal(a.state_tensors, b.state_tensors) and torch.equal(a.legal_masks, b.legal_masks)
+    assert torch.equal(a.policy_targets, b.policy_targets)
+    assert torch.equal(torch.nan_to_num(a.value_targets, nan=9.0), torch.nan_to_num(b.value_targets, nan=9.0))
+    assert pops[0].games_finished == pops[1].games_finished > 0
+    assert pops[0].leaf_evals == pops[1].leaf_evals
