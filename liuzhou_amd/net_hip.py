@@ -106,8 +106,13 @@ class FusedNet:
         return out
 
     def values_only(self, planes: torch.Tensor) -> torch.Tensor:
-        self(planes, want_logits=False)
-        return self.last_value
+        """Scalar values only: the kernel skips the policy head and writes nothing but `value`."""
+        L.require_hip(planes, "net_forward_f16")
+        x = planes if (planes.dtype == torch.float32 and planes.is_contiguous()) else planes.float().contiguous()
+        val = torch.empty((int(x.shape[0]),), dtype=torch.float32, device=x.device)
+        self.forward_into(x, None, None, None, None, val)
+        self.last_value = val
+        return val
 
 
 def _flops(C: int, NB: int) -> float:

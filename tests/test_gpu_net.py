@@ -55,3 +55,18 @@ def test_fused_net_matches_fp32_model(name, n, half):
         assert torch.allclose(got.exp().sum(1), torch.ones(n, device=DEV), atol=1e-4)
     assert (vl - rv).abs().max().item() < 3e-2
     assert (val - rval).abs().max().item() < 3e-3
+
+
+def test_values_only_mode_equals_full_forward():
+    """Skipping the policy head (log-prob outputs NULL) must not change the value output."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from liuzhou_amd.net import ChessNet, MODEL_CONFIGS
+    from liuzhou_amd.net_hip import FusedNet
+    for name, n in (("b6c64", 333), ("b10c128", 100)):
+        torch.manual_seed(3)
+        f = FusedNet(ChessNet(**MODEL_CONFIGS[name]).eval().to(DEV))
+        x = _planes(n, seed=1)
+        f(x)
+        full = f.last_value.clone()
+        assert torch.equal(f.values_only(x), full)
