@@ -304,7 +304,9 @@ LZ_API int lz_root_prepare(const void* root_states, int64_t batch, const float* 
                            const float* log_pmc, const float* noise, float epsilon, int64_t* legal_index_mat,
                            float* priors_mat, int32_t* action_code_mat, uint8_t* valid_mask, int32_t* counts,
                            uint8_t* terminal_mask, float* leaf_mat, void* child_states, int32_t* child_ref,
-                           uint64_t* n_children, void* stream);
+                           uint64_t* n_children, int64_t child_capacity /* records in child_states / child_ref,
+                           >= 72 * batch */, int32_t* overflow /* device counter of roots dropped because the list
+                           was full (0 in correct use), may be NULL */, void* stream);
 LZ_API int lz_root_collect(const void* root_states, const void* child_states, const int32_t* child_ref,
                            const float* child_values, const uint64_t* n_children, int64_t capacity,
                            float soft_value_k, float* leaf_mat, void* stream);

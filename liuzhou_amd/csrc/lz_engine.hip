@@ -861,6 +861,8 @@ __device__ __forceinline__ float bfly_sum(float v) {
     return v;
 }
 
+__global__ void zero_u64_kernel(unsigned long long* p) { if (threadIdx.x == 0) *p = 0ull; }
+
 // one wave per root: legal set (tensor semantics, fast_legal_mask.cpp:134-418), masked softmax of the combined head
 // logits (project_policy_logits_fast.cpp:16-164), left-packed rows with renormalised priors (module.cpp:247-363),
 // optional Dirichlet mix (mcts_gpu.py:1329-1339), child states (fast_apply_moves semantics)
@@ -869,7 +871,8 @@ __global__ __launch_bounds__(kBlock) void root_prepare_kernel(
     const float* __restrict__ lpm, const float* __restrict__ noise, float epsilon, int64_t* __restrict__ legal_index,
     float* __restrict__ priors, int4* __restrict__ codes, uint8_t* __restrict__ valid, int32_t* __restrict__ counts,
     uint8_t* __restrict__ terminal, float* __restrict__ leaf, Packed* __restrict__ child_states,
-    int32_t* __restrict__ child_ref, unsigned long long* __restrict__ n_children) {
+    int32_t* __restrict__ child_ref, unsigned long long* __restrict__ n_children, int64_t child_capacity,
+    int32_t* __restrict__ overflow) {
     const int lane = lane_id();
     const int64_t g = (int64_t)blockIdx.x * kWavesPerBlock + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (g >= B) return;
@@ -945,6 +948,12 @@ __global__ __launch_bounds__(kBlock) void root_prepare_kernel(
             (unsigned int)__builtin_amdgcn_readfirstlane((int)(cbase & 0xFFFFFFFFull));
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // padding stores precede the entry stores of other lanes
     __builtin_amdgcn_wave_barrier();
+    // the child list is sized for 72 children per root; a counter that was not reset (a caller bug) must not turn
+    // into out-of-bounds stores: the row is dropped (no valid action) and the overflow is reported
+    if ((int64_t)cbase + n > child_capacity) {
+        if (lane == 0 && overflow != nullptr) atomicAdd(overflow, 1);
+        return;
+    }
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
         if (!lg[it] || slot[it] >= kRootCap) continue;
@@ -1133,19 +1142,22 @@ static int tree_search_impl(const LzTreeDesc* d, const LzNetDesc* net, int64_t s
 int lz_root_prepare(const void* root_states, int64_t B, const float* lp1, const float* lp2, const float* lpmc,
                     const float* noise, float epsilon, int64_t* legal_index_mat, float* priors_mat,
                     int32_t* action_code_mat, uint8_t* valid_mask, int32_t* counts, uint8_t* terminal_mask,
-                    float* leaf_mat, void* child_states, int32_t* child_ref, uint64_t* n_children, void* stream) {
+                    float* leaf_mat, void* child_states, int32_t* child_ref, uint64_t* n_children,
+                    int64_t child_capacity, int32_t* overflow, void* stream) {
     if (B < 0) return LZ_ERR_ARG;
     if (B == 0) return LZ_OK;
     if (!root_states || !lp1 || !lp2 || !lpmc || !legal_index_mat || !priors_mat || !action_code_mat || !valid_mask ||
-        !counts || !terminal_mask || !leaf_mat || !child_states || !child_ref || !n_children)
+        !counts || !terminal_mask || !leaf_mat || !child_states || !child_ref || !n_children || child_capacity < 0)
         return LZ_ERR_ARG;
     if (reinterpret_cast<uintptr_t>(action_code_mat) & 15) return LZ_ERR_ALIGN;
-    if (hipMemsetAsync(n_children, 0, sizeof(uint64_t), as_stream(stream)) != hipSuccess) return LZ_ERR_LAUNCH;
+    // reset by a kernel, not hipMemsetAsync: a plain kernel node keeps stream order in every capture / replay mode
+    hipLaunchKernelGGL(zero_u64_kernel, dim3(1), dim3(64), 0, as_stream(stream),
+                       reinterpret_cast<unsigned long long*>(n_children));
     hipLaunchKernelGGL(root_prepare_kernel, dim3(gw(B)), dim3(kBlock), 0, as_stream(stream),
                        reinterpret_cast<const Packed*>(root_states), B, lp1, lp2, lpmc, noise, epsilon, legal_index_mat,
                        priors_mat, reinterpret_cast<int4*>(action_code_mat), valid_mask, counts, terminal_mask, leaf_mat,
                        reinterpret_cast<Packed*>(child_states), child_ref,
-                       reinterpret_cast<unsigned long long*>(n_children));
+                       reinterpret_cast<unsigned long long*>(n_children), child_capacity, overflow);
     return st();
 }
 

@@ -5,6 +5,7 @@ one hipGraph.  Same outputs as `V1RootMCTS.search_batch` (asserted against it in
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional
 
 import torch
@@ -26,7 +27,7 @@ class FusedRootSearch:
         self.net, self.B, self.sims, self.device = net, int(num_games), max(1, int(num_simulations)), dev
         self.c, self.add_noise = float(exploration_weight), bool(add_dirichlet_noise)
         self.alpha, self.eps, self.sample_moves, self.soft_k = float(dirichlet_alpha), float(dirichlet_epsilon), bool(sample_moves), float(soft_value_k)
-        self.use_graph = bool(use_graph)
+        self.use_graph = bool(use_graph) and os.environ.get("LZ_ROOT_GRAPH", "on").strip().lower() not in ("off", "0", "false")
         B = self.B
         z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)
         self.root_packed = z((B, 4), torch.int64)
@@ -43,6 +44,7 @@ class FusedRootSearch:
         self.child_ref = z((B * CAP,), torch.int32)
         self.child_values = z((B * CAP,), torch.float32)
         self.n_children = z((1,), torch.int64)
+        self.overflow = z((1,), torch.int32)
         self.visits, self.value_sum = z((B, CAP), torch.float32), z((B, CAP), torch.float32)
         self.puct_root_values = z((B,), torch.float32)
         self.roots = torch.arange(B, dtype=torch.int64, device=dev)
@@ -65,7 +67,8 @@ class FusedRootSearch:
         ck(lib.lz_root_prepare(p(self.root_packed), L.i64(B), p(self.lp1), p(self.lp2), p(self.lpm),
                                p(self.noise) if add_noise else None, C.c_float(self.eps), p(self.legal_index), p(self.priors),
                                p(self.codes), p(self.valid), p(self.counts), p(self.terminal), p(self.leaf),
-                               p(self.child_states), p(self.child_ref), p(self.n_children), st), "root_prepare")
+                               p(self.child_states), p(self.child_ref), p(self.n_children), L.i64(B * CAP),
+                               p(self.overflow), st), "root_prepare")
         ck(lib.lz_net_forward_packed_counted_f16(C.byref(self.net.desc), p(self.child_states), L.i64(B * CAP),
                                                  p(self.n_children), None, None, None, None, p(self.child_values), st),
            "net_forward_packed_counted")

@@ -27,7 +27,8 @@ def self_play_v1_gpu(model, num_games: int, mcts_simulations: int, temperature_i
                      sample_moves: bool = True, concurrent_games: int = 8, child_eval_mode: str = "value_only",
                      sparse_ply: int = 1, sparse_top_k: int = 8, inference_engine=None,
                      collect_step_timing: bool = False, verbose: bool = False,
-                     autocast_dtype: str = "float16") -> Tuple[TensorSelfPlayBatch, SelfPlayV1Stats]:
+                     autocast_dtype: str = "float16", fused_search: bool = True
+                     ) -> Tuple[TensorSelfPlayBatch, SelfPlayV1Stats]:
     if num_games <= 0:
         raise ValueError("num_games must be positive.")
     dev = torch.device(device)
@@ -43,6 +44,18 @@ def self_play_v1_gpu(model, num_games: int, mcts_simulations: int, temperature_i
     mcts = V1RootMCTS(model=model, config=cfg, device=dev, inference_engine=inference_engine,
                       collect_timing=bool(collect_step_timing))
     buffer = TensorTrajectoryBuffer(dev, TOTAL_ACTION_DIM, max_steps_hint=max_plies, concurrent_games_hint=wave)
+    # Fused search (root_search_fused.py): whole waves through one captured, sync-free launch sequence.  It needs the
+    # fused network, a fixed batch (finished games of the wave are searched too and their rows dropped) and none of
+    # the options only the operator chain implements.
+    fused = None
+    if (fused_search and hasattr(model, "desc") and inference_engine is None and opening_n == 0 and
+            str(child_eval_mode) == "value_only" and int(sparse_ply) <= 1 and not collect_step_timing and
+            int(num_games) % wave == 0):
+        from .root_search_fused import FusedRootSearch
+        fused = FusedRootSearch(model, wave, cfg.num_simulations, dev, exploration_weight=cfg.exploration_weight,
+                                add_dirichlet_noise=cfg.add_dirichlet_noise, dirichlet_alpha=cfg.dirichlet_alpha,
+                                dirichlet_epsilon=cfg.dirichlet_epsilon, sample_moves=cfg.sample_moves,
+                                soft_value_k=cfg.soft_value_k)
 
     outcome = torch.zeros((3,), dtype=torch.int64, device=dev)
     delta_hist = torch.zeros((_DELTA_MAX - _DELTA_MIN + 1,), dtype=torch.int64, device=dev)
@@ -83,8 +96,17 @@ def self_play_v1_gpu(model, num_games: int, mcts_simulations: int, temperature_i
             temps = torch.where(act_plies < int(temperature_threshold), float(temperature_init),
                                 float(temperature_final)).to(torch.float32)
             force = (act_plies < opening_n) if opening_n > 0 else None
-            search = mcts.search_batch(act_states, temperatures=temps, add_dirichlet_noise=add_dirichlet_noise,
-                                       force_uniform_random_mask=force)
+            if fused is not None:
+                full_temps = torch.where(plies < int(temperature_threshold), float(temperature_init),
+                                         float(temperature_final)).to(torch.float32)
+                search = fused.search_batch(states, temperatures=full_temps, add_dirichlet_noise=add_dirichlet_noise)
+                if n_active != g:
+                    search = type(search)(*(getattr(search, f).index_select(0, active) for f in (
+                        "model_input", "legal_mask", "policy_dense", "root_value", "terminal_mask",
+                        "chosen_action_indices", "chosen_action_codes", "chosen_valid_mask")))
+            else:
+                search = mcts.search_batch(act_states, temperatures=temps, add_dirichlet_noise=add_dirichlet_noise,
+                                           force_uniform_random_mask=force)
             rows = buffer.append_steps(search.model_input, search.legal_mask, search.policy_dense,
                                        act_states.current_player)
             step_index[active, step_counts.index_select(0, active)] = rows
@@ -131,7 +153,8 @@ def self_play_v1_gpu(model, num_games: int, mcts_simulations: int, temperature_i
         step_timing_ms={k: float(timing_ms[k]) for k in _TRACKED},
         step_timing_ratio={k: (float(timing_ms[k]) / total if total > 0 else 0.0) for k in _TRACKED},
         step_timing_calls={k: int(timing_calls[k]) for k in _TRACKED},
-        mcts_counters={k: int(v) for k, v in mt["counters"].items()},
+        mcts_counters={**{k: int(v) for k, v in mt["counters"].items()},
+                       **({"leaf_eval_count": int(fused.leaf_evals), "fused_root_search": 1} if fused is not None else {})},
         piece_delta_buckets={str(d): int(hist[d - _DELTA_MIN]) for d in range(_DELTA_MIN, _DELTA_MAX + 1)},
         device=str(dev))
     return batch, stats

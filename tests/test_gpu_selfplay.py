@@ -147,3 +147,24 @@ def test_steady_state_root_population_fused_equals_operator_chain():
     assert torch.equal(torch.nan_to_num(a.value_targets, nan=9.0), torch.nan_to_num(b.value_targets, nan=9.0))
     assert pops[0].games_finished == pops[1].games_finished > 0
     assert pops[0].leaf_evals == pops[1].leaf_evals
+
+
+def test_root_self_play_runner_fused_equals_operator_chain():
+    """self_play_v1_gpu: whole waves through the fused search give the same trajectories as the operator chain."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from liuzhou_amd.net import ChessNet, MODEL_CONFIGS
+    from liuzhou_amd.net_hip import FusedNet
+    from liuzhou_amd.self_play_gpu_runner import self_play_v1_gpu
+    torch.manual_seed(20260314)
+    net = FusedNet(ChessNet(**MODEL_CONFIGS["b6c64"]).eval().to("cuda:0"))
+    kw = dict(num_games=96, mcts_simulations=16, temperature_init=1.0, temperature_final=0.1, temperature_threshold=10,
+              exploration_weight=1.0, device="cuda:0", add_dirichlet_noise=False, sample_moves=False, max_game_plies=512,
+              concurrent_games=48)
+    a, sa = self_play_v1_gpu(net, fused_search=True, **kw)
+    b, sb = self_play_v1_gpu(net, fused_search=False, **kw)
+    assert sa.mcts_counters.get("fused_root_search") == 1 and "fused_root_search" not in sb.mcts_counters
+    assert a.num_samples == b.num_samples > 96 * 100
+    for k in ("state_tensors", "legal_masks", "policy_targets", "value_targets", "soft_value_targets"):
+        assert torch.equal(getattr(a, k), getattr(b, k)), k
+    assert (sa.black_wins, sa.white_wins, sa.draws) == (sb.black_wins, sb.white_wins, sb.draws)
