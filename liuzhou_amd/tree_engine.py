@@ -42,6 +42,20 @@ class LzTreeDesc(C.Structure):
 REUSE_EDGES_PER_NODE = 40      # arena sizing for kept subtrees (average fan-out is ~25; overflow drops the subtree)
 
 
+def auto_reuse_factor(num_games: int, sims: int, device, memory_fraction: float = 0.35, cap: float = 16.0) -> float:
+    """Room for kept subtrees, as a multiple of `sims` nodes per game: as much as fits in `memory_fraction` of the
+    device's free memory (a kept subtree that would leave no room for the next search is dropped, so more room = fewer
+    deviations from the reference's unbounded tree; measured on C2: 2 425 / 224 / 12 / 0 drops per 1.2 M moves at
+    factor 3 / 6 / 10 / 16), at most `cap` and at most what 16 384 nodes per game allow."""
+    free, _total = torch.cuda.mem_get_info(torch.device(device))
+    per_game = free * float(memory_fraction) / max(1, int(num_games))
+    base = (sims + 2) * 48 + (sims + 1) * MAX_CHILDREN * 32 + (sims + 3) * 4
+    per_factor = sims * (48 + REUSE_EDGES_PER_NODE * 32 + 4)
+    f = (per_game - base) / max(1, per_factor)
+    f = min(float(cap), f, (16384 - sims - 2) / max(1, sims))
+    return max(1.0, float(int(f * 4) / 4.0))
+
+
 class TreeEngine:
     def __init__(self, num_games: int, max_sims: int, device, exploration_weight: float = 1.0,
                  reuse_factor: float = 0.0) -> None:
@@ -51,6 +65,9 @@ class TreeEngine:
             raise RuntimeError("TreeEngine needs a HIP device (no CPU path)")
         self.device, self.B, self.max_sims = dev, int(num_games), int(max_sims)
         B = self.B
+        if float(reuse_factor) < 0:
+            reuse_factor = auto_reuse_factor(B, self.max_sims, dev)
+        self.reuse_factor = float(reuse_factor)
         extra = int(max(0.0, float(reuse_factor)) * self.max_sims)
         self.node_cap = self.max_sims + 2 + extra
         self.edge_cap = (self.max_sims + 1) * MAX_CHILDREN + extra * REUSE_EDGES_PER_NODE
@@ -192,11 +209,11 @@ class PortableTreeMCTS:
     def __init__(self, net: FusedNet, num_games: int, num_simulations: int, device, exploration_weight: float = 1.0,
                  add_dirichlet_noise: bool = True, dirichlet_alpha: float = 0.3, dirichlet_epsilon: float = 0.25,
                  sample_moves: bool = True, use_graph: Optional[bool] = None, reuse_tree: bool = False,
-                 reuse_factor: float = 3.0, policy_target_temperature: Optional[float] = None,
+                 reuse_factor: float = -1.0, policy_target_temperature: Optional[float] = None,
                  policy_target_prior_pseudocount: float = 0.0) -> None:
         """`reuse_tree`: keep the played child's subtree between consecutive search_batch calls on the same games
         (the reference's portable self-play does, v1/python/portable_self_play.py:191); the arenas then hold
-        (1 + reuse_factor) * sims nodes per game.  `policy_target_*`: portable_mcts.py:690-700."""
+        (1 + reuse_factor) * sims nodes per game (reuse_factor < 0: as much as a third of the free memory allows).  `policy_target_*`: portable_mcts.py:690-700."""
         self.net, self.sims = net, int(num_simulations)
         self.reuse_tree = bool(reuse_tree)
         self.engine = TreeEngine(num_games, num_simulations, device, exploration_weight,
@@ -348,7 +365,7 @@ class SteadyStateTreeSelfPlay:
     def __init__(self, model, num_games: int, sims: int, device, dtype: str = "float16", seed: int = 12345,
                  temperature_init: float = 1.0, temperature_final: float = 0.1, temperature_threshold: int = 10,
                  max_game_plies: int = 512, exploration_weight: float = 1.0, reuse_tree: bool = False,
-                 reuse_factor: float = 3.0, dual_stream: bool = False) -> None:
+                 reuse_factor: float = -1.0, dual_stream: bool = False) -> None:
         from .steady_state import SteadyStateRootSelfPlay
         from .mcts_gpu import V1RootMCTSConfig
         dev = torch.device(device)
@@ -405,7 +422,7 @@ def self_play_tree_gpu(model, num_games: int, mcts_simulations: int, temperature
                        sample_moves: bool = True, concurrent_games: int = 8, verbose: bool = False,
                        policy_target_temperature: Optional[float] = None,
                        policy_target_prior_pseudocount: float = 0.0, reuse_tree: bool = True,
-                       reuse_factor: float = 3.0, dual_stream: Optional[bool] = None
+                       reuse_factor: float = -1.0, dual_stream: Optional[bool] = None
                        ) -> Tuple[TensorSelfPlayBatch, SelfPlayV1Stats]:
     """Tree-search twin of self_play_v1_gpu (same outputs); mirrors v1/python/portable_self_play.py:82-284,
     including the subtree reuse it performs on every move (:191, `reuse_tree`)."""
