@@ -343,3 +343,17 @@ def test_tree_engine_degenerate_sizes():
     d.nodes = eng.desc.nodes
     d.node_cap = 70000
     assert L.lib().lz_tree_advance(C.byref(d), None, None, L.i64(4), None, None) == -1      # 16-bit owner ids
+
+
+def test_auto_reuse_factor_is_bounded_by_memory_and_node_limit():
+    _need_gpu()
+    from liuzhou_amd.tree_engine import TreeEngine, auto_reuse_factor
+    f_small = auto_reuse_factor(256, 200, DEV)
+    assert f_small == 16.0                                        # plenty of memory: the cap
+    assert auto_reuse_factor(256, 2000, DEV) <= (16384 - 2002) / 2000 + 1e-9     # 16 384 nodes per game at most
+    free, _ = torch.cuda.mem_get_info(torch.device(DEV))
+    games = int(free // (3 * 1024 * 1024))                        # ~3 MB of free memory per game
+    f_tight = auto_reuse_factor(games, 800, DEV)
+    assert 1.0 <= f_tight < 16.0
+    eng = TreeEngine(64, 50, DEV, reuse_factor=-1.0)
+    assert eng.reuse_factor == 16.0 and eng.node_cap == 50 + 2 + 16 * 50
