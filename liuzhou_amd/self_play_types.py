@@ -1,42 +1,45 @@
-"""Self-play statistics record (same fields and `to_dict` payload as v1/python/self_play_types.py:9-60)."""
+"""Self-play statistics record.  The field names and the `to_dict` payload are the interface the reference's
+stage scripts and manifest readers consume (v1/python/self_play_types.py:9-60); here one schema table drives
+both the dataclass and its serialiser, so a field cannot be added to one and forgotten in the other."""
 from __future__ import annotations
 
-from dataclasses import dataclass, field
-from typing import Any, Dict, Tuple
+from dataclasses import field, make_dataclass
+from typing import Any, Callable, Dict, Tuple
+
+_MISSING = object()
 
 
-@dataclass
-class SelfPlayV1Stats:
-    num_games: int
-    num_positions: int
-    black_wins: int
-    white_wins: int
-    draws: int
-    avg_game_length: float
-    elapsed_sec: float
-    positions_per_sec: float
-    games_per_sec: float
-    step_timing_ms: Dict[str, float]
-    step_timing_ratio: Dict[str, float]
-    step_timing_calls: Dict[str, int]
-    mcts_counters: Dict[str, int]
-    piece_delta_buckets: Dict[str, int]
-    policy_target_audit: Dict[str, Any] = field(default_factory=dict)
-    device: str = ""
-    fallback_count: int = 0
-    fallback_reasons: Tuple[str, ...] = ()
+def _floats(m) -> Dict[str, float]:
+    return {k: float(v) for k, v in m.items()}
 
-    def to_dict(self) -> Dict[str, object]:
-        d: Dict[str, object] = {k: float(getattr(self, k)) for k in (
-            "num_games", "num_positions", "black_wins", "white_wins", "draws", "avg_game_length", "elapsed_sec",
-            "positions_per_sec", "games_per_sec")}
-        d["step_timing_ms"] = {k: float(v) for k, v in self.step_timing_ms.items()}
-        d["step_timing_ratio"] = {k: float(v) for k, v in self.step_timing_ratio.items()}
-        d["step_timing_calls"] = {k: int(v) for k, v in self.step_timing_calls.items()}
-        d["mcts_counters"] = {k: int(v) for k, v in self.mcts_counters.items()}
-        d["piece_delta_buckets"] = {k: int(v) for k, v in self.piece_delta_buckets.items()}
-        d["policy_target_audit"] = dict(self.policy_target_audit or {})
-        d["device"] = str(self.device)
-        d["fallback_count"] = int(self.fallback_count)
-        d["fallback_reasons"] = list(self.fallback_reasons)
-        return d
+
+def _ints(m) -> Dict[str, int]:
+    return {k: int(v) for k, v in m.items()}
+
+
+# (name, annotation, serialiser, default factory or _MISSING)
+_SCHEMA: Tuple[Tuple[str, Any, Callable, Any], ...] = (
+    *((n, int, float, _MISSING) for n in ("num_games", "num_positions", "black_wins", "white_wins", "draws")),
+    *((n, float, float, _MISSING) for n in ("avg_game_length", "elapsed_sec", "positions_per_sec", "games_per_sec")),
+    ("step_timing_ms", Dict[str, float], _floats, _MISSING),
+    ("step_timing_ratio", Dict[str, float], _floats, _MISSING),
+    ("step_timing_calls", Dict[str, int], _ints, _MISSING),
+    ("mcts_counters", Dict[str, int], _ints, _MISSING),
+    ("piece_delta_buckets", Dict[str, int], _ints, _MISSING),
+    ("policy_target_audit", Dict[str, Any], lambda m: dict(m or {}), dict),
+    ("device", str, str, str),
+    ("fallback_count", int, int, int),
+    ("fallback_reasons", Tuple[str, ...], list, tuple),
+)
+
+
+def _to_dict(self) -> Dict[str, object]:
+    return {name: conv(getattr(self, name)) for name, _, conv, _ in _SCHEMA}
+
+
+SelfPlayV1Stats = make_dataclass(
+    "SelfPlayV1Stats",
+    [(name, ann) if dflt is _MISSING else (name, ann, field(default_factory=dflt)) for name, ann, _, dflt in _SCHEMA],
+    namespace={"to_dict": _to_dict, "__doc__": "Aggregate statistics of one self-play call."},
+)
+SelfPlayV1Stats.__module__ = __name__
