@@ -113,12 +113,18 @@ struct Cfg {
 // lane, so a group mixes 8 cells ("X": columns 0-3,12-15) at chunk q with 8 cells ("Y": columns 4-11) at chunk q+1.
 //   * inside a row the four 16-byte chunks of a 32-channel K block sit 32 bytes apart (two K blocks interleaved):
 //     slot(cell, q) = (STRIDE/16 * row(cell) + 2q + const) mod 16;
-//   * a tile is not 16 consecutive cells but 16 cells chosen so that X and Y each hold one cell of every row class
-//     {0,1,4,5,8,9,12,13} (or {2,3,6,7,...}) mod 16: X slots and Y slots (shifted by 2) then tile all 16 slots.
-// The S*36 rows of a workgroup contain every class equally often, so all tiles are perfect: 4 LDS cycles per read
-// instead of 12 (64 channels) / 8 (128 channels) with consecutive cells.  Rows stay where the zero-bordered board
-// puts them, so 3x3 taps remain constant offsets; only the cell <-> (tile, column) assignment is permuted, which no
-// other phase sees (accumulators keep the same assignment through all layers).
+//   * a tile is not 16 consecutive cells but TWO board cells x 8 samples: the X columns hold one cell, the Y columns
+//     another, for the same 8 samples.  Sample rows are 58 apart (58 * STRIDE/16 = 10 mod 16), so 8 samples of one
+//     cell cover the 8 slots of one parity; the two cells of a pair sit on rows of opposite parity, so X slots and
+//     Y slots (shifted by 2) tile all 16 slots, for either assignment of the two K chunks.
+// All tiles are therefore perfect: 4 LDS cycles per read instead of 12 (64 channels) / 8 (128 channels) with
+// consecutive cells.  Rows stay where the zero-bordered board puts them, so 3x3 taps remain constant offsets; only
+// the cell <-> (tile, column) assignment is chosen, which no other phase sees (accumulators keep the same
+// assignment through all layers).
+// A wave owns 9 such tiles = one HALF board (18 cells) of 8 samples, described in a frame mirrored so that row 0 is
+// always the outer edge: top-half and bottom-half waves then have the same out-of-board taps at the same tile
+// index, and those tile-taps are not computed at all (tap_live).  The mirror costs one wave-uniform row step
+// (+-7 rows) and three weight-row offsets in SGPRs; every other offset stays an instruction immediate.
 __host__ __device__ constexpr int board_row(int n) {                // row index of board cell n = 36*sample + 6*r + c
     const int s = n / 36, p = n - s * 36;
     const int r = p / 6, c = p - r * 6;
@@ -129,21 +135,32 @@ __host__ __device__ constexpr int chunk_pos(int chunk) {            // 16-byte p
 }
 template <int C, int S>
 struct TileMap { unsigned short cell[S * 36 / 16][16]; };
+// Cell pairs of a half board in the MIRRORED frame (r' = distance from the outer board edge, c): {X cell, Y cell}.
+// Both cells of a pair lie on rows of opposite parity ((r + c) odd vs even), which is what makes the two column
+// sets land on complementary slots, and they share their out-of-board taps as far as 9 cells in 9 tiles allow:
+// tiles 0-2 have no row towards the edge, tile 3 no left column, tile 4 no right column (tap_live below).
+constexpr int kPairCell[9][2][2] = {{{0, 0}, {0, 5}}, {{0, 1}, {0, 2}}, {{0, 3}, {0, 4}}, {{1, 0}, {2, 0}}, {{1, 5}, {2, 5}},
+                                    {{1, 1}, {1, 2}}, {{1, 3}, {1, 4}}, {{2, 1}, {2, 2}}, {{2, 3}, {2, 4}}};
 template <int C, int S>
 constexpr TileMap<C, S> make_tile_map() {
-    constexpr int NT = S * 36 / 16;
-    constexpr int m = ((C * 2 + 16) / 16) & 15;
     constexpr int xcols[8] = {0, 1, 2, 3, 12, 13, 14, 15}, ycols[8] = {4, 5, 6, 7, 8, 9, 10, 11};
     TileMap<C, S> t{};
-    int count[2][8] = {};
-    for (int n = 0; n < S * 36; ++n) {
-        const int res = (m * board_row(n)) & 15;
-        const int type = (res & 3) >> 1, idx = (res >> 2) * 2 + (res & 1);
-        const int k = count[type][idx]++;                           // every class occurs exactly NT times
-        const int tile = type * (NT / 2) + (k >> 1);
-        t.cell[tile][(k & 1) ? ycols[idx] : xcols[idx]] = (unsigned short)n;
+    for (int pg = 0; pg < S / 4; ++pg) {                                // cell group = (8 samples) x (board half)
+        const int half = pg & 1, s0 = (pg >> 1) * 8;
+        for (int i = 0; i < 9; ++i)
+            for (int k = 0; k < 8; ++k)
+                for (int y = 0; y < 2; ++y) {
+                    const int rm = kPairCell[i][y][0], c = kPairCell[i][y][1];
+                    const int r = half ? 5 - rm : rm;
+                    t.cell[pg * 9 + i][y ? ycols[k] : xcols[k]] = (unsigned short)((s0 + k) * 36 + r * 6 + c);
+                }
     }
     return t;
+}
+// Is tap (mirrored row t: 0 = towards the outer edge, 1 = own row, 2 = towards the centre; dx: 0 = left .. 2 = right)
+// inside the board for BOTH cells of tile i?  Dead tile-taps are skipped entirely: 15 of 81 per 3x3 conv.
+__host__ __device__ constexpr bool tap_live(int i, int t, int dx) {
+    return i < 3 ? t != 0 : i == 3 ? dx != 0 : i == 4 ? dx != 2 : true;
 }
 template <int C, int S>
 constexpr bool tile_map_ok() {                                      // compile-time proof of the claim above
@@ -164,6 +181,17 @@ constexpr bool tile_map_ok() {                                      // compile-t
             }
         }
     for (int n = 0; n < S * 36; ++n) if (!seen[n]) return false;
+    for (int tile = 0; tile < NT; ++tile)                           // every skipped tap is out of board for all 16 cells
+        for (int col = 0; col < 16; ++col) {
+            const int p = t.cell[tile][col] % 36, r = p / 6, c = p % 6;
+            const int sy = ((tile / 9) & 1) ? -1 : 1;
+            for (int tr = 0; tr < 3; ++tr)
+                for (int dx = 0; dx < 3; ++dx) {
+                    const int rr = r + sy * (tr - 1), cc = c + dx - 1;
+                    const bool inside = rr >= 0 && rr < 6 && cc >= 0 && cc < 6;
+                    if (!tap_live(tile % 9, tr, dx) && inside) return false;
+                }
+        }
     return true;
 }
 static_assert(tile_map_ok<64, 16>() && tile_map_ok<128, 8>() && tile_map_ok<64, 8>(),
@@ -189,29 +217,51 @@ __device__ __forceinline__ int act_addr(int n, int chunk) {
 // that runs one cell tile ahead of the MFMAs.
 typedef f4 Acc[9][2];
 
-// byte offset of K step `step` relative to the top-left neighbour's row (compile-time after unrolling)
+// Compile-time schedule of the K steps of one conv.  3x3: rows in the order {own, towards the centre, towards the
+// edge} (the walk starts and ends on the cell's own row, where `base` points for the 1x1 convs and the stores), three
+// columns per row, K::KB channel blocks per tap.  `row` is in the wave's mirrored frame.
 template <int C, int S, bool TAPS9, bool STEM>
-__device__ __forceinline__ constexpr int step_offset(int step) {
+struct Steps {
     using K = Cfg<C, S>;
-    const int tap = !TAPS9 ? 4 : (STEM ? step : step / K::KB);
-    const int kb = !TAPS9 ? step : (STEM ? 0 : step % K::KB);
-    return ((tap / 3) * 7 + (tap % 3)) * K::STRIDE + (chunk_pos(kb * 4) << 4);
-}
+    static constexpr int KBS = STEM ? 1 : K::KB;                    // K blocks per tap
+    static constexpr int N = TAPS9 ? 9 * KBS : K::KB;
+    static constexpr int seq(int step) { return TAPS9 ? step / (3 * KBS) : 0; }
+    static constexpr int row(int step) { return !TAPS9 ? 1 : seq(step) == 0 ? 1 : seq(step) == 1 ? 2 : 0; }
+    static constexpr int dx(int step) { return TAPS9 ? (step / KBS) % 3 : 1; }
+    static constexpr int kb(int step) { return TAPS9 ? step % KBS : step; }
+    // LDS byte offset relative to the LEFT neighbour on the current row (`base`)
+    static constexpr int lds_imm(int step) { return dx(step) * K::STRIDE + (chunk_pos(kb(step) * 4) << 4); }
+    // weight byte offset relative to the start of the tap row (3x3) / of the layer (1x1), for CTN output tiles
+    static constexpr int w_imm(int step, int ctn) { return (TAPS9 ? dx(step) * KBS + kb(step) : step) * ctn * 1024; }
+    static constexpr int w_row_bytes(int ctn) { return TAPS9 ? 3 * KBS * ctn * 1024 : 0; }
+    static constexpr bool live(int i, int step) { return !TAPS9 || tap_live(i, row(step), dx(step)); }
+    // rows to move `base` by after `step` (in units of the wave's row step): own -> centre-side -> edge-side -> own
+    static constexpr int shift(int step) {
+        return !TAPS9 ? 0 : step + 1 == N ? 1 : seq(step + 1) == seq(step) ? 0 : seq(step) == 0 ? 1 : -2;
+    }
+};
 
 // One K step, software-pipelined IN PLACE: tile i's activation fragment register is reloaded for the next K step
 // right after its two MFMAs have been issued, so the LDS reads are spread over the whole step (one ds_read per
 // two MFMAs) and overlap the matrix pipe instead of forming a separate read phase.  The counted lgkmcnt waits
-// the compiler derives from this order leave 8 reads in flight.
-template <int C, int S, bool TAPS9, bool STEM, int STEP, int NSTEPS>
+// the compiler derives from this order leave 8 reads in flight.  Tile-taps that are out of board for the whole
+// tile issue neither the MFMAs nor the read.
+template <int C, int S, bool TAPS9, bool STEM, int STEP>
 __device__ __forceinline__ void gemm_step(Acc& acc, const h8 (&A)[2], h8 (&B)[9], const unsigned char* lds,
-                                          const int (&base)[9]) {
-    constexpr int next_off = (STEP + 1 < NSTEPS) ? step_offset<C, S, TAPS9, STEM>(STEP + 1) : 0;
+                                          int (&base)[9], int row_step) {
+    using T = Steps<C, S, TAPS9, STEM>;
+    constexpr bool more = STEP + 1 < T::N;
+    constexpr int shift = T::shift(STEP);
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
+        if (T::live(i, STEP)) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[j], B[i], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[j], B[i], acc[i][j], 0, 0, 0);
+        }
+        if (shift != 0) base[i] += shift * row_step;
 #ifndef LZ_EXP_NO_BRELOAD   /* timing experiment only: without the LDS operand reloads the results are wrong */
-        if (STEP + 1 < NSTEPS) B[i] = *reinterpret_cast<const h8*>(lds + base[i] + next_off);
+        if (more && T::live(i, more ? STEP + 1 : STEP))
+            B[i] = *reinterpret_cast<const h8*>(lds + base[i] + T::lds_imm(more ? STEP + 1 : STEP));
 #endif
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -220,47 +270,56 @@ __device__ __forceinline__ void gemm_step(Acc& acc, const h8 (&A)[2], h8 (&B)[9]
 template <int C, int S, bool TAPS9, bool STEM, int CTN, int STEP, int NSTEPS>
 struct GemmSteps {
     static __device__ __forceinline__ void run(Acc& acc, h8 (&A0)[2], h8 (&A1)[2], h8 (&B)[9], __amdgpu_buffer_rsrc_t rw,
-                                               int wbyte, int lane16, const unsigned char* lds, const int (&base)[9]) {
+                                               const int (&wrow)[3], int lane16, const unsigned char* lds,
+                                               int (&base)[9], int row_step) {
+        using T = Steps<C, S, TAPS9, STEM>;
         // weight fragments (L2) are prefetched one K step ahead into the other register pair
         if (STEP + 1 < NSTEPS) {
+            constexpr int nx = STEP + 1 < NSTEPS ? STEP + 1 : STEP;
 #pragma unroll
-            for (int j = 0; j < 2; ++j) A1[j] = load_wfrag(rw, lane16, wbyte + ((STEP + 1) * CTN + j) * 1024);
+            for (int j = 0; j < 2; ++j) A1[j] = load_wfrag(rw, lane16, wrow[T::row(nx)] + T::w_imm(nx, CTN) + j * 1024);
         }
-        gemm_step<C, S, TAPS9, STEM, STEP, NSTEPS>(acc, A0, B, lds, base);
-        GemmSteps<C, S, TAPS9, STEM, CTN, STEP + 1, NSTEPS>::run(acc, A1, A0, B, rw, wbyte, lane16, lds, base);
+        gemm_step<C, S, TAPS9, STEM, STEP>(acc, A0, B, lds, base, row_step);
+        GemmSteps<C, S, TAPS9, STEM, CTN, STEP + 1, NSTEPS>::run(acc, A1, A0, B, rw, wrow, lane16, lds, base, row_step);
     }
 };
 template <int C, int S, bool TAPS9, bool STEM, int CTN, int NSTEPS>
 struct GemmSteps<C, S, TAPS9, STEM, CTN, NSTEPS, NSTEPS> {
-    static __device__ __forceinline__ void run(Acc&, h8 (&)[2], h8 (&)[2], h8 (&)[9], __amdgpu_buffer_rsrc_t, int, int,
-                                               const unsigned char*, const int (&)[9]) {}
+    static __device__ __forceinline__ void run(Acc&, h8 (&)[2], h8 (&)[2], h8 (&)[9], __amdgpu_buffer_rsrc_t,
+                                               const int (&)[3], int, const unsigned char*, int (&)[9], int) {}
 };
 
 // Fully unrolled over the K steps (9 taps x C/32 blocks): every LDS read offset is an immediate and every
-// weight address is {descriptor, scalar offset, lane offset}, so a step is 9 ds_read + 2 buffer_load +
-// 18 MFMA and nothing else.
-// `layer_half_off` = offset of the layer in halfs, ct0 = first output tile of this wave (both wave-uniform).
-// first two weight fragments of a layer: issued a whole phase early (before the barrier / LDS store phase that
-// precedes the conv) so their L2 latency never sits on the critical path
+// weight address is {descriptor, scalar offset, lane offset}, so a step is <= 9 ds_read + 2 buffer_load +
+// <= 18 MFMA and (on the two row changes and at the end) 9 address adds.
+// `layer_half_off` = offset of the layer in halfs, ct0 = first output tile of this wave (both wave-uniform);
+// `mirror` = the wave owns a bottom half board (its mirrored rows run against the weight rows).
+// first two weight fragments of a layer (own row, left tap -- the same for both mirror states): issued a whole
+// phase early (before the barrier / LDS store phase that precedes the conv) so their L2 latency never sits on the
+// critical path
+template <int C, int S, bool TAPS9, bool STEM, int CTN>
 __device__ __forceinline__ void load_first_frags(__amdgpu_buffer_rsrc_t rw, int layer_half_off, int ct0, int lane,
                                                  h8 (&A0)[2]) {
-    const int wbyte = __builtin_amdgcn_readfirstlane(layer_half_off * 2 + ct0 * 1024);
+    using T = Steps<C, S, TAPS9, STEM>;
+    const int wbyte = __builtin_amdgcn_readfirstlane(layer_half_off * 2 + ct0 * 1024) + T::w_row_bytes(CTN);
 #pragma unroll
     for (int j = 0; j < 2; ++j) A0[j] = load_wfrag(rw, lane * 16, wbyte + j * 1024);
 }
 
 template <int C, int S, bool TAPS9, bool STEM, int CTN>
 __device__ __forceinline__ void conv_gemm(Acc& acc, __amdgpu_buffer_rsrc_t rw, int layer_half_off, int ct0,
-                                          const unsigned char* lds, const int (&base)[9], int lane, h8 (&A0)[2]) {
-    using K = Cfg<C, S>;
-    constexpr int nsteps = TAPS9 ? (STEM ? 9 : 9 * K::KB) : K::KB;
+                                          const unsigned char* lds, int (&base)[9], int lane, h8 (&A0)[2],
+                                          bool mirror, int row_step) {
+    using T = Steps<C, S, TAPS9, STEM>;
     const int wbyte = __builtin_amdgcn_readfirstlane(layer_half_off * 2 + ct0 * 1024);
+    const int wrow[3] = {wbyte + (mirror ? 2 : 0) * T::w_row_bytes(CTN), wbyte + T::w_row_bytes(CTN),
+                         wbyte + (mirror ? 0 : 2) * T::w_row_bytes(CTN)};
     const int lane16 = lane * 16;
     h8 A1[2], B[9];
-    constexpr int off0 = step_offset<C, S, TAPS9, STEM>(0);
 #pragma unroll
-    for (int i = 0; i < 9; ++i) B[i] = *reinterpret_cast<const h8*>(lds + base[i] + off0);
-    GemmSteps<C, S, TAPS9, STEM, CTN, 0, nsteps>::run(acc, A0, A1, B, rw, wbyte, lane16, lds, base);
+    for (int i = 0; i < 9; ++i)
+        if (T::live(i, 0)) B[i] = *reinterpret_cast<const h8*>(lds + base[i] + T::lds_imm(0));
+    GemmSteps<C, S, TAPS9, STEM, CTN, 0, T::N>::run(acc, A0, A1, B, rw, wrow, lane16, lds, base, row_step);
 }
 
 // workgroup barrier that only orders LDS traffic: prefetched global loads stay in flight across it
@@ -293,15 +352,15 @@ __device__ __forceinline__ void load_chan_params(__amdgpu_buffer_rsrc_t rf, int 
     for (int j = 0; j < 2; ++j) v[j] = load_f4(rf, sub, float_off + chan_base + j * 16);
 }
 
-// The store address of the lane's cell in tile i is derived from base[i] (the read address of its top-left
-// neighbour + the lane's K chunk): row(cell) = base[i] + 8*STRIDE - 32*(lane>>4); the lane writes channels
+// The store address of the lane's cell in tile i is derived from base[i] (the read address of its left
+// neighbour + the lane's K chunk): row(cell) = base[i] + STRIDE - 32*(lane>>4); the lane writes channels
 // chan_base + 16j + 4q .. +4 (q = lane>>4, chan_base a multiple of 32), i.e. chunk chan_base/8 + 2j + (q>>1), half
 // (q&1).  One per-lane delta + the immediate 64j instead of 18 independently computed (hoisted, spilled) addresses.
 template <int C, int S>
 __device__ __forceinline__ int store_delta(int chan_base, int lane) {
     using K = Cfg<C, S>;
     const int q = lane >> 4;
-    return 8 * K::STRIDE - 32 * q + (chunk_pos(chan_base >> 3) << 4) + 32 * (q >> 1) + 8 * (q & 1);
+    return K::STRIDE - 32 * q + (chunk_pos(chan_base >> 3) << 4) + 32 * (q >> 1) + 8 * (q & 1);
 }
 
 template <int C, int S, bool HAS_SCALE>
@@ -418,12 +477,14 @@ __global__ __launch_bounds__(W * 64, 2) void net_forward_kernel(NetParams P, con
     const __amdgpu_buffer_rsrc_t rf = make_rsrc(P.fp, P.fparams_bytes);
 
     // per-lane cell geometry of the 9 tiles
-    int base[9];                                         // top-left neighbour of the lane's cell, + the lane's K chunk
+    int base[9];                                         // left neighbour of the lane's cell, + the lane's K chunk
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
         const int n = tile_cell<C, S>(tile0 + i, lane & 15);
-        base[i] = K::ACT_OFF + board_row(n) * K::STRIDE + (lane >> 4) * 32 - 8 * K::STRIDE;
+        base[i] = K::ACT_OFF + board_row(n) * K::STRIDE + (lane >> 4) * 32 - K::STRIDE;
     }
+    const bool mirror = (pg & 1) != 0;                   // bottom half board: mirrored rows run upwards
+    const int row_step = mirror ? -7 * K::STRIDE : 7 * K::STRIDE;
     // zero the whole activation buffer once: the board borders stay zero for every layer / pass
     for (int i = tid; i < K::ZERO_OFF / 16; i += NTHR) reinterpret_cast<uint4*>(lds + K::ACT_OFF)[i] = make_uint4(0, 0, 0, 0);
     float* gvec = reinterpret_cast<float*>(lds + K::G_OFF);
@@ -496,9 +557,9 @@ __global__ __launch_bounds__(W * 64, 2) void net_forward_kernel(NetParams P, con
         h8 Af[2];                                              // first weight fragments of the upcoming conv
         f4 pa[2], pb[2];                                       // per-channel parameters of the upcoming store
         // ---- stem: x = relu(conv(planes) + bias) ----
-        load_first_frags(rw, P.layer_off[0], ct0, lane, Af);
+        load_first_frags<C, S, true, true, K::CT>(rw, P.layer_off[0], ct0, lane, Af);
         load_chan_params(rf, P.stem_bias, chan0, lane, pb);
-        conv_gemm<C, S, true, true, K::CT>(x, rw, P.layer_off[0], ct0, lds, base, lane, Af);
+        conv_gemm<C, S, true, true, K::CT>(x, rw, P.layer_off[0], ct0, lds, base, lane, Af, mirror, row_step);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
 #pragma unroll
@@ -519,7 +580,7 @@ __global__ __launch_bounds__(W * 64, 2) void net_forward_kernel(NetParams P, con
             const int bp = P.blk0 + blk * 3 * C;               // float offsets: a1 | b1 | bias1
             load_chan_params(rf, bp, chan0, lane, pa);
             load_chan_params(rf, bp + C, chan0, lane, pb);
-            load_first_frags(rw, P.layer_off[1 + 2 * blk], ct0, lane, Af);
+            load_first_frags<C, S, true, false, K::CT>(rw, P.layer_off[1 + 2 * blk], ct0, lane, Af);
             LZ_STAMP(0)
             lds_barrier();                                     // everyone finished reading the act buffer
             LZ_STAMP(1)
@@ -532,8 +593,8 @@ __global__ __launch_bounds__(W * 64, 2) void net_forward_kernel(NetParams P, con
             for (int i = 0; i < 9; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
-            conv_gemm<C, S, true, false, K::CT>(acc, rw, P.layer_off[1 + 2 * blk], ct0, lds, base, lane, Af);
-            load_first_frags(rw, P.layer_off[2 + 2 * blk], ct0, lane, Af);
+            conv_gemm<C, S, true, false, K::CT>(acc, rw, P.layer_off[1 + 2 * blk], ct0, lds, base, lane, Af, mirror, row_step);
+            load_first_frags<C, S, true, false, K::CT>(rw, P.layer_off[2 + 2 * blk], ct0, lane, Af);
             LZ_STAMP(4)
             lds_barrier();
             LZ_STAMP(5)
@@ -541,7 +602,7 @@ __global__ __launch_bounds__(W * 64, 2) void net_forward_kernel(NetParams P, con
             LZ_STAMP(6)
             lds_barrier();
             LZ_STAMP(7)
-            conv_gemm<C, S, true, false, K::CT>(x, rw, P.layer_off[2 + 2 * blk], ct0, lds, base, lane, Af);  // x += conv2(u)
+            conv_gemm<C, S, true, false, K::CT>(x, rw, P.layer_off[2 + 2 * blk], ct0, lds, base, lane, Af, mirror, row_step);  // x += conv2(u)
             LZ_STAMP(8)
         }
 #ifdef LZ_EXP_STAMPS
@@ -558,7 +619,7 @@ __global__ __launch_bounds__(W * 64, 2) void net_forward_kernel(NetParams P, con
         const int ht1 = K::CG * K::CTW + cg * K::CTW;              // head tile of x     (HP == 2 only)
         load_chan_params(rf, P.trunk_a, chan0, lane, pa);
         load_chan_params(rf, P.trunk_b, chan0, lane, pb);
-        load_first_frags(rw, wh, ht0, lane, Af);
+        load_first_frags<C, S, false, false, 8>(rw, wh, ht0, lane, Af);
         lds_barrier();
         store_act<C, S, true>(x, lds, base, chan0, pa, pb, lane);
         lds_barrier();
@@ -567,10 +628,10 @@ __global__ __launch_bounds__(W * 64, 2) void net_forward_kernel(NetParams P, con
 #pragma unroll
             for (int j = 0; j < 2; ++j) { acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f}; x[i][j] = (f4){0.f, 0.f, 0.f, 0.f}; }
         // pass 0 -> acc, pass 1 (only when 4 waves' worth of tiles cover half of the 8 head tiles) -> x
-        conv_gemm<C, S, false, false, 8>(acc, rw, wh, ht0, lds, base, lane, Af);
+        conv_gemm<C, S, false, false, 8>(acc, rw, wh, ht0, lds, base, lane, Af, mirror, row_step);
         if (K::HP == 2) {
-            load_first_frags(rw, wh, ht1, lane, Af);
-            conv_gemm<C, S, false, false, 8>(x, rw, wh, ht1, lds, base, lane, Af);
+            load_first_frags<C, S, false, false, 8>(rw, wh, ht1, lane, Af);
+            conv_gemm<C, S, false, false, 8>(x, rw, wh, ht1, lds, base, lane, Af, mirror, row_step);
         }
         __syncthreads();
         if (P.debug_stop == 4) { if (lane == 0 && (acc[0][0][0] + x[0][0][0]) == 123.f) lp1[0] = 1.f; continue; }   // after head convs
