@@ -163,6 +163,45 @@ LZ_API int lz_finalize_trajectory_inplace(float* value_targets, float* soft_valu
                                           void* stream);
 
 
+/* Fused per-ply tail of the v1 wave loop for a FIXED wave of G slots (v1/python/self_play_gpu_runner.py:205-247 with
+ * v1/python/trajectory_buffer.py:63-140): finished slots stay in the batch and are masked by `done`, so that nothing
+ * in the loop needs the host.  Same results as append_steps + step_index update + self_play_step_inplace +
+ * finalize_trajectory_inplace on the live slots (tests/test_gpu_selfplay.py).
+ *
+ * lz_wave_record: live slot g (done[g]==0, ascending g) gets arena row *cursor + rank(g); its model input
+ * float32[11*36], legal mask uint8[T], policy float32[T] are copied into the arena row, value / soft targets are set
+ * to NaN, sign = (current_player >= 0 ? 1 : -1); step_index[g, step_counts[g]++] = row; rows[g] = row (-1 for
+ * finished slots); *cursor += live count.  A row >= capacity or a full step_index row drops the sample and bumps
+ * *overflow (the host sizes both so that this never happens). */
+LZ_API int lz_wave_record(const uint8_t* done, int64_t num_slots, int64_t* cursor, int64_t capacity,
+                          int64_t max_steps, int64_t* step_index_matrix, int64_t* step_counts, int64_t* rows,
+                          int32_t* overflow, const float* model_input, const uint8_t* legal_mask,
+                          const float* policy_dense, const int64_t* current_player, int64_t action_dim,
+                          float* arena_state, uint8_t* arena_legal, float* arena_policy, float* arena_value,
+                          float* arena_soft, int8_t* arena_sign, void* stream);
+
+/* lz_wave_step_finish: for every live slot apply chosen_action_codes[g] (self_play_step_inplace rules,
+ * module.cpp:724-856); a game that ends has value = sign*result / soft = sign*tanh(k*delta/18) written over its rows
+ * (module.cpp:547-630), outcome int64[3] += [black wins, white wins, draws] (games with >= 1 recorded step),
+ * delta_hist int64[37] (optional) += final black-white piece difference clamped to [-18,18], lengths[slot_game ?
+ * slot_game[g] : g] (optional) = recorded steps, *finished (optional) += 1.  reseat == 0: done[g] = 1.  reseat != 0: the slot restarts from the empty
+ * board (plies, step_counts = 0, reseated[g] = 1 if given) -- the steady-state population of bench.py. */
+LZ_API int lz_wave_step_finish(const LzStateSoA* states, int64_t num_slots, int64_t* plies, uint8_t* done,
+                               const int32_t* chosen_action_codes, const uint8_t* terminal_mask,
+                               const uint8_t* chosen_valid_mask, int64_t max_game_plies, float soft_value_k,
+                               float* value_targets, float* soft_value_targets, const int8_t* player_signs,
+                               const int64_t* step_index_matrix, int64_t* step_counts, int64_t max_steps,
+                               int64_t* outcome, int64_t* delta_hist, int64_t* lengths, const int64_t* slot_game,
+                               int64_t* finished, uint8_t* reseated, int reseat, void* stream);
+
+/* lz_wave_reseat: the wave loop of self_play_gpu_runner.py:84-90 starts the next `concurrent_games` games only when the
+ * whole wave has finished; here finished slots (done[g] != 0, ascending g) restart from the empty board at once while
+ * *budget (games not yet started) lasts: slot_game[g] = (*next_game)++, plies / step_counts = 0, done[g] = 0,
+ * reseated[g] = 1 (optional); *budget is decremented.  Deterministic (one workgroup, ordered scan). */
+LZ_API int lz_wave_reseat(const LzStateSoA* states, int64_t num_slots, uint8_t* done, int64_t* plies,
+                          int64_t* step_counts, int64_t* budget, int64_t* next_game, int64_t* slot_game,
+                          uint8_t* reseated, void* stream);
+
 /* ---- network forward ------------------------------------------------------------------------- */
 
 /* Packed network description (built by liuzhou_amd/net_pack.py from a ChessNet state_dict:

@@ -715,6 +715,188 @@ __global__ __launch_bounds__(kBlock) void finalize_trajectory_kernel(
     }
 }
 
+// =================================================================================================
+// Fused per-ply tail of the wave loop for a FIXED wave of G slots (finished slots stay in the batch and are
+// masked by `done`): trajectory rows are assigned and written on the device, the move is applied and finished
+// games are finalised (and optionally re-seated) without a host round trip.
+// =================================================================================================
+constexpr int kRowsBlock = 1024;
+// rows[g] = *cursor + (number of live slots below g), -1 for finished slots; step_index / step_counts updated.
+__global__ __launch_bounds__(kRowsBlock) void wave_rows_kernel(
+    const uint8_t* __restrict__ done, int64_t G, int64_t* __restrict__ cursor, int64_t capacity, int64_t Tmax,
+    int64_t* __restrict__ step_index, int64_t* __restrict__ step_counts, int64_t* __restrict__ rows,
+    int32_t* __restrict__ overflow) {
+    __shared__ int wave_total[kRowsBlock / kWave];
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), w = tid / kWave;
+    const int64_t per = (G + kRowsBlock - 1) / kRowsBlock;
+    const int64_t lo = tid * per, hi = (lo + per < G) ? lo + per : G;
+    int cnt = 0;
+    for (int64_t j = lo; j < hi; ++j) cnt += done[j] == 0 ? 1 : 0;
+    int incl = cnt;
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+        const int v = __shfl_up(incl, d, kWave);
+        if (lane >= d) incl += v;
+    }
+    if (lane == kWave - 1) wave_total[w] = incl;
+    __syncthreads();
+    int before = 0, total = 0;
+    for (int i = 0; i < kRowsBlock / kWave; ++i) { if (i < w) before += wave_total[i]; total += wave_total[i]; }
+    int64_t row = *cursor + before + incl - cnt;
+    __syncthreads();                                    // every thread has read the cursor
+    for (int64_t j = lo; j < hi; ++j) {
+        if (done[j] != 0) { rows[j] = -1; continue; }
+        const int64_t n = step_counts[j];
+        if (row >= capacity || n >= Tmax) { rows[j] = -1; atomicAdd(overflow, 1); }
+        else { rows[j] = row; step_index[j * Tmax + n] = row; step_counts[j] = n + 1; }
+        ++row;
+    }
+    if (tid == 0) *cursor += total;
+}
+
+// Start the next games in finished slots, in ascending slot order while the budget lasts (deterministic): slot g
+// restarts from the empty board as game *next_game + rank(g).  One workgroup, same scan as wave_rows_kernel.
+__global__ __launch_bounds__(kRowsBlock) void wave_reseat_kernel(
+    LzStateSoA s, int64_t G, uint8_t* __restrict__ done, int64_t* __restrict__ plies,
+    int64_t* __restrict__ step_counts, int64_t* __restrict__ budget, int64_t* __restrict__ next_game,
+    int64_t* __restrict__ slot_game, uint8_t* __restrict__ reseated) {
+    __shared__ int wave_total[kRowsBlock / kWave];
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), w = tid / kWave;
+    const int64_t left = *budget;
+    if (left <= 0) return;                              // uniform: the common case once every game has started
+    const int64_t per = (G + kRowsBlock - 1) / kRowsBlock;
+    const int64_t lo = tid * per, hi = (lo + per < G) ? lo + per : G;
+    int cnt = 0;
+    for (int64_t j = lo; j < hi; ++j) cnt += done[j] != 0 ? 1 : 0;
+    int incl = cnt;
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+        const int v = __shfl_up(incl, d, kWave);
+        if (lane >= d) incl += v;
+    }
+    if (lane == kWave - 1) wave_total[w] = incl;
+    __syncthreads();
+    int before = 0, total = 0;
+    for (int i = 0; i < kRowsBlock / kWave; ++i) { if (i < w) before += wave_total[i]; total += wave_total[i]; }
+    const int64_t first = *next_game;
+    int64_t rank = before + incl - cnt;
+    __syncthreads();                                    // every thread has read budget / next_game
+    for (int64_t j = lo; j < hi; ++j) {
+        if (done[j] == 0) continue;
+        if (rank < left) {
+            State fresh{};
+            fresh.phase = kPlacement;
+            fresh.player = 1;
+            store_state(s, j, fresh);
+            plies[j] = 0;
+            step_counts[j] = 0;
+            done[j] = 0;
+            slot_game[j] = first + rank;
+            if (reseated) reseated[j] = 1;
+        }
+        ++rank;
+    }
+    if (tid == 0) {
+        const int64_t used = total < left ? total : left;
+        *budget = left - used;
+        *next_game = first + used;
+    }
+}
+
+// one wave per slot: copy the ply's sample into arena row rows[g] (value targets start as NaN)
+__global__ __launch_bounds__(kBlock) void wave_record_kernel(
+    const int64_t* __restrict__ rows, int64_t G, const float* __restrict__ model_input,
+    const uint8_t* __restrict__ legal, const float* __restrict__ policy, const int64_t* __restrict__ player, int T,
+    float* __restrict__ a_state, uint8_t* __restrict__ a_legal, float* __restrict__ a_policy,
+    float* __restrict__ a_value, float* __restrict__ a_soft, int8_t* __restrict__ a_sign) {
+    const int lane = lane_id();
+    const int64_t g = wave_item();
+    if (g >= G) return;
+    const int64_t row = rows[g];
+    if (row < 0) return;
+    constexpr int kIn = 11 * 36;
+    for (int j = lane; j < kIn; j += kWave) a_state[row * kIn + j] = model_input[g * kIn + j];
+    for (int j = lane; j < T; j += kWave) {
+        a_legal[row * T + j] = legal[g * T + j];
+        a_policy[row * T + j] = policy[g * T + j];
+    }
+    if (lane == 0) {
+        a_value[row] = __builtin_nanf("");
+        a_soft[row] = __builtin_nanf("");
+        a_sign[row] = player[g] >= 0 ? 1 : -1;
+    }
+}
+
+// one wave per slot: lane 0 plays the move (same rules as self_play_step_kernel), then the wave finalises a
+// finished game's rows (finalize_trajectory_kernel) and books it; `reseat` puts a fresh game into the slot.
+__global__ __launch_bounds__(kBlock) void wave_step_finish_kernel(
+    LzStateSoA s, int64_t G, int64_t* __restrict__ plies, uint8_t* __restrict__ done, const int4* __restrict__ codes,
+    const uint8_t* __restrict__ terminal, const uint8_t* __restrict__ cvalid, int64_t max_plies, float k,
+    float* __restrict__ value_t, float* __restrict__ soft_t, const int8_t* __restrict__ signs,
+    const int64_t* __restrict__ step_index, int64_t* __restrict__ step_counts, int64_t Tmax,
+    unsigned long long* __restrict__ outcome, unsigned long long* __restrict__ delta_hist,
+    int64_t* __restrict__ lengths, const int64_t* __restrict__ slot_game, unsigned long long* __restrict__ finished,
+    uint8_t* __restrict__ reseated, int reseat) {
+    const int lane = lane_id();
+    const int64_t g = wave_item();
+    if (g >= G) return;
+    if (done[g] != 0) return;
+    int fin = 0, delta = 0;
+    float res = 0.f, sft = 0.f;
+    if (lane == 0) {
+        State st = load_state(s, g);
+        const bool term = terminal[g] != 0;
+        if (term || cvalid[g] == 0) {
+            fin = 1;
+            res = term ? -(float)s.current_player[g] : 0.f;
+        } else {
+            const int4 code = codes[g];
+            apply(st, code.x, code.y, code.z);
+            store_state(s, g, st);
+            const int64_t np = plies[g] + 1;
+            plies[g] = np;
+            int winner = 0;
+            const bool post = st.phase == kMovement || st.phase == kCaptureSelection || st.phase == kCounterRemoval;
+            if (post && popc(st.black) < kLoseThreshold) winner = -1;
+            if (post && popc(st.white) < kLoseThreshold) winner = 1;
+            const bool draw = st.move_count >= kMaxMoveCount || st.msc >= kNoCaptureLimit;
+            if (winner != 0 || draw || np >= max_plies) { fin = 2; res = (float)winner; }
+        }
+        if (fin) { sft = soft_value(st.black, st.white, k); delta = popc(st.black) - popc(st.white); }
+    }
+    fin = __shfl(fin, 0, kWave);
+    if (fin == 0) return;
+    res = __shfl(res, 0, kWave);
+    sft = __shfl(sft, 0, kWave);
+    int64_t n = step_counts[g];
+    if (n > Tmax) n = Tmax;
+    for (int64_t j = lane; j < n; j += kWave) {
+        const int64_t idx = step_index[g * Tmax + j];
+        const float sg = (float)signs[idx];
+        value_t[idx] = sg * res;
+        soft_t[idx] = sg * sft;
+    }
+    if (lane == 0) {
+        if (n > 0) {
+            atomicAdd(&outcome[res > 0.f ? 0 : (res < 0.f ? 1 : 2)], 1ull);
+            if (lengths) lengths[slot_game ? slot_game[g] : g] = n;
+        }
+        if (delta_hist) atomicAdd(&delta_hist[delta < -18 ? 0 : (delta > 18 ? 36 : delta + 18)], 1ull);
+        if (finished) atomicAdd(finished, 1ull);
+        if (reseat) {
+            State fresh{};
+            fresh.phase = kPlacement;
+            fresh.player = 1;
+            store_state(s, g, fresh);
+            plies[g] = 0;
+            step_counts[g] = 0;
+            if (reseated) reseated[g] = 1;
+        } else {
+            done[g] = 1;
+        }
+    }
+}
+
 inline unsigned grid_waves(int64_t items) { return (unsigned)((items + kWavesPerBlock - 1) / kWavesPerBlock); }
 inline unsigned grid_threads(int64_t items) { return (unsigned)((items + kBlock - 1) / kBlock); }
 
@@ -894,6 +1076,54 @@ int lz_finalize_trajectory_inplace(float* value_t, float* soft_t, const int8_t* 
     hipLaunchKernelGGL(finalize_trajectory_kernel, dim3(grid_waves(F)), dim3(kBlock), 0, as_stream(stream), value_t,
                        soft_t, signs, step_index, step_counts, G, Tmax, slots, result, softv, F, keep, final_counts,
                        reinterpret_cast<unsigned long long*>(counts_out));
+    return launch_status();
+}
+
+int lz_wave_record(const uint8_t* done, int64_t G, int64_t* cursor, int64_t capacity, int64_t Tmax, int64_t* step_index,
+                   int64_t* step_counts, int64_t* rows, int32_t* overflow, const float* model_input,
+                   const uint8_t* legal_mask, const float* policy, const int64_t* current_player, int64_t T,
+                   float* a_state, uint8_t* a_legal, float* a_policy, float* a_value, float* a_soft, int8_t* a_sign,
+                   void* stream) {
+    if (G < 0 || capacity < 0 || Tmax <= 0 || T <= 0) return LZ_ERR_ARG;
+    if (G == 0) return LZ_OK;
+    if (!done || !cursor || !step_index || !step_counts || !rows || !overflow || !model_input || !legal_mask || !policy ||
+        !current_player || !a_state || !a_legal || !a_policy || !a_value || !a_soft || !a_sign)
+        return LZ_ERR_ARG;
+    hipStream_t st = as_stream(stream);
+    hipLaunchKernelGGL(wave_rows_kernel, dim3(1), dim3(kRowsBlock), 0, st, done, G, cursor, capacity, Tmax, step_index,
+                       step_counts, rows, overflow);
+    hipLaunchKernelGGL(wave_record_kernel, dim3(grid_waves(G)), dim3(kBlock), 0, st, rows, G, model_input, legal_mask,
+                       policy, current_player, (int)T, a_state, a_legal, a_policy, a_value, a_soft, a_sign);
+    return launch_status();
+}
+
+int lz_wave_step_finish(const LzStateSoA* s, int64_t G, int64_t* plies, uint8_t* done, const int32_t* codes,
+                        const uint8_t* terminal, const uint8_t* cvalid, int64_t max_plies, float k, float* value_t,
+                        float* soft_t, const int8_t* signs, const int64_t* step_index, int64_t* step_counts,
+                        int64_t Tmax, int64_t* outcome, int64_t* delta_hist, int64_t* lengths,
+                        const int64_t* slot_game, int64_t* finished, uint8_t* reseated, int reseat, void* stream) {
+    if (G < 0 || max_plies <= 0 || Tmax <= 0) return LZ_ERR_ARG;
+    if (G == 0) return LZ_OK;
+    if (!soa_ok(s) || !plies || !done || !codes || !terminal || !cvalid || !value_t || !soft_t || !signs ||
+        !step_index || !step_counts || !outcome)
+        return LZ_ERR_ARG;
+    if (!soa_aligned(s) || !aligned(codes, 16)) return LZ_ERR_ALIGN;
+    hipLaunchKernelGGL(wave_step_finish_kernel, dim3(grid_waves(G)), dim3(kBlock), 0, as_stream(stream), *s, G, plies,
+                       done, reinterpret_cast<const int4*>(codes), terminal, cvalid, max_plies, k, value_t, soft_t,
+                       signs, step_index, step_counts, Tmax, reinterpret_cast<unsigned long long*>(outcome),
+                       reinterpret_cast<unsigned long long*>(delta_hist), lengths, slot_game,
+                       reinterpret_cast<unsigned long long*>(finished), reseated, reseat);
+    return launch_status();
+}
+
+int lz_wave_reseat(const LzStateSoA* s, int64_t G, uint8_t* done, int64_t* plies, int64_t* step_counts, int64_t* budget,
+                   int64_t* next_game, int64_t* slot_game, uint8_t* reseated, void* stream) {
+    if (G < 0) return LZ_ERR_ARG;
+    if (G == 0) return LZ_OK;
+    if (!soa_ok(s) || !done || !plies || !step_counts || !budget || !next_game || !slot_game) return LZ_ERR_ARG;
+    if (!soa_aligned(s)) return LZ_ERR_ALIGN;
+    hipLaunchKernelGGL(wave_reseat_kernel, dim3(1), dim3(kRowsBlock), 0, as_stream(stream), *s, G, done, plies,
+                       step_counts, budget, next_game, slot_game, reseated);
     return launch_status();
 }
 

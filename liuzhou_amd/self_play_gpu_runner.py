@@ -6,6 +6,7 @@ per ply: search -> append trajectory rows -> `self_play_step_inplace` -> finaliz
 """
 from __future__ import annotations
 
+import os
 import time
 from typing import Dict, Tuple
 
@@ -20,6 +21,39 @@ _DELTA_MIN, _DELTA_MAX = -18, 18
 _TRACKED = ("root_puct_ms", "pack_writeback_ms", "self_play_step_ms", "finalize_ms")
 
 
+def _fused_wave(fused, tail, states, plies, done, step_index, step_counts, lengths, t_init, t_final, t_threshold,
+                add_noise, games_to_start: int = 0) -> None:
+    """Wave loop with the fused search and the device tail: nothing in a ply needs the host.  `games_to_start` > 0:
+    a slot whose game has finished starts the next game at once (lz_wave_reseat) instead of idling until the whole
+    wave is done; `lengths` is then indexed by game.  The loop ends on the `all done` flag of TWO plies ago (copied
+    to pinned memory behind an event), so the host stays one ply ahead of the device and at most one extra, fully
+    masked ply is run."""
+    dev = states.board.device
+    g = int(done.numel())
+    flags = [torch.zeros((1,), dtype=torch.bool).pin_memory() for _ in range(2)]
+    events = [torch.cuda.Event() for _ in range(2)]
+    budget = torch.full((1,), int(games_to_start), dtype=torch.int64, device=dev)
+    next_game = torch.full((1,), g, dtype=torch.int64, device=dev)
+    slot_game = torch.arange(g, dtype=torch.int64, device=dev)
+    ply = 0
+    while True:
+        k = ply & 1
+        if ply >= 2:
+            events[k].synchronize()
+            if bool(flags[k].item()):
+                break
+        if games_to_start > 0 and ply > 0:
+            tail.start_next_games(states, plies, done, step_counts, budget, next_game, slot_game)
+        temps = torch.where(plies < int(t_threshold), float(t_init), float(t_final)).to(torch.float32)
+        search = fused.search_batch(states, temperatures=temps, add_dirichlet_noise=add_noise)
+        tail.record(states, done, step_index, step_counts, search)
+        tail.step_finish(states, plies, done, step_index, step_counts, search, lengths=lengths, slot_game=slot_game)
+        # all finished and nothing left to start (a finished slot restarts at the top of the next ply otherwise)
+        flags[k].copy_((done.all() & (budget <= 0).all()).view(1), non_blocking=True)
+        events[k].record(torch.cuda.current_stream(dev))
+        ply += 1
+
+
 def self_play_v1_gpu(model, num_games: int, mcts_simulations: int, temperature_init: float,
                      temperature_final: float, temperature_threshold: int, exploration_weight: float, device: str,
                      add_dirichlet_noise: bool = True, dirichlet_alpha: float = 0.3, dirichlet_epsilon: float = 0.25,
@@ -27,7 +61,7 @@ def self_play_v1_gpu(model, num_games: int, mcts_simulations: int, temperature_i
                      sample_moves: bool = True, concurrent_games: int = 8, child_eval_mode: str = "value_only",
                      sparse_ply: int = 1, sparse_top_k: int = 8, inference_engine=None,
                      collect_step_timing: bool = False, verbose: bool = False,
-                     autocast_dtype: str = "float16", fused_search: bool = True
+                     autocast_dtype: str = "float16", fused_search: bool = True, continuous_waves: bool = True
                      ) -> Tuple[TensorSelfPlayBatch, SelfPlayV1Stats]:
     if num_games <= 0:
         raise ValueError("num_games must be positive.")
@@ -50,7 +84,7 @@ def self_play_v1_gpu(model, num_games: int, mcts_simulations: int, temperature_i
     fused = None
     if (fused_search and hasattr(model, "desc") and inference_engine is None and opening_n == 0 and
             str(child_eval_mode) == "value_only" and int(sparse_ply) <= 1 and not collect_step_timing and
-            int(num_games) % wave == 0):
+            (int(num_games) % wave == 0 or continuous_waves)):
         from .root_search_fused import FusedRootSearch
         fused = FusedRootSearch(model, wave, cfg.num_simulations, dev, exploration_weight=cfg.exploration_weight,
                                 add_dirichlet_noise=cfg.add_dirichlet_noise, dirichlet_alpha=cfg.dirichlet_alpha,
@@ -59,6 +93,11 @@ def self_play_v1_gpu(model, num_games: int, mcts_simulations: int, temperature_i
 
     outcome = torch.zeros((3,), dtype=torch.int64, device=dev)
     delta_hist = torch.zeros((_DELTA_MAX - _DELTA_MIN + 1,), dtype=torch.int64, device=dev)
+    tail = None
+    if fused is not None and os.environ.get("LZ_WAVE_TAIL", "1") != "0":   # device-side record / move / finalise (wave_tail.py)
+        from .wave_tail import WaveTail
+        tail = WaveTail(buffer, wave, max_plies, dev, soft_value_k=float(soft_value_k))
+        outcome, delta_hist = tail.outcome, tail.delta_hist
     lengths = torch.zeros((int(num_games),), dtype=torch.int64, device=dev)
     timing_ms: Dict[str, float] = {k: 0.0 for k in _TRACKED}
     timing_calls: Dict[str, int] = {k: 0 for k in _TRACKED}
@@ -78,7 +117,10 @@ def self_play_v1_gpu(model, num_games: int, mcts_simulations: int, temperature_i
                 self.e.record(); events.append((self.n, self.s, self.e))
 
     started = time.perf_counter()
-    for base in range(0, int(num_games), wave):
+    # continuous_waves (fused path): ONE wave whose finished slots start the remaining games at once, instead of the
+    # reference's sequential waves that idle until their longest game has ended (self_play_gpu_runner.py:84-90)
+    continuous = tail is not None and bool(continuous_waves)
+    for base in range(0, wave if continuous else int(num_games), wave):
         g = min(wave, int(num_games) - base)
         states = GpuStateBatch.initial(dev, g)
         step_index = torch.full((g, max_plies), -1, dtype=torch.int64, device=dev)
@@ -86,6 +128,12 @@ def self_play_v1_gpu(model, num_games: int, mcts_simulations: int, temperature_i
         plies = torch.zeros((g,), dtype=torch.int64, device=dev)
         done = torch.zeros((g,), dtype=torch.bool, device=dev)
         ones = torch.ones((g,), dtype=torch.int64, device=dev)
+        if tail is not None:
+            _fused_wave(fused, tail, states, plies, done, step_index, step_counts,
+                        lengths if continuous else lengths[base:base + g], temperature_init, temperature_final,
+                        temperature_threshold, add_dirichlet_noise,
+                        games_to_start=int(num_games) - wave if continuous else 0)
+            continue
         while True:
             active = torch.nonzero(~done).view(-1)
             n_active = int(active.numel())
@@ -96,7 +144,7 @@ def self_play_v1_gpu(model, num_games: int, mcts_simulations: int, temperature_i
             temps = torch.where(act_plies < int(temperature_threshold), float(temperature_init),
                                 float(temperature_final)).to(torch.float32)
             force = (act_plies < opening_n) if opening_n > 0 else None
-            if fused is not None:
+            if fused is not None and g == fused.B:              # LZ_WAVE_TAIL=0: fused search, host-side tail
                 full_temps = torch.where(plies < int(temperature_threshold), float(temperature_init),
                                          float(temperature_final)).to(torch.float32)
                 search = fused.search_batch(states, temperatures=full_temps, add_dirichlet_noise=add_dirichlet_noise)
@@ -134,6 +182,8 @@ def self_play_v1_gpu(model, num_games: int, mcts_simulations: int, temperature_i
 
     if dev.type == "cuda":
         torch.cuda.synchronize(dev)
+    if tail is not None:
+        tail.check_overflow()
     elapsed = max(1e-9, time.perf_counter() - started)
     for name, s, e in events:
         timing_ms[name] += float(s.elapsed_time(e)); timing_calls[name] += 1

@@ -16,7 +16,8 @@ from .trajectory_buffer import TensorTrajectoryBuffer
 class SteadyStateRootSelfPlay:
     def __init__(self, model, num_games: int, config: V1RootMCTSConfig, device, *, temperature_init: float = 1.0,
                  temperature_final: float = 0.1, temperature_threshold: int = 10, max_game_plies: int = 512,
-                 arena_rows: Optional[int] = None, seed: int = 12345, fused_search: bool = True) -> None:
+                 arena_rows: Optional[int] = None, seed: int = 12345, fused_search: bool = True,
+                 device_tail: bool = True) -> None:
         self.dev = torch.device(device)
         self.B = int(num_games)
         self.cfg = config
@@ -43,9 +44,19 @@ class SteadyStateRootSelfPlay:
         self.buffer = TensorTrajectoryBuffer(self.dev, TOTAL_ACTION_DIM, initial_capacity=arena_rows or self.B * 64)
         self.gen = torch.Generator(device=self.dev)
         self.gen.manual_seed(int(seed))
-        self.games_finished = 0
+        self._games_finished = 0
         self.positions = 0
-        self.outcome = torch.zeros((3,), dtype=torch.int64, device=self.dev)
+        # device_tail: record / move / finalise / re-seat on the device (wave_tail.WaveTail), no host round trip per step
+        self.tail = None
+        if device_tail:
+            from .wave_tail import WaveTail
+            self.tail = WaveTail(self.buffer, self.B, self.max_plies, self.dev, soft_value_k=float(config.soft_value_k),
+                                 reseat=True)
+        self.outcome = self.tail.outcome if self.tail is not None else torch.zeros((3,), dtype=torch.int64, device=self.dev)
+
+    @property
+    def games_finished(self) -> int:
+        return self._games_finished + (int(self.tail.finished.item()) if self.tail is not None else 0)
 
     @property
     def leaf_evals(self) -> int:
@@ -84,6 +95,16 @@ class SteadyStateRootSelfPlay:
     def step(self) -> None:
         temps = torch.where(self.plies < self.t_thr, self.t_init, self.t_final).to(torch.float32)
         search = (self.fused or self.mcts).search_batch(self.states, temperatures=temps)
+        self.finish_step(search)
+
+    def finish_step(self, search, reseated: Optional[torch.Tensor] = None) -> None:
+        """Trajectory rows, the chosen move, finalisation and re-seating of finished games for one searched ply."""
+        if self.tail is not None:
+            self.tail.record(self.states, self.done, self.step_index, self.step_counts, search)
+            self.tail.step_finish(self.states, self.plies, self.done, self.step_index, self.step_counts, search,
+                                  reseated=reseated)
+            self.positions += self.B
+            return
         rows = self.buffer.append_steps(search.model_input, search.legal_mask, search.policy_dense,
                                         self.states.current_player)
         self.step_index[self.all_idx, self.step_counts] = rows
@@ -98,5 +119,7 @@ class SteadyStateRootSelfPlay:
                                                            step_counts=self.step_counts, slots=fin,
                                                            result_from_black=result, soft_value_from_black=soft)
             self.outcome.add_(out)
-            self.games_finished += int(fin.numel())
+            self._games_finished += int(fin.numel())
             self._reset_slots(fin)
+            if reseated is not None:
+                reseated.index_fill_(0, fin, 1)

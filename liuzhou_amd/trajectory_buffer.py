@@ -41,6 +41,11 @@ class TensorTrajectoryBuffer:
         self._size = 0
         self._shape: Optional[Tuple[int, int, int]] = None
         self._state = self._legal = self._policy = self._value = self._soft = self._sign = None
+        # device-side appends (wave_tail.WaveTail): the row cursor lives on the device, the host only tracks an upper
+        # bound of it and reads the true value back when it has to (growth, host appends, build)
+        self._cursor: Optional[torch.Tensor] = None
+        self._upper = 0
+        self._device_dirty = False
 
     def _allocate(self, capacity: int, shape: Tuple[int, int, int]) -> None:
         dev = self.device
@@ -60,6 +65,37 @@ class TensorTrajectoryBuffer:
         for dst, src in zip((self._state, self._legal, self._policy, self._value, self._soft, self._sign), old):
             dst[:n].copy_(src[:n])
 
+    # ---- device-side appends --------------------------------------------------------------------
+    def reserve_rows(self, n: int, shape: Tuple[int, int, int] = (11, 6, 6)) -> torch.Tensor:
+        """Make room for up to `n` more rows written by the device and return the int64[1] device cursor."""
+        if self._state is None:
+            self._allocate(self._capacity, tuple(shape))
+        if self._cursor is None:
+            self._cursor = torch.full((1,), self._size, dtype=torch.int64, device=self.device)
+            self._upper = self._size
+        if self._upper + int(n) > self._capacity:
+            self.sync_cursor()
+            if self._size + int(n) > self._capacity:
+                self._grow(self._size + int(n))
+        self._upper += int(n)
+        self._device_dirty = True
+        return self._cursor
+
+    def sync_cursor(self) -> int:
+        """Read the device cursor back (one host synchronisation)."""
+        if self._device_dirty:
+            self._size = int(self._cursor.item())
+            self._upper = self._size
+            self._device_dirty = False
+        return self._size
+
+    @property
+    def capacity(self) -> int:
+        return self._capacity
+
+    def arena(self):
+        return self._state, self._legal, self._policy, self._value, self._soft, self._sign
+
     def append_step(self, model_input, legal_mask, policy_dense, player_sign: int) -> int:
         idx = self.append_steps(model_input.unsqueeze(0), legal_mask.unsqueeze(0), policy_dense.unsqueeze(0),
                                 torch.tensor([int(player_sign)], dtype=torch.int64, device=model_input.device))
@@ -76,6 +112,7 @@ class TensorTrajectoryBuffer:
         if int(sign.numel()) != n:
             raise ValueError(f"player_sign must have {n} elements, got {int(sign.numel())}")
         shape = tuple(int(x) for x in model_input.shape[1:])
+        self.sync_cursor()
         if self._state is None:
             self._allocate(self._capacity, shape)
         elif self._shape != shape:
@@ -91,10 +128,14 @@ class TensorTrajectoryBuffer:
         self._soft[s].fill_(float("nan"))
         self._sign[s].copy_(torch.where(sign >= 0, 1, -1).to(torch.int8))
         start, self._size = self._size, end
+        if self._cursor is not None:
+            self._cursor.fill_(end)
+            self._upper = end
         return torch.arange(start, end, dtype=torch.int64, device=self.device)
 
     def finalize_games_inplace(self, *, step_index_matrix, step_counts, slots, result_from_black,
                                soft_value_from_black):
+        self.sync_cursor()
         if self._size == 0:
             e = torch.empty((0,), dtype=torch.int64, device=self.device)
             return e, e.clone(), torch.zeros((3,), dtype=torch.int64, device=self.device)
@@ -102,6 +143,7 @@ class TensorTrajectoryBuffer:
                                                    step_counts, slots, result_from_black, soft_value_from_black)
 
     def build(self) -> TensorSelfPlayBatch:
+        self.sync_cursor()
         if self._size == 0:
             shape = self._shape or (11, 6, 6)
             dev = self.device

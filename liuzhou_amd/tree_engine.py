@@ -399,20 +399,8 @@ class SteadyStateTreeSelfPlay:
         temps = torch.where(p.plies < p.t_thr, p.t_init, p.t_final).to(torch.float32)
         search = self.mcts.search_batch(p.states, temperatures=temps, reset=self._reseated)
         self._reseated.zero_()
-        rows = p.buffer.append_steps(search.model_input, search.legal_mask, search.policy_dense, p.states.current_player)
-        p.step_index[p.all_idx, p.step_counts] = rows
-        p.step_counts.add_(p.ones)
-        fin, result, soft = v0_core.self_play_step_inplace(*p.states.tensors(), p.plies, p.done, p.all_idx,
-                                                           search.chosen_action_codes, search.terminal_mask,
-                                                           search.chosen_valid_mask, p.max_plies, 2.0)
+        p.finish_step(search, reseated=self._reseated)
         self.positions += self.B
-        if int(fin.numel()) > 0:
-            _, _, out = p.buffer.finalize_games_inplace(step_index_matrix=p.step_index, step_counts=p.step_counts,
-                                                        slots=fin, result_from_black=result, soft_value_from_black=soft)
-            p.outcome.add_(out)
-            p.games_finished += int(fin.numel())
-            p._reset_slots(fin)
-            self._reseated.index_fill_(0, fin, 1)
 
 
 def self_play_tree_gpu(model, num_games: int, mcts_simulations: int, temperature_init: float, temperature_final: float,

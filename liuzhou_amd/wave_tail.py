@@ -1,0 +1,82 @@
+"""Device-side tail of one ply of the v1 wave loop for a fixed wave of slots: trajectory rows, the move and the
+finalisation of finished games without a host round trip (`lz_wave_record`, `lz_wave_step_finish`).
+
+It replaces, for whole waves, the sequence `append_steps` -> `step_index[...] = rows` -> `self_play_step_inplace` ->
+`finalize_games_inplace` of v1/python/self_play_gpu_runner.py:205-247, whose `nonzero`-shaped outputs force one host
+synchronisation per ply; finished slots stay in the batch and are masked by `done`."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib as L
+from .mcts_gpu import GpuStateBatch, RootSearchBatchOutput
+from .trajectory_buffer import TensorTrajectoryBuffer
+
+DELTA_BINS = 37
+
+
+class WaveTail:
+    def __init__(self, buffer: TensorTrajectoryBuffer, num_slots: int, max_game_plies: int, device,
+                 soft_value_k: float = 2.0, reseat: bool = False) -> None:
+        dev = torch.device(device)
+        if dev.type != "cuda":
+            raise RuntimeError("WaveTail needs a HIP device (no CPU path)")
+        self.buffer, self.G, self.max_plies, self.device = buffer, int(num_slots), int(max_game_plies), dev
+        self.soft_k, self.reseat = float(soft_value_k), bool(reseat)
+        z = lambda n, dt: torch.zeros((n,), dtype=dt, device=dev)
+        self.rows = z(self.G, torch.int64)
+        self.overflow = z(1, torch.int32)
+        self.outcome = z(3, torch.int64)
+        self.delta_hist = z(DELTA_BINS, torch.int64)
+        self.finished = z(1, torch.int64)
+
+    def record(self, states: GpuStateBatch, done: torch.Tensor, step_index: torch.Tensor, step_counts: torch.Tensor,
+               search: RootSearchBatchOutput) -> None:
+        """Append this ply's sample of every live slot to the trajectory arena."""
+        G = self.G
+        cursor = self.buffer.reserve_rows(G, tuple(int(x) for x in search.model_input.shape[1:]))
+        a_state, a_legal, a_policy, a_value, a_soft, a_sign = self.buffer.arena()
+        mi, lm, pol = search.model_input.contiguous(), search.legal_mask.contiguous(), search.policy_dense.contiguous()
+        T = int(pol.shape[1])
+        with torch.cuda.device(self.device):
+            L.check(L.lib().lz_wave_record(
+                L.ptr(done), L.i64(G), L.ptr(cursor), L.i64(self.buffer.capacity), L.i64(int(step_index.shape[1])),
+                L.ptr(step_index), L.ptr(step_counts), L.ptr(self.rows), L.ptr(self.overflow), L.ptr(mi), L.ptr(lm),
+                L.ptr(pol), L.ptr(states.current_player), L.i64(T), L.ptr(a_state), L.ptr(a_legal), L.ptr(a_policy),
+                L.ptr(a_value), L.ptr(a_soft), L.ptr(a_sign), L.stream_ptr(self.device)), "wave_record")
+
+    def step_finish(self, states: GpuStateBatch, plies: torch.Tensor, done: torch.Tensor, step_index: torch.Tensor,
+                    step_counts: torch.Tensor, search: RootSearchBatchOutput, lengths: Optional[torch.Tensor] = None,
+                    reseated: Optional[torch.Tensor] = None, slot_game: Optional[torch.Tensor] = None) -> None:
+        """Play the chosen move of every live slot; finalise (and re-seat, if asked) the games that end."""
+        _, _, _, a_value, a_soft, a_sign = self.buffer.arena()
+        ts = states.tensors()
+        if any(not t.is_contiguous() for t in ts):
+            raise RuntimeError("WaveTail.step_finish: state tensors must be contiguous (they are updated in place)")
+        codes = search.chosen_action_codes.contiguous()
+        term = search.terminal_mask.contiguous()
+        cvalid = search.chosen_valid_mask.contiguous()
+        with torch.cuda.device(self.device):
+            L.check(L.lib().lz_wave_step_finish(
+                C.byref(L.soa(ts)), L.i64(self.G), L.ptr(plies), L.ptr(done), L.ptr(codes), L.ptr(term), L.ptr(cvalid),
+                L.i64(self.max_plies), C.c_float(self.soft_k), L.ptr(a_value), L.ptr(a_soft), L.ptr(a_sign),
+                L.ptr(step_index), L.ptr(step_counts), L.i64(int(step_index.shape[1])), L.ptr(self.outcome),
+                L.ptr(self.delta_hist), L.ptr(lengths), L.ptr(slot_game), L.ptr(self.finished), L.ptr(reseated),
+                C.c_int(1 if self.reseat else 0), L.stream_ptr(self.device)), "wave_step_finish")
+
+    def start_next_games(self, states: GpuStateBatch, plies: torch.Tensor, done: torch.Tensor, step_counts: torch.Tensor,
+                         budget: torch.Tensor, next_game: torch.Tensor, slot_game: torch.Tensor,
+                         reseated: Optional[torch.Tensor] = None) -> None:
+        """Finished slots restart from the empty board (ascending slot order) while `budget` games remain to be started."""
+        with torch.cuda.device(self.device):
+            L.check(L.lib().lz_wave_reseat(C.byref(L.soa(states.tensors())), L.i64(self.G), L.ptr(done), L.ptr(plies),
+                                           L.ptr(step_counts), L.ptr(budget), L.ptr(next_game), L.ptr(slot_game),
+                                           L.ptr(reseated), L.stream_ptr(self.device)), "wave_reseat")
+
+    def check_overflow(self) -> None:
+        n = int(self.overflow.item())
+        if n:
+            raise RuntimeError(f"WaveTail: {n} trajectory rows were dropped (arena or step-index capacity too small)")

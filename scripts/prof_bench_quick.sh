@@ -7,6 +7,6 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -- python3 "$GRAF
 python3 - <<PY
 import csv, glob
 rows = list(csv.DictReader(open(glob.glob("$OUT/*/*kernel_stats.csv")[0])))
-for r in rows[:6]:
+for r in rows[:int("${TOPN:-6}")]:
     print("%-60s calls=%s avg_us=%.2f pct=%s" % (r["Name"][:60], r["Calls"], float(r["AverageNs"]) / 1e3, r["Percentage"]))
 PY

@@ -134,8 +134,12 @@ def test_steady_state_root_population_fused_equals_operator_chain():
     torch.manual_seed(20260314)
     net = FusedNet(ChessNet(**MODEL_CONFIGS["b6c64"]).eval().to(dev))
     cfg = V1RootMCTSConfig(num_simulations=32, add_dirichlet_noise=False, sample_moves=False)
-    pops = [SteadyStateRootSelfPlay(net, 300, cfg, dev, seed=5, max_game_plies=40, fused_search=f) for f in (True, False)]
+    # [0] fused search + device tail (record / move / finalise / re-seat without the host), [1] operator chain + host
+    # bookkeeping, [2] operator chain + device tail
+    pops = [SteadyStateRootSelfPlay(net, 300, cfg, dev, seed=5, max_game_plies=40, fused_search=f, device_tail=t)
+            for f, t in ((True, True), (False, False), (False, True))]
     assert pops[0].fused is not None and pops[1].fused is None
+    assert pops[0].tail is not None and pops[1].tail is None and pops[2].tail is not None
     for p in pops:
         p.preroll(30)
         for _ in range(25):
@@ -145,7 +149,17 @@ def test_steady_state_root_population_fused_equals_operator_chain():
     assert torch.equal(a.state_tensors, b.state_tensors) and torch.equal(a.legal_masks, b.legal_masks)
     assert torch.equal(a.policy_targets, b.policy_targets)
     assert torch.equal(torch.nan_to_num(a.value_targets, nan=9.0), torch.nan_to_num(b.value_targets, nan=9.0))
-    assert pops[0].games_finished == pops[1].games_finished > 0
+    c = pops[2].buffer.build()
+    assert torch.equal(c.state_tensors, b.state_tensors) and torch.equal(c.policy_targets, b.policy_targets)
+    assert torch.equal(torch.nan_to_num(c.soft_value_targets, nan=9.0), torch.nan_to_num(b.soft_value_targets, nan=9.0))
+    assert torch.equal(torch.nan_to_num(a.soft_value_targets, nan=9.0), torch.nan_to_num(b.soft_value_targets, nan=9.0))
+    assert pops[0].games_finished == pops[1].games_finished == pops[2].games_finished > 0
+    assert torch.equal(pops[0].outcome, pops[1].outcome) and torch.equal(pops[2].outcome, pops[1].outcome)
+    for q in (pops[0], pops[2]):
+        q.tail.check_overflow()
+        for t in ("plies", "step_counts"):
+            assert torch.equal(getattr(q, t), getattr(pops[1], t)), t
+        assert torch.equal(q.states.board, pops[1].states.board)
     assert pops[0].leaf_evals == pops[1].leaf_evals
 
 
@@ -168,3 +182,42 @@ def test_root_self_play_runner_fused_equals_operator_chain():
     for k in ("state_tensors", "legal_masks", "policy_targets", "value_targets", "soft_value_targets"):
         assert torch.equal(getattr(a, k), getattr(b, k)), k
     assert (sa.black_wins, sa.white_wins, sa.draws) == (sb.black_wins, sb.white_wins, sb.draws)
+    # the fused path also records, moves and finalises on the device (wave_tail.WaveTail): same bookkeeping
+    assert sa.piece_delta_buckets == sb.piece_delta_buckets and sum(sa.piece_delta_buckets.values()) == 96
+    assert sa.avg_game_length == sb.avg_game_length and sa.num_positions == sb.num_positions
+
+
+def test_root_self_play_runner_continuous_waves_start_next_games_in_finished_slots():
+    """80 sampled games through 32 slots: finished slots start the remaining games at once (lz_wave_reseat); every game
+    is finalised exactly once, the bookkeeping adds up and the run is reproducible from the torch seed."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from liuzhou_amd.net import ChessNet, MODEL_CONFIGS
+    from liuzhou_amd.net_hip import FusedNet
+    from liuzhou_amd.self_play_gpu_runner import self_play_v1_gpu
+    torch.manual_seed(20260314)
+    net = FusedNet(ChessNet(**MODEL_CONFIGS["b6c64"]).eval().to("cuda:0"))
+    kw = dict(num_games=80, mcts_simulations=16, temperature_init=1.0, temperature_final=0.5, temperature_threshold=10,
+              exploration_weight=1.0, device="cuda:0", add_dirichlet_noise=True, sample_moves=True, max_game_plies=160,
+              concurrent_games=32)
+    runs = []
+    for _ in range(2):
+        torch.manual_seed(77)
+        runs.append(self_play_v1_gpu(net, **kw))
+    (a, sa), (b, sb) = runs
+    assert sa.mcts_counters.get("fused_root_search") == 1
+    assert sa.num_games == 80 and sa.black_wins + sa.white_wins + sa.draws == 80
+    assert sum(sa.piece_delta_buckets.values()) == 80
+    assert a.num_samples == sa.num_positions == round(sa.avg_game_length * 80)
+    assert not torch.isnan(a.value_targets).any() and not torch.isnan(a.soft_value_targets).any()
+    assert a.value_targets.abs().max() <= 1.0 and (a.policy_targets.sum(dim=1) - 1.0).abs().max() < 1e-4
+    assert bool((a.policy_targets[~a.legal_masks] == 0).all())
+    # sampled games differ in length, so slots re-seat at different plies: more plies than one game, fewer than 3 waves
+    assert a.num_samples > 80 * 20
+    for k in ("state_tensors", "legal_masks", "policy_targets", "value_targets", "soft_value_targets"):
+        assert torch.equal(getattr(a, k), getattr(b, k)), k
+    assert sa.piece_delta_buckets == sb.piece_delta_buckets
+    # sequential waves (the reference's loop) play the same number of games to the same kind of samples
+    torch.manual_seed(77)
+    c, sc = self_play_v1_gpu(net, continuous_waves=False, **{**kw, "num_games": 64})
+    assert sc.black_wins + sc.white_wins + sc.draws == 64 and not torch.isnan(c.value_targets).any()
