@@ -21,39 +21,6 @@ _DELTA_MIN, _DELTA_MAX = -18, 18
 _TRACKED = ("root_puct_ms", "pack_writeback_ms", "self_play_step_ms", "finalize_ms")
 
 
-def _fused_wave(fused, tail, states, plies, done, step_index, step_counts, lengths, t_init, t_final, t_threshold,
-                add_noise, games_to_start: int = 0) -> None:
-    """Wave loop with the fused search and the device tail: nothing in a ply needs the host.  `games_to_start` > 0:
-    a slot whose game has finished starts the next game at once (lz_wave_reseat) instead of idling until the whole
-    wave is done; `lengths` is then indexed by game.  The loop ends on the `all done` flag of TWO plies ago (copied
-    to pinned memory behind an event), so the host stays one ply ahead of the device and at most one extra, fully
-    masked ply is run."""
-    dev = states.board.device
-    g = int(done.numel())
-    flags = [torch.zeros((1,), dtype=torch.bool).pin_memory() for _ in range(2)]
-    events = [torch.cuda.Event() for _ in range(2)]
-    budget = torch.full((1,), int(games_to_start), dtype=torch.int64, device=dev)
-    next_game = torch.full((1,), g, dtype=torch.int64, device=dev)
-    slot_game = torch.arange(g, dtype=torch.int64, device=dev)
-    ply = 0
-    while True:
-        k = ply & 1
-        if ply >= 2:
-            events[k].synchronize()
-            if bool(flags[k].item()):
-                break
-        if games_to_start > 0 and ply > 0:
-            tail.start_next_games(states, plies, done, step_counts, budget, next_game, slot_game)
-        temps = torch.where(plies < int(t_threshold), float(t_init), float(t_final)).to(torch.float32)
-        search = fused.search_batch(states, temperatures=temps, add_dirichlet_noise=add_noise)
-        tail.record(states, done, step_index, step_counts, search)
-        tail.step_finish(states, plies, done, step_index, step_counts, search, lengths=lengths, slot_game=slot_game)
-        # all finished and nothing left to start (a finished slot restarts at the top of the next ply otherwise)
-        flags[k].copy_((done.all() & (budget <= 0).all()).view(1), non_blocking=True)
-        events[k].record(torch.cuda.current_stream(dev))
-        ply += 1
-
-
 def self_play_v1_gpu(model, num_games: int, mcts_simulations: int, temperature_init: float,
                      temperature_final: float, temperature_threshold: int, exploration_weight: float, device: str,
                      add_dirichlet_noise: bool = True, dirichlet_alpha: float = 0.3, dirichlet_epsilon: float = 0.25,
@@ -129,10 +96,11 @@ def self_play_v1_gpu(model, num_games: int, mcts_simulations: int, temperature_i
         done = torch.zeros((g,), dtype=torch.bool, device=dev)
         ones = torch.ones((g,), dtype=torch.int64, device=dev)
         if tail is not None:
-            _fused_wave(fused, tail, states, plies, done, step_index, step_counts,
-                        lengths if continuous else lengths[base:base + g], temperature_init, temperature_final,
-                        temperature_threshold, add_dirichlet_noise,
-                        games_to_start=int(num_games) - wave if continuous else 0)
+            tail.run(lambda st, temps, dn, reseated: fused.search_batch(st, temperatures=temps,
+                                                                        add_dirichlet_noise=add_dirichlet_noise),
+                     states, plies, done, step_index, step_counts, lengths if continuous else lengths[base:base + g],
+                     temperature_init, temperature_final, temperature_threshold,
+                     games_to_start=int(num_games) - wave if continuous else 0)
             continue
         while True:
             active = torch.nonzero(~done).view(-1)

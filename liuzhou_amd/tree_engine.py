@@ -410,8 +410,8 @@ def self_play_tree_gpu(model, num_games: int, mcts_simulations: int, temperature
                        sample_moves: bool = True, concurrent_games: int = 8, verbose: bool = False,
                        policy_target_temperature: Optional[float] = None,
                        policy_target_prior_pseudocount: float = 0.0, reuse_tree: bool = True,
-                       reuse_factor: float = -1.0, dual_stream: Optional[bool] = None
-                       ) -> Tuple[TensorSelfPlayBatch, SelfPlayV1Stats]:
+                       reuse_factor: float = -1.0, dual_stream: Optional[bool] = None, continuous_waves: bool = True,
+                       device_tail: bool = True) -> Tuple[TensorSelfPlayBatch, SelfPlayV1Stats]:
     """Tree-search twin of self_play_v1_gpu (same outputs); mirrors v1/python/portable_self_play.py:82-284,
     including the subtree reuse it performs on every move (:191, `reuse_tree`)."""
     dev = torch.device(device)
@@ -429,8 +429,18 @@ def self_play_tree_gpu(model, num_games: int, mcts_simulations: int, temperature
     buffer = TensorTrajectoryBuffer(dev, TOTAL_ACTION_DIM, max_steps_hint=max_game_plies, concurrent_games_hint=wave)
     outcome = torch.zeros((3,), dtype=torch.int64, device=dev)
     lengths = torch.zeros((int(num_games),), dtype=torch.int64, device=dev)
+    # device_tail: rows / move / finalisation on the device (wave_tail.WaveTail); continuous_waves: one wave whose
+    # finished slots start the remaining games at once instead of sequential waves that idle until their longest game
+    tail = None
+    delta_hist = None
+    if device_tail:
+        from .wave_tail import WaveTail
+        tail = WaveTail(buffer, wave, int(max_game_plies), dev, soft_value_k=float(soft_value_k))
+        outcome, delta_hist = tail.outcome, tail.delta_hist
+    continuous = tail is not None and bool(continuous_waves)
+    wasted_plies = 0
     started = time.perf_counter()
-    for base in range(0, int(num_games), wave):
+    for base in range(0, wave if continuous else int(num_games), wave):
         g = min(wave, int(num_games) - base)
         states = GpuStateBatch.initial(dev, wave)
         step_index = torch.full((wave, max_game_plies), -1, dtype=torch.int64, device=dev)
@@ -440,6 +450,16 @@ def self_play_tree_gpu(model, num_games: int, mcts_simulations: int, temperature
         if g < wave:
             done[g:] = True
         mcts.reset_trees()
+        if tail is not None:
+            force_n = int(opening_random_moves)
+            tail.run(lambda st, temps, dn, reseated: mcts.search_batch(
+                         st, temperatures=temps, active=~dn, reset=reseated,
+                         force_uniform_random_mask=(plies < force_n) if force_n > 0 else None),
+                     states, plies, done, step_index, step_counts, lengths if continuous else lengths[base:base + g],
+                     temperature_init, temperature_final, temperature_threshold,
+                     games_to_start=int(num_games) - wave if continuous else 0)
+            wasted_plies += 1
+            continue
         while True:
             active = torch.nonzero(~done).view(-1)
             if int(active.numel()) == 0:
@@ -469,14 +489,20 @@ def self_play_tree_gpu(model, num_games: int, mcts_simulations: int, temperature
                 outcome.add_(f_out)
     torch.cuda.synchronize(dev)
     elapsed = max(1e-9, time.perf_counter() - started)
+    if tail is not None:
+        tail.check_overflow()
     batch = buffer.build()
     o = outcome.tolist()
+    hist = delta_hist.tolist() if delta_hist is not None else []
     keys = ("root_puct_ms", "pack_writeback_ms", "self_play_step_ms", "finalize_ms")
     stats = SelfPlayV1Stats(
         num_games=num_games, num_positions=batch.num_samples, black_wins=int(o[0]), white_wins=int(o[1]), draws=int(o[2]),
         avg_game_length=float(lengths.to(torch.float32).mean().item()), elapsed_sec=elapsed,
         positions_per_sec=float(batch.num_samples / elapsed), games_per_sec=float(num_games / elapsed),
         step_timing_ms={k: 0.0 for k in keys}, step_timing_ratio={k: 0.0 for k in keys},
-        step_timing_calls={k: 0 for k in keys}, mcts_counters={"leaf_eval_count": int(mcts.leaf_evals)},
-        piece_delta_buckets={}, device=str(dev))
+        step_timing_calls={k: 0 for k in keys},
+        # the device-tail loop runs one fully masked ply per wave after the last game has ended (wave_tail.WaveTail.run)
+        mcts_counters={"leaf_eval_count": int(mcts.leaf_evals) - wasted_plies * wave * (int(mcts_simulations) + 1),
+                       "masked_extra_plies": wasted_plies},
+        piece_delta_buckets={str(d - 18): int(v) for d, v in enumerate(hist)}, device=str(dev))
     return batch, stats

@@ -76,6 +76,43 @@ class WaveTail:
                                            L.ptr(step_counts), L.ptr(budget), L.ptr(next_game), L.ptr(slot_game),
                                            L.ptr(reseated), L.stream_ptr(self.device)), "wave_reseat")
 
+    def run(self, search_fn, states: GpuStateBatch, plies: torch.Tensor, done: torch.Tensor, step_index: torch.Tensor,
+            step_counts: torch.Tensor, lengths: torch.Tensor, t_init: float, t_final: float, t_threshold: int,
+            games_to_start: int = 0) -> int:
+        """The wave loop with nothing per ply on the host: `search_fn(states, temperatures, done, reseated)` ->
+        RootSearchBatchOutput for all slots (finished ones are masked by `done`; `reseated` uint8 marks slots that
+        have just started a new game), then record / move / finalise on the device.  `games_to_start` > 0: a slot
+        whose game has finished starts the next game at once (lz_wave_reseat) instead of idling until the whole wave
+        is done; `lengths` is then indexed by game.  The loop ends on the `all done` flag of TWO plies ago (copied to
+        pinned memory behind an event), so the host stays one ply ahead of the device; the price is exactly one
+        extra, fully masked ply at the end.  Returns the number of plies launched (including that one)."""
+        dev, g = self.device, self.G
+        flags = [torch.zeros((1,), dtype=torch.bool).pin_memory() for _ in range(2)]
+        events = [torch.cuda.Event() for _ in range(2)]
+        budget = torch.full((1,), int(games_to_start), dtype=torch.int64, device=dev)
+        next_game = torch.full((1,), g, dtype=torch.int64, device=dev)
+        slot_game = torch.arange(g, dtype=torch.int64, device=dev)
+        reseated = torch.zeros((g,), dtype=torch.uint8, device=dev)
+        ply = 0
+        while True:
+            k = ply & 1
+            if ply >= 2:
+                events[k].synchronize()
+                if bool(flags[k].item()):
+                    break
+            if games_to_start > 0 and ply > 0:
+                self.start_next_games(states, plies, done, step_counts, budget, next_game, slot_game, reseated)
+            temps = torch.where(plies < int(t_threshold), float(t_init), float(t_final)).to(torch.float32)
+            search = search_fn(states, temps, done, reseated)
+            reseated.zero_()
+            self.record(states, done, step_index, step_counts, search)
+            self.step_finish(states, plies, done, step_index, step_counts, search, lengths=lengths, slot_game=slot_game)
+            # all finished and nothing left to start (a finished slot restarts at the top of the next ply otherwise)
+            flags[k].copy_((done.all() & (budget <= 0).all()).view(1), non_blocking=True)
+            events[k].record(torch.cuda.current_stream(dev))
+            ply += 1
+        return ply
+
     def check_overflow(self) -> None:
         n = int(self.overflow.item())
         if n:

@@ -79,6 +79,16 @@ def test_tree_self_play_runner_dual_stream_matches_contract():
         assert bool((batch.policy_targets[~batch.legal_masks] == 0).all())
         assert bool(torch.isfinite(batch.value_targets).all())
         assert stats.mcts_counters["leaf_eval_count"] == 65 * 13 * 30
+    # 100 games through 40 slots: finished slots start the remaining games at once (60, then a partial batch of 20);
+    # the host-side wave loop (no device tail) plays the same number of positions in three sequential waves
+    for tail in (True, False):
+        batch, stats = self_play_tree_gpu(net, num_games=100, mcts_simulations=8, temperature_init=1.0,
+                                          temperature_final=0.1, temperature_threshold=10, exploration_weight=1.0,
+                                          device="cuda:0", max_game_plies=24, concurrent_games=40, device_tail=tail)
+        assert batch.num_samples == 100 * 24 == stats.num_positions and stats.avg_game_length == 24.0
+        assert stats.black_wins + stats.white_wins + stats.draws == 100
+        assert bool(torch.isfinite(batch.value_targets).all()) and bool(torch.isfinite(batch.soft_value_targets).all())
+        assert stats.mcts_counters["leaf_eval_count"] == 120 * 9 * 24      # 72 plies x all 40 slots x (8 sims + root)
 
 
 @pytest.mark.parametrize("sims,use_graph", [(1, False), (64, False), (200, True)])
