@@ -10,6 +10,7 @@
 #include <stdint.h>
 
 #include "lz_soa.h"
+#include "lz_wave.h"
 
 using namespace lz;
 
@@ -448,43 +449,58 @@ __global__ __launch_bounds__(kBlock) void root_puct_kernel(const float* __restri
     const int lane = lane_id();
     const int64_t root = wave_item();
     if (root >= R) return;
-    float p[SLOTS], lv[SLOTS], vis[SLOTS], vs[SLOTS];
+    float cp[SLOTS], lv[SLOTS], vis[SLOTS], vs[SLOTS], q[SLOTS];
     bool ok[SLOTS];
+    int live = 0;                                       // wave-uniform: slots beyond the last valid action are skipped
 #pragma unroll
     for (int j = 0; j < SLOTS; ++j) {
         const int a = j * kWave + lane;
         ok[j] = a < A && valid[root * A + (a < A ? a : 0)] != 0;
-        p[j] = a < A ? priors[root * A + a] : 0.f;
+        cp[j] = c * (a < A ? priors[root * A + a] : 0.f);           // first product of c * p * sqrt_total
         lv[j] = a < A ? leaf[root * A + a] : 0.f;
         vis[j] = 0.f;
         vs[j] = 0.f;
+        q[j] = 0.f;                                     // vs / max(vis, 1e-8), refreshed when the action is visited
+        if (__ballot(ok[j]) != 0ull) live = j + 1;
     }
     float total = 0.f;
     for (int64_t sim = 0; sim < sims; ++sim) {
         const float sqrt_total = sqrtf(total + 1.0f);      // correctly rounded (hipcc default)
-        unsigned long long key = 0ull;                  // 0 == "no candidate"
+        // same operation order as root_puct_fused.cu:53-56; built with -ffp-contract=off.  Highest score, lowest
+        // index on ties: wave maximum of the scores on DPP, then the first lane (of the first slot) that holds it.
+        float sc[SLOTS];
+        float best = -INFINITY;
+        bool any = false;
 #pragma unroll
         for (int j = 0; j < SLOTS; ++j) {
-            const float v = vis[j];
-            // same operation order as root_puct_fused.cu:53-56; built with -ffp-contract=off
-            const float q = v > 0.f ? (vs[j] / fmaxf(v, 1e-8f)) : 0.f;
-            const float u = c * p[j] * sqrt_total / (1.0f + v);
-            const float score = (q + u) + 0.0f;                      // +0 canonicalises -0
-            if (ok[j] && score == score) {
-                const unsigned long long k = ((unsigned long long)float_order(score) << 32) |
-                                             (unsigned long long)(0xFFFFFFFFu - (uint32_t)(j * kWave + lane));
-                key = k > key ? k : key;
+            sc[j] = -INFINITY;
+            if (j < live) {
+                const float u = cp[j] * sqrt_total / (1.0f + vis[j]);
+                const float score = (q[j] + u) + 0.0f;                // +0 canonicalises -0
+                const bool cand = ok[j] && score == score;
+                if (cand) { sc[j] = score; any = true; best = score > best ? score : best; }
+                else sc[j] = __builtin_nanf("");                      // never equal to the maximum
             }
         }
-        key = wave_max_u64(key);
-        if (key != 0ull) {
-            const int chosen = (int)(0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFull));
+        if (__ballot(any) == 0ull) continue;
+        const float m = lzw::wave_max(best);
+        int chosen = -1;
 #pragma unroll
-            for (int j = 0; j < SLOTS; ++j) {
-                if (chosen == j * kWave + lane) { vis[j] += 1.0f; vs[j] += lv[j]; }
+        for (int j = 0; j < SLOTS; ++j) {
+            if (j < live && chosen < 0) {
+                const unsigned long long hit = __ballot(sc[j] == m);
+                if (hit != 0ull) chosen = j * kWave + __builtin_ctzll(hit);
             }
-            total += 1.0f;
         }
+#pragma unroll
+        for (int j = 0; j < SLOTS; ++j) {
+            if (chosen == j * kWave + lane) {
+                vis[j] += 1.0f;
+                vs[j] += lv[j];
+                q[j] = vs[j] / fmaxf(vis[j], 1e-8f);
+            }
+        }
+        total += 1.0f;
     }
     float sv = 0.f, sw = 0.f;
 #pragma unroll
