@@ -537,6 +537,12 @@ __global__ __launch_bounds__(kBlock) void tree_expand_select_kernel(Tree t, cons
                                                                     const float* __restrict__ values,
                                                                     const float* __restrict__ noise, int noise_stride,
                                                                     float epsilon) {
+#ifndef LZ_EXP_NO_TREE_PRIO
+    // The kernel is a chain of dependent loads with a few dozen instructions in between; in the two-stream search it
+    // shares the SIMDs with the other half's network waves, which always have MFMAs to issue.  Raised wave priority
+    // lets the short bursts between two loads go first.
+    __builtin_amdgcn_s_setprio(3);
+#endif
     const int g = wave_game();
     if (g >= t.B) return;
     const int lane = lane_id();
