@@ -146,8 +146,10 @@ def test_steady_state_root_population_fused_equals_operator_chain():
     cfg = V1RootMCTSConfig(num_simulations=32, add_dirichlet_noise=False, sample_moves=False)
     # [0] fused search + device tail (record / move / finalise / re-seat without the host), [1] operator chain + host
     # bookkeeping, [2] operator chain + device tail
-    pops = [SteadyStateRootSelfPlay(net, 300, cfg, dev, seed=5, max_game_plies=40, fused_search=f, device_tail=t)
-            for f, t in ((True, True), (False, False), (False, True))]
+    # ([2] starts with room for two plies only: the arena grows under the device cursor several times)
+    pops = [SteadyStateRootSelfPlay(net, 300, cfg, dev, seed=5, max_game_plies=40, fused_search=f, device_tail=t,
+                                    arena_rows=r)
+            for f, t, r in ((True, True, None), (False, False, None), (False, True, 600))]
     assert pops[0].fused is not None and pops[1].fused is None
     assert pops[0].tail is not None and pops[1].tail is None and pops[2].tail is not None
     for p in pops:
