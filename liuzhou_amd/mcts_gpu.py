@@ -161,8 +161,6 @@ class V1RootMCTS:
 
     def __init__(self, model, config: V1RootMCTSConfig, device, inference_engine=None,
                  collect_timing: bool = False) -> None:
-        if int(config.sparse_ply) > 1:
-            raise NotImplementedError("sparse_ply > 1 (experimental in the reference, default 1) is not supported")
         mode = str(config.child_eval_mode).strip().lower()
         if mode not in ("value_only", "full"):
             raise ValueError(f"unknown child_eval_mode: {config.child_eval_mode}")
@@ -330,6 +328,55 @@ class V1RootMCTS:
             raise ValueError(f"temperatures size mismatch: expected {batch_size}, got {int(t.numel())}")
         return t
 
+    # ---- children of a batch of positions, valued from the parent mover's side ----
+    def _children_leaf_matrix(self, state: GpuStateBatch, codes_all, parents_all, flat_idx, R: int, M: int) -> torch.Tensor:
+        """leaf_mat [R, M]: value of every packed child as its parent's mover sees it; a child that ends the game
+        takes the soft piece-count value instead of the network's (mcts_gpu.py:1341-1375)."""
+        cfg = self.config
+        child = batch_apply_moves_compat(state, codes_all, parents_all)
+        if self._child_eval_mode == "full":
+            child_values = self._evaluate_batch(child)[4]
+        else:
+            child_values = self._evaluate_values_only(child)
+        parent_player = state.current_player.index_select(0, parents_all)
+        leaf = self._child_values_to_parent_perspective(child_values, parent_player, child.current_player)
+        term_child = self._terminal_mask_from_next_state(child)        # sync-free here
+        soft_black = self._soft_tanh_from_board_black(child.board, float(cfg.soft_value_k))
+        sign = torch.where(parent_player.ge(0), 1.0, -1.0).to(torch.float32)
+        leaf = torch.where(term_child, soft_black * sign, leaf)
+        leaf_mat = torch.zeros((R, M), dtype=torch.float32, device=state.device)
+        leaf_mat.view(-1).index_copy_(0, flat_idx, leaf)
+        return leaf_mat
+
+    def _refine_via_topk_lookahead(self, root_states: GpuStateBatch, leaf_mat: torch.Tensor, valid_mask: torch.Tensor,
+                                   code_mat: torch.Tensor) -> torch.Tensor:
+        """One ply deeper below the K best children of every root (mcts_gpu.py:976-1046): a child's value becomes
+        max(its value, the best value among its own children as its mover sees them).  Slots beyond a root's legal
+        count carry no action: they re-evaluate the root's first action and their result is dropped."""
+        R, M = int(valid_mask.shape[0]), int(valid_mask.shape[1])
+        K = min(int(self.config.sparse_top_k), M)
+        if K <= 0 or R <= 0:
+            return leaf_mat
+        dev = leaf_mat.device
+        top = torch.topk(leaf_mat.masked_fill(~valid_mask, float("-inf")), k=K, dim=1).indices      # [R, K]
+        picked = valid_mask.gather(1, top)
+        safe = torch.where(picked, top, top[:, :1].expand(-1, K))
+        l2_codes = code_mat.gather(1, safe.unsqueeze(-1).expand(-1, -1, 4)).reshape(-1, 4).contiguous()
+        parents = torch.arange(R, dtype=torch.int64, device=dev).repeat_interleave(K)
+        l2 = batch_apply_moves_compat(root_states, l2_codes, parents)
+        _, l2_mask, l2_meta, l2_probs, _ = self._evaluate_batch(l2)
+        (_, l2_roots, _, l2_valid, _, _, _, l2_flat, l2_codes_all, l2_parents_all) = \
+            v0_core.root_pack_sparse_actions(l2_mask, l2_probs, l2_meta)
+        refined = torch.zeros((R * K,), dtype=torch.float32, device=dev)          # no grandchildren -> 0
+        if int(l2_roots.numel()) > 0:
+            l3 = self._children_leaf_matrix(l2, l2_codes_all, l2_parents_all, l2_flat, int(l2_valid.shape[0]),
+                                            int(l2_valid.shape[1]))
+            best = l3.masked_fill(~l2_valid, float("-inf")).max(dim=1).values
+            refined.index_copy_(0, l2_roots, torch.where(torch.isfinite(best), best, torch.zeros_like(best)))
+        new = torch.maximum(leaf_mat.gather(1, top), refined.view(R, K))
+        keep = leaf_mat.gather(1, top)
+        return leaf_mat.scatter(1, top, torch.where(picked, new, keep))
+
     # ---- the search ----
     def search_batch(self, state: GpuStateBatch, *, temperatures=None, add_dirichlet_noise: Optional[bool] = None,
                      force_uniform_random_mask: Optional[torch.Tensor] = None) -> RootSearchBatchOutput:
@@ -371,19 +418,11 @@ class V1RootMCTS:
                 mixed = (1.0 - eps) * priors_mat + eps * noise
                 priors_mat = torch.where(counts.gt(1).view(-1, 1), mixed, priors_mat)
 
-            child = batch_apply_moves_compat(state, codes_all, parents_all)
-            if self._child_eval_mode == "full":
-                child_values = self._evaluate_batch(child)[4]
-            else:
-                child_values = self._evaluate_values_only(child)
-            parent_player = state.current_player.index_select(0, parents_all)
-            leaf = self._child_values_to_parent_perspective(child_values, parent_player, child.current_player)
-            term_child = self._terminal_mask_from_next_state(child)    # mcts_gpu.py:1352-1370 (sync-free here)
-            soft_black = self._soft_tanh_from_board_black(child.board, float(cfg.soft_value_k))
-            sign = torch.where(parent_player.ge(0), 1.0, -1.0).to(torch.float32)
-            leaf = torch.where(term_child, soft_black * sign, leaf)
-            leaf_mat = torch.zeros((R, M), dtype=torch.float32, device=dev)
-            leaf_mat.view(-1).index_copy_(0, flat_idx, leaf)
+            leaf_mat = self._children_leaf_matrix(state, codes_all, parents_all, flat_idx, R, M)
+            if int(cfg.sparse_ply) > 1:                                 # experimental top-K lookahead, :1150-1160
+                root_states = state.select(roots)
+                for _ in range(2, int(cfg.sparse_ply) + 1):
+                    leaf_mat = self._refine_via_topk_lookahead(root_states, leaf_mat, valid_mask, code_mat)
 
             sims = max(1, int(cfg.num_simulations))
             with self._timed("root_puct_ms"):

@@ -20,6 +20,7 @@ Fixture groups:
   g11_loss.npz      training-loss values and head gradients from the reference's own loss functions
   g10_tree_selfplay.npz  full-tree self-play traces of the reference portable runner (subtree reuse on every move)
   g9_net.npz        network outputs for seeded weights (tiny / 6x64 / 10x128)
+  g12_sparse_selfplay.npz  root-PUCT self-play traces of the reference v1 runner with sparse_ply = 2 and 3 (top-K lookahead)
 """
 from __future__ import annotations
 
@@ -572,6 +573,32 @@ def gen_selfplay():
 
 
 # --------------------------------------------------------------------------------------------
+# G12: reference v1 runner with the experimental multi-ply lookahead (sparse_ply > 1) on CPU
+# --------------------------------------------------------------------------------------------
+def gen_sparse_selfplay():
+    from v1.python.self_play_gpu_runner import self_play_v1_gpu
+    out = {}
+    for tag, ply, top_k in (("p2k4", 2, 4), ("p3k3", 3, 3)):
+        model = small_model()
+        torch.manual_seed(0); np.random.seed(0); random.seed(0)
+        batch, stats = self_play_v1_gpu(
+            model=model, num_games=3, mcts_simulations=16, temperature_init=1.0, temperature_final=0.1,
+            temperature_threshold=10, exploration_weight=1.0, device="cpu", add_dirichlet_noise=False,
+            soft_value_k=2.0, opening_random_moves=0, max_game_plies=48, sample_moves=False,
+            concurrent_games=3, sparse_ply=ply, sparse_top_k=top_k)
+        n = batch.num_samples
+        out[f"{tag}_state_tensors"] = np.packbits(batch.state_tensors.numpy().astype(bool).reshape(n, -1), axis=1)
+        out[f"{tag}_legal_masks"] = np.packbits(batch.legal_masks.numpy(), axis=1)
+        out[f"{tag}_policy_targets"] = batch.policy_targets.numpy()
+        out[f"{tag}_value_targets"] = batch.value_targets.numpy()
+        out[f"{tag}_soft_value_targets"] = batch.soft_value_targets.numpy()
+        out[f"{tag}_config"] = np.asarray([ply, top_k, 3, 16, 48], np.int64)
+        out[f"{tag}_outcome"] = np.asarray([stats.black_wins, stats.white_wins, stats.draws], np.int64)
+        print(f"[g12/{tag}] samples={n} W/L/D={stats.black_wins}/{stats.white_wins}/{stats.draws}")
+    np.savez_compressed(os.path.join(OUT, "g12_sparse_selfplay.npz"), **out)
+
+
+# --------------------------------------------------------------------------------------------
 # G10: reference portable (full tree, subtree reuse) self-play traces on CPU
 # --------------------------------------------------------------------------------------------
 def gen_tree_selfplay():
@@ -710,6 +737,8 @@ def main():
         gen_net(chosen)
     if not which or "g10" in which:
         gen_tree_selfplay()
+    if not which or "g12" in which:
+        gen_sparse_selfplay()
     if not which or "g11" in which:
         gen_loss()
     for f in sorted(os.listdir(OUT)):

@@ -25,30 +25,23 @@ def _net_eval(model, planes: np.ndarray):
     return lp1.float().numpy(), lp2.float().numpy(), lpm.float().numpy(), val.numpy().astype(np.float32)
 
 
-def root_search_batch(model, states: Dict[str, np.ndarray], temps: np.ndarray, sims: int, c: float,
-                      soft_k: float = 2.0, noise: Optional[np.ndarray] = None, eps: float = 0.25):
-    """variant R on a batch (sample_moves=False): returns dict with model_input, legal_mask, policy_dense,
-    chosen codes/idx/valid, terminal_mask, visits matrices."""
+def _children_leaf(model, states: Dict[str, np.ndarray], soft_k: float):
+    """Every legal child of every state evaluated, as seen by the parent's mover (mcts_gpu.py:900-975,
+    :1341-1375): dict with the packed-root tensors, leaf_mat [R,M] and the two eval counts."""
     B = states["board"].shape[0]
     planes = O.states_to_model_input(states)
     lp1, lp2, lpm, values = _net_eval(model, planes)
     mask, meta = O.encode_actions(states)
     probs, _ = O.project_policy(lp1, lp2, lpm, mask)
     (term, roots, counts, valid, lidx, pri, codes, flat, codes_all, parents_all) = O.root_pack_sparse_actions(mask, probs, meta)
-    out = dict(model_input=planes, legal_mask=mask, policy_dense=np.zeros((B, 220), np.float32),
-               chosen_idx=np.full(B, -1, np.int64), chosen_codes=np.full((B, 4), -1, np.int32),
-               chosen_valid=np.zeros(B, bool), terminal_mask=term, root_value=values.copy(), leaf_evals=B)
+    out = dict(planes=planes, mask=mask, values=values, term=term, roots=roots, counts=counts, valid=valid, lidx=lidx,
+               pri=pri, codes=codes, evals=B, leaf=None)
     if roots.size == 0:
         return out
     R, M = valid.shape
-    if noise is not None and M > 1:
-        nz = noise[:R, :M].astype(np.float32) * valid
-        nz = nz / np.maximum(nz.sum(1, keepdims=True), np.float32(1e-8))
-        mixed = (np.float32(1.0 - eps) * pri + np.float32(eps) * nz).astype(np.float32)
-        pri = np.where((counts > 1)[:, None], mixed, pri)
     child = O.apply_moves(states, codes_all, parents_all, strict=True)
     _, _, _, cvals = _net_eval(model, O.states_to_model_input(child))
-    out["leaf_evals"] += int(cvals.shape[0])
+    out["evals"] += int(cvals.shape[0])
     parent_player = states["current_player"][parents_all]
     leaf = np.where(child["current_player"] == parent_player, cvals, -cvals).astype(np.float32)
     tchild = O.terminal_mask_from_next_state(child)
@@ -57,6 +50,66 @@ def root_search_batch(model, states: Dict[str, np.ndarray], temps: np.ndarray, s
     leaf = np.where(tchild, soft * sign, leaf).astype(np.float32)
     leaf_mat = np.zeros((R, M), np.float32)
     leaf_mat.reshape(-1)[flat] = leaf
+    out["leaf"] = leaf_mat
+    return out
+
+
+def _refine_topk(model, root_states: Dict[str, np.ndarray], leaf_mat: np.ndarray, valid: np.ndarray,
+                 codes: np.ndarray, top_k: int, soft_k: float):
+    """One more ply below the K best children of every root (mcts_gpu.py:976-1046): the child's value becomes
+    max(its value, best value among ITS children as its own mover sees them).  Returns (leaf_mat, evals)."""
+    R, M = valid.shape
+    K = min(int(top_k), M)
+    if K <= 0 or R <= 0:
+        return leaf_mat, 0
+    masked = np.where(valid, leaf_mat, -np.inf).astype(np.float32)
+    top = np.argsort(-masked, axis=1, kind="stable")[:, :K]                       # [R,K] local action slots
+    picked_valid = np.take_along_axis(valid, top, axis=1)                          # fewer than K legal actions
+    # slots past the legal count carry no action: evaluate the root's first action there and discard the result
+    safe = np.where(picked_valid, top, top[:, :1])
+    l2_codes = np.take_along_axis(codes, safe[:, :, None], axis=1).reshape(-1, 4)
+    parents = np.repeat(np.arange(R, dtype=np.int64), K)
+    l2 = O.apply_moves(root_states, l2_codes, parents, strict=True)
+    sub = _children_leaf(model, l2, soft_k)
+    refined = np.zeros(R * K, np.float32)                                          # no grandchildren -> 0
+    if sub["leaf"] is not None:
+        best = np.where(sub["valid"], sub["leaf"], -np.inf).max(axis=1)
+        refined[sub["roots"]] = np.where(np.isfinite(best), best, 0.0).astype(np.float32)
+    refined = refined.reshape(R, K)
+    original = np.take_along_axis(leaf_mat, top, axis=1)
+    new = np.maximum(original, refined).astype(np.float32)
+    out = leaf_mat.copy()
+    rr, kk = np.nonzero(picked_valid)
+    out[rr, top[rr, kk]] = new[rr, kk]
+    return out, sub["evals"]
+
+
+def root_search_batch(model, states: Dict[str, np.ndarray], temps: np.ndarray, sims: int, c: float,
+                      soft_k: float = 2.0, noise: Optional[np.ndarray] = None, eps: float = 0.25,
+                      sparse_ply: int = 1, sparse_top_k: int = 8):
+    """variant R on a batch (sample_moves=False): returns dict with model_input, legal_mask, policy_dense,
+    chosen codes/idx/valid, terminal_mask, visits matrices.  `sparse_ply` > 1: the reference's experimental top-K
+    lookahead refines the children's values before the bandit (mcts_gpu.py:1048-1160)."""
+    B = states["board"].shape[0]
+    ch = _children_leaf(model, states, soft_k)
+    planes, mask, values, term, roots = ch["planes"], ch["mask"], ch["values"], ch["term"], ch["roots"]
+    out = dict(model_input=planes, legal_mask=mask, policy_dense=np.zeros((B, 220), np.float32),
+               chosen_idx=np.full(B, -1, np.int64), chosen_codes=np.full((B, 4), -1, np.int32),
+               chosen_valid=np.zeros(B, bool), terminal_mask=term, root_value=values.copy(), leaf_evals=ch["evals"])
+    if roots.size == 0:
+        return out
+    counts, valid, lidx, pri, codes, leaf_mat = ch["counts"], ch["valid"], ch["lidx"], ch["pri"], ch["codes"], ch["leaf"]
+    R, M = valid.shape
+    if noise is not None and M > 1:
+        nz = noise[:R, :M].astype(np.float32) * valid
+        nz = nz / np.maximum(nz.sum(1, keepdims=True), np.float32(1e-8))
+        mixed = (np.float32(1.0 - eps) * pri + np.float32(eps) * nz).astype(np.float32)
+        pri = np.where((counts > 1)[:, None], mixed, pri)
+    if int(sparse_ply) > 1:
+        root_states = O.select_states(states, roots)
+        for _ in range(2, int(sparse_ply) + 1):
+            leaf_mat, more = _refine_topk(model, root_states, leaf_mat, valid, codes, sparse_top_k, soft_k)
+            out["leaf_evals"] += more
     visits, vsum, _ = O.root_puct(pri, leaf_mat, valid, sims, c)
     pol, cidx, ccodes, cvalid, rv = O.root_finalize_from_visits(lidx, codes, valid, visits, vsum, roots, B, 220,
                                                                 temps[roots])
@@ -68,7 +121,8 @@ def root_search_batch(model, states: Dict[str, np.ndarray], temps: np.ndarray, s
 
 def self_play_root(model, num_games: int, sims: int, temperature_init: float = 1.0, temperature_final: float = 0.1,
                    temperature_threshold: int = 10, c: float = 1.0, soft_k: float = 2.0, max_game_plies: int = 512,
-                   max_total_plies: Optional[int] = None, time_budget_s: Optional[float] = None):
+                   max_total_plies: Optional[int] = None, time_budget_s: Optional[float] = None,
+                   sparse_ply: int = 1, sparse_top_k: int = 8):
     """variant-R wave loop, deterministic (sample_moves=False, no noise).  Returns (tensors dict, stats dict)."""
     states = O.initial_states(num_games)
     plies = np.zeros(num_games, np.int64); done = np.zeros(num_games, bool)
@@ -87,7 +141,7 @@ def self_play_root(model, num_games: int, sims: int, temperature_init: float = 1
             break
         act = O.select_states(states, active)
         temps = np.where(plies[active] < temperature_threshold, temperature_init, temperature_final).astype(np.float32)
-        sr = root_search_batch(model, act, temps, sims, c, soft_k)
+        sr = root_search_batch(model, act, temps, sims, c, soft_k, sparse_ply=sparse_ply, sparse_top_k=sparse_top_k)
         leaf_evals += sr["leaf_evals"]
         n = active.size
         S.append(sr["model_input"]); L.append(sr["legal_mask"]); P.append(sr["policy_dense"])

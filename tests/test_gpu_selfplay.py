@@ -35,6 +35,36 @@ def test_gpu_root_selfplay_matches_reference_trace():
     assert set(stats.step_timing_ms) == {"root_puct_ms", "pack_writeback_ms", "self_play_step_ms", "finalize_ms"}
 
 
+@pytest.mark.parametrize("tag", ["p2k4", "p3k3"])
+def test_gpu_root_selfplay_with_topk_lookahead_matches_reference_trace(tag):
+    """sparse_ply = 2 / 3 (the reference's experimental multi-ply refinement of the children's values,
+    v1/python/mcts_gpu.py:976-1160) on the HIP operators reproduces the reference runner's own traces (g12)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from liuzhou_amd.net import ChessNet, MODEL_CONFIGS
+    from liuzhou_amd.self_play_gpu_runner import self_play_v1_gpu
+    z = load("g12_sparse_selfplay.npz")
+    ply, top_k, games, sims, max_plies = (int(x) for x in z[f"{tag}_config"])
+    torch.manual_seed(7)
+    model = ChessNet(**MODEL_CONFIGS["tiny"]).eval().to("cuda:0")
+    batch, stats = self_play_v1_gpu(model, num_games=games, mcts_simulations=sims, temperature_init=1.0,
+                                    temperature_final=0.1, temperature_threshold=10, exploration_weight=1.0,
+                                    device="cuda:0", add_dirichlet_noise=False, soft_value_k=2.0,
+                                    opening_random_moves=0, max_game_plies=max_plies, sample_moves=False,
+                                    concurrent_games=games, autocast_dtype="float32", sparse_ply=ply,
+                                    sparse_top_k=top_k)
+    n = z[f"{tag}_policy_targets"].shape[0]
+    assert stats.num_positions == n
+    want_states = np.unpackbits(z[f"{tag}_state_tensors"], axis=1)[:, :11 * 36].reshape(n, 11, 6, 6).astype(np.float32)
+    assert np.array_equal(batch.state_tensors.cpu().numpy(), want_states)
+    assert np.array_equal(batch.legal_masks.cpu().numpy(),
+                          np.unpackbits(z[f"{tag}_legal_masks"], axis=1)[:, :220].astype(bool))
+    np.testing.assert_allclose(batch.policy_targets.cpu().numpy(), z[f"{tag}_policy_targets"], atol=1e-5, rtol=0)
+    np.testing.assert_array_equal(batch.value_targets.cpu().numpy(), z[f"{tag}_value_targets"])
+    np.testing.assert_allclose(batch.soft_value_targets.cpu().numpy(), z[f"{tag}_soft_value_targets"], atol=1e-6, rtol=0)
+    assert [stats.black_wins, stats.white_wins, stats.draws] == z[f"{tag}_outcome"].tolist()
+
+
 def test_gpu_selfplay_sampled_contract():
     """Contract asserts of tests/v1/test_v1_tensor_pipeline_smoke.py:73-111 (noise + sampling + opening moves)."""
     if not torch.cuda.is_available():

@@ -24,6 +24,32 @@ def test_oracle_root_selfplay_matches_reference_trace():
     assert (stats["black_wins"], stats["white_wins"], stats["draws"]) == (int(z["black_wins"]), int(z["white_wins"]), int(z["draws"]))
 
 
+def _check_sparse(tensors, stats, z, tag):
+    n = z[f"{tag}_policy_targets"].shape[0]
+    assert stats["num_positions"] == n
+    want_states = np.unpackbits(z[f"{tag}_state_tensors"], axis=1)[:, :11 * 36].reshape(n, 11, 6, 6).astype(np.float32)
+    assert np.array_equal(np.asarray(tensors["state_tensors"]), want_states)
+    assert np.array_equal(np.asarray(tensors["legal_masks"]),
+                          np.unpackbits(z[f"{tag}_legal_masks"], axis=1)[:, :220].astype(bool))
+    np.testing.assert_allclose(np.asarray(tensors["policy_targets"]), z[f"{tag}_policy_targets"], atol=1e-5, rtol=0)
+    np.testing.assert_array_equal(np.asarray(tensors["value_targets"]), z[f"{tag}_value_targets"])
+    np.testing.assert_allclose(np.asarray(tensors["soft_value_targets"]), z[f"{tag}_soft_value_targets"], atol=1e-6, rtol=0)
+
+
+def test_oracle_root_selfplay_with_topk_lookahead_matches_reference_traces():
+    """sparse_ply = 2 and 3 (the reference's experimental multi-ply refinement, mcts_gpu.py:976-1160): g12."""
+    z = load("g12_sparse_selfplay.npz")
+    for tag in ("p2k4", "p3k3"):
+        ply, top_k, games, sims, max_plies = (int(x) for x in z[f"{tag}_config"])
+        torch.manual_seed(7)
+        model = ChessNet(**MODEL_CONFIGS["tiny"]).eval()
+        tensors, stats = SO.self_play_root(model, num_games=games, sims=sims, temperature_init=1.0,
+                                           temperature_final=0.1, temperature_threshold=10, c=1.0, soft_k=2.0,
+                                           max_game_plies=max_plies, sparse_ply=ply, sparse_top_k=top_k)
+        _check_sparse(tensors, stats, z, tag)
+        assert [stats["black_wins"], stats["white_wins"], stats["draws"]] == z[f"{tag}_outcome"].tolist()
+
+
 def _tree_trace(z, tag, **kw):
     torch.manual_seed(7)
     model = ChessNet(**MODEL_CONFIGS["tiny"]).eval()
