@@ -20,6 +20,7 @@ Fixture groups:
   g11_loss.npz      training-loss values and head gradients from the reference's own loss functions
   g10_tree_selfplay.npz  full-tree self-play traces of the reference portable runner (subtree reuse on every move)
   g9_net.npz        network outputs for seeded weights (tiny / 6x64 / 10x128)
+  g13_legacy_waves.npz  root visit counts of src/mcts.py searches with batch_K = 16 / 4 (wave-batched leaves), incl. tree reuse
   g12_sparse_selfplay.npz  root-PUCT self-play traces of the reference v1 runner with sparse_ply = 2 and 3 (top-K lookahead)
 """
 from __future__ import annotations
@@ -573,6 +574,54 @@ def gen_selfplay():
 
 
 # --------------------------------------------------------------------------------------------
+# G13: the legacy search (src/mcts.py) with its wave-batched leaves: batch_K > 1, no virtual loss
+# --------------------------------------------------------------------------------------------
+def gen_legacy_waves():
+    from src.mcts import MCTS as LegacyMCTS
+    model = small_model()
+    rng = random.Random(13)
+    pool = [s for s in representative_states() if not s.is_game_over() and generate_all_legal_moves(s)]
+    play = random_playout_states(6, seed=131, max_moves=90)[0]
+    pool = rng.sample(pool, min(10, len(pool))) + rng.sample(play, min(14, len(play)))
+    pool = [s for s in pool if not s.is_game_over() and generate_all_legal_moves(s)]
+    roots, case_root, case_sims, case_k, case_moves, visits = [], [], [], [], [], []
+    for ri, st in enumerate(pool):
+        roots.append(st)
+        for sims, k in ((16, 16), (40, 16), (200, 16), (50, 4)):
+            if sims == 200 and ri % 3:
+                continue
+            mcts = LegacyMCTS(model, num_simulations=sims, exploration_weight=1.0, temperature=1.0, device="cpu",
+                              add_dirichlet_noise=False, virtual_loss_weight=0.0, batch_K=k)
+            # three consecutive moves with tree reuse (advance_root): most-visited child, lowest index on ties
+            cur = st.copy()
+            rows, picks = [], []
+            for _ in range(3):
+                if cur.is_game_over() or not generate_all_legal_moves(cur):
+                    break
+                mcts.search(cur)
+                v = np.zeros(TOTAL_DIM, np.int32)
+                for child in mcts.root.children:
+                    v[int(action_to_index(child.move, 6))] = child.visit_count
+                rows.append(v)
+                best = int(np.flatnonzero(v == v.max())[0])
+                mv = next(ch.move for ch in mcts.root.children if int(action_to_index(ch.move, 6)) == best)
+                picks.append(best)
+                cur = apply_move(cur.copy(), mv, quiet=True)
+                mcts.advance_root(mv)
+            case_root.append(ri); case_sims.append(sims); case_k.append(k)
+            case_moves.append(len(rows))
+            while len(rows) < 3:
+                rows.append(np.zeros(TOTAL_DIM, np.int32))
+            visits.append(np.stack(rows))
+    np.savez_compressed(
+        os.path.join(OUT, "g13_legacy_waves.npz"),
+        case_root=np.array(case_root, np.int32), case_sims=np.array(case_sims, np.int32),
+        case_k=np.array(case_k, np.int32), case_moves=np.array(case_moves, np.int32), case_visits=np.stack(visits),
+        **prefixed("r", pack_states(roots)))
+    print(f"[g13] legacy wave searches: roots={len(roots)} cases={len(case_root)}")
+
+
+# --------------------------------------------------------------------------------------------
 # G12: reference v1 runner with the experimental multi-ply lookahead (sparse_ply > 1) on CPU
 # --------------------------------------------------------------------------------------------
 def gen_sparse_selfplay():
@@ -737,6 +786,8 @@ def main():
         gen_net(chosen)
     if not which or "g10" in which:
         gen_tree_selfplay()
+    if not which or "g13" in which:
+        gen_legacy_waves()
     if not which or "g12" in which:
         gen_sparse_selfplay()
     if not which or "g11" in which:

@@ -625,6 +625,7 @@ typedef struct {
     double initial_value;
 } lzo_node;
 
+#define LZO_WAVE_MAX 64
 struct lzo_tree {
     lzo_node* nodes;
     int n_nodes, cap;
@@ -634,6 +635,8 @@ struct lzo_tree {
     int path_len;
     int pending;   /* node index awaiting evaluation, -1 if none */
     int pending_is_root;
+    int wave_eval[LZO_WAVE_MAX];   /* leaves of the current wave that await evaluation (src/mcts.py batch_K waves) */
+    int wave_n;
 };
 
 static int tree_new_node(lzo_tree* t, const lzo_state* s, int parent, int action, double prior) {
@@ -797,6 +800,139 @@ void lzo_tree_root_noise(lzo_tree* t, const float* noise, float epsilon) {
     }
     float denom = sum < 1e-8f ? 1e-8f : sum;
     for (int k = 0; k < r->n_children; ++k) t->nodes[r->first_child + k].prior = (double)(pr[k] / denom);
+}
+
+/* ---- wave-batched selection of the legacy search (src/mcts.py:318-497, batch_K leaves per wave, no virtual loss) ----
+ * Literal restatement: every attempt walks down from the root choosing the best child that is not banned for this
+ * attempt; a leaf already reserved in this wave is banned at its parent and the walk moves to the next best sibling
+ * or, when a node has no candidate left, backs up one level and bans that node (:341-420).  Backups go through the
+ * parent links like MCTSNode.backpropagate (:106-131). */
+static void backup_from(lzo_tree* t, int ni, double leaf_value) {
+    double value = leaf_value;
+    while (ni >= 0) {
+        lzo_node* n = &t->nodes[ni];
+        n->visit_count += 1;
+        n->value_sum += value;
+        const int par = (ni == t->root) ? -1 : n->parent;
+        if (par >= 0 && t->nodes[par].player != n->player) value = -value;
+        ni = par;
+    }
+}
+
+static int in_list(const int* a, int n, int v) {
+    for (int i = 0; i < n; ++i) if (a[i] == v) return 1;
+    return 0;
+}
+
+/* MCTSNode.get_best_child_excluding (:205-222): first maximum in child order among the children not banned */
+static int best_child_excluding(const lzo_tree* t, int ni, const int* banned, int nb) {
+    const lzo_node* n = &t->nodes[ni];
+    if (!n->expanded || n->n_children <= 0) return -1;
+    const double sqrt_total = sqrt((double)(n->visit_count > 1 ? n->visit_count : 1));
+    double best = -INFINITY;
+    int best_child = -1;
+    for (int k = 0; k < n->n_children; ++k) {
+        const int ci = n->first_child + k;
+        if (in_list(banned, nb, ci)) continue;
+        const lzo_node* ch = &t->nodes[ci];
+        double q = 0.0;
+        if (ch->visit_count > 0) {
+            const double mv = ch->value_sum / (double)ch->visit_count;
+            q = (n->player == ch->player) ? mv : -mv;
+        }
+        const double u = t->c * ch->prior * sqrt_total / (1.0 + (double)ch->visit_count);
+        const double score = q + u;
+        if (score > best) { best = score; best_child = ci; }
+    }
+    return best_child;
+}
+
+/* Collect up to `to_collect` distinct leaves (:333-425), then the terminal fast paths in leaf order (:432-459).
+ * Returns the number of simulations consumed (= leaves collected); the leaves that need the network are left in
+ * wave_eval[0..wave_n). */
+int lzo_tree_select_wave(lzo_tree* t, int to_collect) {
+    t->wave_n = 0;
+    if (to_collect > LZO_WAVE_MAX) to_collect = LZO_WAVE_MAX;
+    const lzo_node* rootn = &t->nodes[t->root];
+    if (rootn->terminal || !rootn->expanded || rootn->n_children == 0) return 0;
+    int leaves[LZO_WAVE_MAX];
+    int collected = 0, attempts = 0;
+    const int max_attempts = (8 * to_collect > 64) ? 8 * to_collect : 64;
+    int* banned = (int*)malloc(sizeof(int) * 4096);
+    while (collected < to_collect && attempts < max_attempts) {
+        ++attempts;
+        int node = t->root, nb = 0, backtrack = 0;
+        for (;;) {
+            const lzo_node* n = &t->nodes[node];
+            if (!n->expanded || n->terminal) {                       /* candidate leaf */
+                if (in_list(leaves, collected, node)) {              /* reserved in this wave */
+                    if (node == t->root) break;
+                    const int parent = n->parent;
+                    if (nb < 4096) banned[nb++] = node;
+                    const int alt = best_child_excluding(t, parent, banned, nb);
+                    if (alt < 0) { node = parent; if (++backtrack > 128) break; continue; }
+                    node = alt;
+                    continue;
+                }
+                leaves[collected++] = node;
+                break;
+            }
+            const int child = best_child_excluding(t, node, banned, nb);
+            if (child < 0) {
+                if (node == t->root) break;
+                if (nb < 4096) banned[nb++] = node;
+                node = n->parent;
+                if (++backtrack > 128) break;
+                continue;
+            }
+            node = child;
+        }
+    }
+    free(banned);
+    for (int i = 0; i < collected; ++i) {
+        lzo_node* leaf = &t->nodes[leaves[i]];
+        if (leaf->terminal) {                                        /* known terminal, or game over on arrival */
+            backup_from(t, leaves[i], leaf->no_legal_terminal ? -1.0 : terminal_value(&leaf->state));
+            continue;
+        }
+        int idx[80];
+        if (lzo_legal_indices_py(&leaf->state, idx) == 0) {          /* no legal move: the mover loses */
+            leaf->terminal = 1; leaf->no_legal_terminal = 1; leaf->expanded = 1;
+            backup_from(t, leaves[i], -1.0);
+            continue;
+        }
+        t->wave_eval[t->wave_n++] = leaves[i];
+    }
+    return collected;
+}
+
+int lzo_tree_wave_count(const lzo_tree* t) { return t->wave_n; }
+void lzo_tree_wave_state(const lzo_tree* t, int j, lzo_state* out) { *out = t->nodes[t->wave_eval[j]].state; }
+
+/* :478-497: expand every evaluated leaf with its priors and back its value up, in leaf order */
+void lzo_tree_complete_wave(lzo_tree* t, const float* priors220, const float* values) {
+    for (int j = 0; j < t->wave_n; ++j) {
+        const int ni = t->wave_eval[j];
+        lzo_state st = t->nodes[ni].state;
+        int idx[80];
+        const int n = lzo_legal_indices_py(&st, idx);
+        float pr[80];
+        float sum = 0.0f;
+        for (int k = 0; k < n; ++k) { pr[k] = priors220[(size_t)j * 220 + idx[k]]; sum += pr[k]; }
+        if (!isfinite(sum) || sum <= 0.0f) { for (int k = 0; k < n; ++k) pr[k] = 1.0f / (float)n; }
+        else { for (int k = 0; k < n; ++k) pr[k] = pr[k] / sum; }
+        const int first = t->n_nodes;
+        for (int k = 0; k < n; ++k) {
+            lzo_state cs;
+            lzo_apply_index(&st, idx[k], &cs);
+            tree_new_node(t, &cs, ni, idx[k], (double)pr[k]);
+        }
+        lzo_node* nd = &t->nodes[ni];
+        nd->first_child = first; nd->n_children = n; nd->expanded = 1;
+        nd->initial_value = (double)values[j];
+        backup_from(t, ni, (double)values[j]);
+    }
+    t->wave_n = 0;
 }
 
 int lzo_tree_root_terminal(const lzo_tree* t) {

@@ -76,6 +76,10 @@ def lib():
         L.lzo_tree_pending_state.argtypes = [C.c_void_p, C.POINTER(CState)]
         L.lzo_tree_complete.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_float]
         L.lzo_tree_root_noise.argtypes = [C.c_void_p, C.c_void_p, C.c_float]
+        L.lzo_tree_select_wave.argtypes = [C.c_void_p, C.c_int]
+        L.lzo_tree_wave_count.argtypes = [C.c_void_p]
+        L.lzo_tree_wave_state.argtypes = [C.c_void_p, C.c_int, C.POINTER(CState)]
+        L.lzo_tree_complete_wave.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.lzo_tree_root_terminal.argtypes = [C.c_void_p]
         L.lzo_tree_root_children.argtypes = [C.c_void_p] + [C.c_void_p] * 5
         L.lzo_tree_root_visits.argtypes = [C.c_void_p]
@@ -429,6 +433,24 @@ class OracleTree:
         nz = None if noise is None else np.ascontiguousarray(noise, np.float32)
         self._L.lzo_tree_complete(self._t, p.ctypes.data, C.c_float(float(value)),
                                   None if nz is None else nz.ctypes.data, C.c_float(float(epsilon)))
+
+    # ---- legacy batch_K waves (src/mcts.py:318-497) ----
+    def select_wave(self, to_collect: int) -> int:
+        """Collect up to `to_collect` distinct leaves, back the terminal ones up; returns simulations consumed."""
+        return int(self._L.lzo_tree_select_wave(self._t, int(to_collect)))
+
+    def wave_states(self):
+        out = []
+        for j in range(int(self._L.lzo_tree_wave_count(self._t))):
+            s = CState()
+            self._L.lzo_tree_wave_state(self._t, j, C.byref(s))
+            out.append(s)
+        return out
+
+    def complete_wave(self, priors220: np.ndarray, values: np.ndarray) -> None:
+        p = np.ascontiguousarray(priors220, np.float32).reshape(-1, 220)
+        v = np.ascontiguousarray(values, np.float32).reshape(-1)
+        self._L.lzo_tree_complete_wave(self._t, p.ctypes.data, v.ctypes.data)
 
     def root_noise(self, noise: np.ndarray, epsilon: float) -> None:
         nz = np.ascontiguousarray(noise, np.float32)

@@ -208,6 +208,48 @@ def tree_search_batch(evaluate: Callable[[Dict[str, np.ndarray]], Tuple[np.ndarr
     return evals
 
 
+def tree_search_waves(evaluate: Callable[[Dict[str, np.ndarray]], Tuple[np.ndarray, np.ndarray]], trees, sims: int,
+                      batch_k: int) -> int:
+    """The legacy search of src/mcts.py:280-497 (batch_K leaves per wave, no virtual loss) for several trees at once:
+    roots expanded without backup, then waves of up to `batch_k` distinct leaves per tree -- terminal leaves are
+    backed up at once, the others are evaluated together, expanded and backed up in leaf order.  With batch_k = 1
+    this is tree_search_batch.  Returns the number of network evaluations."""
+    evals = 0
+    fresh = [i for i, t in enumerate(trees) if t.prepare_root()]
+    if fresh:
+        pri, val = evaluate(O.batch_from_states([trees[i].pending_state() for i in fresh]))
+        evals += len(fresh)
+        for k, i in enumerate(fresh):
+            trees[i].complete(pri[k], float(val[k]))
+    done = [0] * len(trees)
+    while True:
+        owners, states = [], []
+        progressed = False
+        for i, t in enumerate(trees):
+            if done[i] >= sims or t.root_terminal():
+                continue
+            got = t.select_wave(min(int(batch_k), sims - done[i]))
+            if got == 0:
+                done[i] = sims                      # nothing collectable (cannot happen on a live tree)
+                continue
+            progressed = True
+            done[i] += got
+            ws = t.wave_states()
+            if ws:
+                owners.append((i, len(ws)))
+                states.extend(ws)
+        if states:
+            pri, val = evaluate(O.batch_from_states(states))
+            evals += len(states)
+            off = 0
+            for i, n in owners:
+                trees[i].complete_wave(pri[off:off + n], val[off:off + n])
+                off += n
+        if not progressed:
+            break
+    return evals
+
+
 def make_net_evaluator(model):
     def evaluate(states):
         planes = O.states_to_model_input(states)

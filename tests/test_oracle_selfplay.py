@@ -50,6 +50,33 @@ def test_oracle_root_selfplay_with_topk_lookahead_matches_reference_traces():
         assert [stats["black_wins"], stats["white_wins"], stats["draws"]] == z[f"{tag}_outcome"].tolist()
 
 
+def test_oracle_legacy_wave_search_matches_reference_visit_counts():
+    """src/mcts.py with batch_K = 16 / 4 (leaves collected in waves, no virtual loss), three consecutive searches
+    with advance_root in between: the oracle's wave search reproduces the reference's root visit counts (g13)."""
+    from oracle import lz_oracle as O
+    from tests.golden_utils import states
+    z = load("g13_legacy_waves.npz")
+    roots = states(z, "r")
+    torch.manual_seed(7)
+    model = ChessNet(**MODEL_CONFIGS["tiny"]).eval()
+    evaluate = SO.make_net_evaluator(model)
+    n = z["case_root"].shape[0]
+    assert n >= 60 and int(z["case_k"].max()) == 16
+    for ci in range(n):
+        cur = O.state_from_batch(roots, int(z["case_root"][ci]))
+        sims, k = int(z["case_sims"][ci]), int(z["case_k"][ci])
+        tree = O.OracleTree(cur, 1.0)
+        for mv in range(int(z["case_moves"][ci])):
+            SO.tree_search_waves(evaluate, [tree], sims, k)
+            idx, vis, _, _, _ = tree.root_children()
+            got = np.zeros(220, np.int32); got[idx] = vis
+            assert np.array_equal(got, z["case_visits"][ci, mv]), (ci, mv, sims, k)
+            pick = int(np.flatnonzero(got == got.max())[0])
+            cur = O.apply_index(cur, pick)
+            if not tree.advance(pick):
+                tree = O.OracleTree(cur, 1.0)
+
+
 def _tree_trace(z, tag, **kw):
     torch.manual_seed(7)
     model = ChessNet(**MODEL_CONFIGS["tiny"]).eval()
