@@ -295,6 +295,37 @@ typedef struct LzTreeDesc {
 } LzTreeDesc;
 
 /* SoA batch -> packed records; packed records -> float32[B,11,6,6] model input (src/neural_network.py:15-65) */
+/* Wave-batched leaves: the legacy search of src/mcts.py:280-497 (`batch_K` distinct leaves per tree and wave, no
+ * virtual loss; batch_K = 1 is the protocol above).  Per-leaf arrays are slot-major [batch_k][B]; `leaf_state` is the
+ * network batch of a wave (batch_k * B packed states, inactive slots keep their previous content). */
+typedef struct LzTreeWaveDesc {
+    int32_t  batch_k;              /* leaves per game and wave, 1..32 */
+    int32_t  path_cap;             /* entries per leaf path, > 48 (deeper descents are not followed) */
+    int32_t* path;                 /* [batch_k][B][path_cap] */
+    int32_t* path_len;             /* [batch_k][B] */
+    int32_t* leaf_kind;            /* [batch_k][B] 0 inactive, 1 needs evaluation, 2 terminal */
+    void*    leaf_state;           /* [batch_k][B] packed */
+    float*   leaf_value;           /* [batch_k][B] */
+    int32_t* leaf_edge;            /* [batch_k][B] */
+    int32_t* leaf_parent;          /* [batch_k][B] */
+    int32_t* sims_done;            /* [B] simulations used by the current search */
+    int32_t* unfinished;           /* [1] games with budget left after the last lz_tree_wave_select */
+} LzTreeWaveDesc;
+/* SelectLeaves for a wave: up to min(batch_k, sims - sims_done) distinct leaves per game, in the order the reference
+ * collects them (src/mcts.py:333-425); sims_done += leaves found.  reset_budget != 0 starts a new search. */
+LZ_API int lz_tree_wave_select(const LzTreeDesc* tree, const LzTreeWaveDesc* wave, int64_t sims, int reset_budget,
+                               void* stream);
+/* CompletePending for a wave (src/mcts.py:427-497): terminal / no-legal-move leaves are backed up first, then the
+ * evaluated leaves are expanded and backed up, each group in leaf order.  Heads / priors220 / values: batch_k * B rows. */
+LZ_API int lz_tree_wave_expand(const LzTreeDesc* tree, const LzTreeWaveDesc* wave, const float* log_p1,
+                               const float* log_p2, const float* log_pmc, const float* priors220, const float* values,
+                               void* stream);
+/* Whole search of one move in waves, enqueued from C++ (hipGraph-capturable); see lz_engine.hip. */
+LZ_API int lz_tree_search_waves(const LzTreeDesc* tree, const LzTreeWaveDesc* wave, const LzNetDesc* net, int64_t sims,
+                                int64_t waves, float* log_p1, float* log_p2, float* log_pmc, float* values,
+                                const float* noise, int64_t noise_stride, float epsilon, int continue_trees,
+                                int skip_roots, void* stream);
+
 LZ_API int lz_pack_states(const LzStateSoA* states, int64_t batch, void* packed_out, void* stream);
 LZ_API int lz_packed_to_model_input(const void* packed, int64_t batch, float* out, void* stream);
 

@@ -30,7 +30,7 @@ SYMBOLS = (
     "lz_root_pack_rows", "lz_root_puct_allocate_visits", "lz_root_finalize_from_visits",
     "lz_self_play_step_inplace", "lz_finalize_trajectory_inplace", "lz_net_forward_f16", "lz_net_forward_packed_f16", "lz_net_configure",
     "lz_pack_states", "lz_packed_to_model_input", "lz_tree_begin", "lz_tree_select", "lz_tree_expand",
-    "lz_tree_finish", "lz_tree_search", "lz_tree_advance", "lz_tree_search_continue", "lz_policy_value_loss_fwd_bwd", "lz_pack_trajectory_rows", "lz_unpack_trajectory_rows", "lz_prof_enable", "lz_prof_net_summary", "lz_prof_net_busy", "lz_net_forward_packed_counted_f16", "lz_root_prepare", "lz_root_collect", "lz_wave_record", "lz_wave_step_finish", "lz_wave_reseat",
+    "lz_tree_finish", "lz_tree_search", "lz_tree_advance", "lz_tree_search_continue", "lz_policy_value_loss_fwd_bwd", "lz_pack_trajectory_rows", "lz_unpack_trajectory_rows", "lz_prof_enable", "lz_prof_net_summary", "lz_prof_net_busy", "lz_net_forward_packed_counted_f16", "lz_root_prepare", "lz_root_collect", "lz_wave_record", "lz_wave_step_finish", "lz_wave_reseat", "lz_tree_wave_select", "lz_tree_wave_expand", "lz_tree_search_waves",
 )
 
 

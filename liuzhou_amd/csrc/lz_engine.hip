@@ -553,6 +553,205 @@ __global__ __launch_bounds__(kBlock) void tree_expand_select_kernel(Tree t, cons
     tree_select(t, g, lane, root);
 }
 
+// ---- wave-batched leaves: the legacy search of src/mcts.py (batch_K leaves per tree and wave, no virtual loss) ------
+// src/mcts.py:318-497.  Within a wave the statistics do not change, so the K leaves the reference collects with its
+// restart-and-ban walks (:341-420) are simply the first K leaves of a depth-first traversal that visits the children
+// of every node in descending PUCT order (first maximum first) -- the walk below continues that traversal instead of
+// restarting it: per level it remembers the (score, index) of the last child it consumed and picks the next one
+// in that order; a reserved / terminal / unexpanded child is a leaf, an expanded child is entered, a node without
+// candidates is left.  Leaves go to slot j of the [batch_k][B] slot-major arrays; the slots' leaf states are the next
+// network batch.  (The reference's safety limits -- 128 back-steps per walk, 8K walks per wave -- are not modelled;
+// descents deeper than kWaveDepth levels are not followed.)
+constexpr int kWaveDepth = 48;
+struct WaveArrays {
+    int K, cap;
+    int* path; int* path_len; int* leaf_kind; Packed* leaf_state; float* leaf_value; int* leaf_edge; int* leaf_parent;
+    int* sims_done; int* unfinished;
+};
+struct Level { int e0, ne_pl, parent_n, node; double last_sc; int last_k, in_edge; };
+static_assert(sizeof(Level) == 32, "level record is 32 bytes");
+
+__device__ __forceinline__ Tree slot_view(const Tree& t, const WaveArrays& w, int j) {
+    Tree v = t;
+    const size_t o = (size_t)j * t.B;
+    v.path = w.path + o * w.cap; v.path_cap = w.cap; v.path_len = w.path_len + o; v.leaf_kind = w.leaf_kind + o;
+    v.leaf_state = w.leaf_state + o; v.leaf_value = w.leaf_value + o; v.leaf_edge = w.leaf_edge + o;
+    v.leaf_parent = w.leaf_parent + o;
+    return v;
+}
+
+__device__ __forceinline__ void tree_select_wave(const Tree& t, const WaveArrays& w, int g, int lane,
+                                                 const RootInfo& root, int sims, Level* stack) {
+    const int done = w.sims_done[g];
+    int to_collect = sims - done;
+    to_collect = to_collect < w.K ? to_collect : w.K;
+    const bool live = t.root_terminal[g] == 0 && root.ne > 0 && to_collect > 0;
+    const Node* nodes = t.nodes + (size_t)g * t.node_cap;
+    const Edge* edges = t.edges + (size_t)g * t.edge_cap;
+    int found = 0;
+    if (live) {
+        int d = 0;
+        int e0 = root.e0, ne = root.ne, parent_n = root.visits, node_player = root.player, node = 0;
+        double last_sc = INFINITY;
+        int last_k = -1;
+        Packed node_state = root.state;
+        while (found < to_collect) {
+            // next child of the current node in descending (score, -index) order
+            const double sq = sqrt((double)(parent_n > 1 ? parent_n : 1));
+            double best = -INFINITY;
+            int best_k = -1;
+            Edge mine[2];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int k = r * kWave + lane;
+                if (k < ne) {
+                    mine[r] = load_edge(&edges[e0 + k]);
+                    const int n = edge_n(mine[r].n_info);
+                    double q = 0.0;
+                    if (n > 0) {
+                        const double mv = mine[r].W / (double)n;
+                        const int child_player = (edge_info(mine[r].n_info) & kInfoWhite) ? -1 : 1;
+                        q = child_player == node_player ? mv : -mv;
+                    }
+                    const double u = t.c_puct * (double)mine[r].P * sq / (1.0 + (double)n);
+                    const double sc = q + u;
+                    const bool open = sc < last_sc || (sc == last_sc && k > last_k);    // not consumed yet
+                    if (open && sc > best) { best = sc; best_k = k; }
+                }
+            }
+            const double mx = lzw::wave_max(best);
+            const uint64_t lo = __ballot(best_k >= 0 && best_k < kWave && best == mx);
+            int chosen = -1;
+            if (lo) chosen = __ffsll((unsigned long long)lo) - 1;
+            else {
+                const uint64_t hi = __ballot(best_k >= kWave && best == mx);
+                if (hi) chosen = kWave + __ffsll((unsigned long long)hi) - 1;
+            }
+            if (chosen < 0) {                                           // nothing left below this node
+                if (d == 0) break;
+                --d;
+                const Level up = stack[d];
+                e0 = up.e0; ne = up.ne_pl & 0xFF; node_player = (up.ne_pl & 0x100) ? -1 : 1; parent_n = up.parent_n;
+                node = up.node; last_sc = up.last_sc; last_k = up.last_k;
+                node_state = d == 0 ? root.state : load_state(&nodes[node].state);
+                continue;
+            }
+            chosen = __builtin_amdgcn_readfirstlane(chosen);
+            last_sc = mx; last_k = chosen;
+            const int src = chosen & 63;
+            const bool up2 = chosen >= kWave;
+            const uint32_t c_ni = (uint32_t)lzw::lane_bcast((int)(up2 ? mine[1].n_info : mine[0].n_info), src);
+            const int c_child = lzw::lane_bcast(up2 ? mine[1].child : mine[0].child, src);
+            const int c_begin = lzw::lane_bcast(up2 ? mine[1].cbegin : mine[0].cbegin, src);
+            const int c_meta = lzw::lane_bcast((int)(up2 ? mine[1].act : mine[0].act) | ((int)(up2 ? mine[1].cn : mine[0].cn) << 8), src);
+            const uint8_t info = edge_info(c_ni);
+            const int child_player = (info & kInfoWhite) ? -1 : 1;
+            const int edge_id = e0 + chosen;
+            const int entry = edge_id | (child_player != node_player ? (int)kPathFlip : 0);
+            const bool terminal = (info & kInfoTerminal) != 0;
+            if (terminal || c_child < 0) {                             // a leaf: slot `found`
+                const size_t slot = (size_t)found * t.B + g;
+                int* path = w.path + slot * w.cap;
+                if (lane < d) path[lane] = stack[lane + 1].in_edge;
+                if (lane == 0) {
+                    path[d] = entry;
+                    w.path_len[slot] = d + 1;
+                    w.leaf_kind[slot] = terminal ? kLeafTerminal : kLeafExpand;
+                    w.leaf_value[slot] = terminal ? (float)((int)((info >> 2) & 3) - 1) : 0.f;
+                    w.leaf_edge[slot] = edge_id;
+                    w.leaf_parent[slot] = node;
+                    if (!terminal) {
+                        State leaf = unpack(node_state);
+                        int kd, p, q2, ex;
+                        index_to_code(leaf.phase, c_meta & 0xFF, kd, p, q2, ex);
+                        apply(leaf, kd, p, q2);
+                        w.leaf_state[slot] = pack(leaf);
+                    }
+                }
+                ++found;
+                continue;
+            }
+            if (d + 1 >= kWaveDepth) continue;                          // too deep: not followed
+            if (lane == 0) {
+                Level here;
+                here.e0 = e0; here.ne_pl = ne | (node_player < 0 ? 0x100 : 0); here.parent_n = parent_n; here.node = node;
+                here.last_sc = last_sc; here.last_k = last_k; here.in_edge = stack[d].in_edge;
+                stack[d] = here;
+                stack[d + 1].in_edge = entry;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            ++d;
+            e0 = c_begin; ne = c_meta >> 8; parent_n = edge_n(c_ni); node_player = child_player; node = c_child;
+            last_sc = INFINITY; last_k = -1;
+            node_state = load_state(&nodes[node].state);
+        }
+    }
+    for (int j = found + lane; j < w.K; j += kWave) w.leaf_kind[(size_t)j * t.B + g] = kLeafInactive;
+    if (lane == 0) {
+        int nd = done + found;
+        if (live && found == 0) nd = sims;                              // nothing collectable: give the budget up
+        w.sims_done[g] = nd;
+        if (t.root_terminal[g] == 0 && root.ne > 0 && nd < sims) atomicAdd(w.unfinished, 1);
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void tree_select_wave_kernel(Tree t, WaveArrays w, int sims) {
+    __shared__ Level s_stack[kWavesPerBlock][kWaveDepth];
+    const int g = wave_game();
+    if (g >= t.B) return;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    __builtin_amdgcn_s_setprio(3);
+    tree_select_wave(t, w, g, lane_id(), load_root_info(t, g), sims, s_stack[wv]);
+}
+
+__global__ __launch_bounds__(kBlock) void wave_budget_reset_kernel(WaveArrays w, int B, int reset_done) {
+    const int g = blockIdx.x * kBlock + threadIdx.x;
+    if (g == 0) *w.unfinished = 0;
+    if (reset_done && g < B) w.sims_done[g] = 0;
+}
+
+// The wave's leaves in the reference's order (src/mcts.py:427-497): first every terminal leaf and every leaf whose
+// position has no legal move is backed up (leaf order), then the evaluated leaves are expanded and backed up (leaf
+// order).  Each step is the single-leaf expand of variant P on the slot's view of the per-leaf arrays; a device fence
+// between two steps keeps their updates of the same edges in order.
+__global__ __launch_bounds__(kBlock) void tree_expand_wave_kernel(Tree t, WaveArrays w, const float* __restrict__ lp1,
+                                                                  const float* __restrict__ lp2,
+                                                                  const float* __restrict__ lpm,
+                                                                  const float* __restrict__ priors220,
+                                                                  const float* __restrict__ values) {
+    const int g = wave_game();
+    if (g >= t.B) return;
+    const int lane = lane_id();
+    __builtin_amdgcn_s_setprio(3);
+    uint32_t second = 0;                                                 // slots handled by the second pass
+    for (int pass = 0; pass < 2; ++pass) {
+        for (int j = 0; j < w.K; ++j) {
+            const size_t slot = (size_t)j * t.B + g;
+            bool run;
+            if (pass == 0) {
+                const int kind = w.leaf_kind[slot];
+                if (kind == kLeafInactive) break;                        // slots are filled in order
+                run = kind == kLeafTerminal;
+                if (kind == kLeafExpand) {
+                    const State s = unpack(load_state(&w.leaf_state[slot]));
+                    if (legal_count(legal_actions(s, 0)) == 0) run = true;
+                    else second |= 1u << j;
+                }
+            } else {
+                run = (second >> j) & 1u;
+            }
+            if (!run) continue;
+            const size_t o = (size_t)j * t.B;
+            tree_expand<false>(slot_view(t, w, j), g, lane, lp1 ? lp1 + o * 36 : nullptr, lp2 ? lp2 + o * 36 : nullptr,
+                               lpm ? lpm + o * 36 : nullptr, priors220 ? priors220 + o * 220 : nullptr, values + o,
+                               nullptr, 0, 0.f);
+            __threadfence();
+        }
+    }
+}
+
 // ---- advance (a21): promote the played child to root, keep its subtree ---------------------------------------
 // src/mcts.py:577-592, portable_mcts.py:74-87, portable_mcts.cpp:739-769.  One wave per game, in place:
 //   1. mark the subtree of the chosen child: node ids ascend in expansion order, so a node is kept iff its parent
@@ -1025,6 +1224,19 @@ bool tree_ok(const LzTreeDesc* d) {
            d->root_visits && d->root_w && d->root_init_value && d->path && d->path_len && d->leaf_kind &&
            d->leaf_state && d->leaf_value && d->root_terminal && d->leaf_edge && d->leaf_parent;
 }
+WaveArrays make_wave(const LzTreeWaveDesc* w) {
+    WaveArrays a;
+    a.K = w->batch_k; a.cap = w->path_cap;
+    a.path = w->path; a.path_len = w->path_len; a.leaf_kind = w->leaf_kind;
+    a.leaf_state = reinterpret_cast<Packed*>(w->leaf_state); a.leaf_value = w->leaf_value; a.leaf_edge = w->leaf_edge;
+    a.leaf_parent = w->leaf_parent; a.sims_done = w->sims_done; a.unfinished = w->unfinished;
+    return a;
+}
+bool wave_ok(const LzTreeWaveDesc* w) {
+    return w && w->batch_k >= 1 && w->batch_k <= 32 && w->path_cap > kWaveDepth && w->path && w->path_len &&
+           w->leaf_kind && w->leaf_state && w->leaf_value && w->leaf_edge && w->leaf_parent && w->sims_done &&
+           w->unfinished;
+}
 inline unsigned gw(int64_t n) { return (unsigned)((n + kWavesPerBlock - 1) / kWavesPerBlock); }
 inline unsigned gt(int64_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
 
@@ -1190,6 +1402,55 @@ int lz_tree_search_continue(const LzTreeDesc* d, const LzNetDesc* net, int64_t s
                             float* lp2, float* lpmc, float* values, const float* noise, int64_t noise_stride,
                             float epsilon, void* stream) {
     return tree_search_impl(d, net, sims, planes, lp1, lp2, lpmc, values, noise, noise_stride, epsilon, true, stream);
+}
+
+int lz_tree_wave_select(const LzTreeDesc* d, const LzTreeWaveDesc* w, int64_t sims, int reset_budget, void* stream) {
+    if (!tree_ok(d) || !wave_ok(w) || sims < 0) return LZ_ERR_ARG;
+    if (d->num_games == 0) return LZ_OK;
+    const Tree t = make_tree(d);
+    const WaveArrays a = make_wave(w);
+    hipLaunchKernelGGL(wave_budget_reset_kernel, dim3(gt(t.B)), dim3(kBlock), 0, as_stream(stream), a, t.B, reset_budget);
+    hipLaunchKernelGGL(tree_select_wave_kernel, dim3(gw(t.B)), dim3(kBlock), 0, as_stream(stream), t, a, (int)sims);
+    return st();
+}
+
+int lz_tree_wave_expand(const LzTreeDesc* d, const LzTreeWaveDesc* w, const float* lp1, const float* lp2,
+                        const float* lpmc, const float* priors220, const float* values, void* stream) {
+    if (!tree_ok(d) || !wave_ok(w) || !values) return LZ_ERR_ARG;
+    if (!priors220 && (!lp1 || !lp2 || !lpmc)) return LZ_ERR_ARG;
+    if (d->num_games == 0) return LZ_OK;
+    hipLaunchKernelGGL(tree_expand_wave_kernel, dim3(gw(d->num_games)), dim3(kBlock), 0, as_stream(stream), make_tree(d),
+                       make_wave(w), lp1, lp2, lpmc, priors220, values);
+    return st();
+}
+
+// Whole wave-batched search of one move (hipGraph-capturable): begin -> net(roots) -> expand roots ->
+// `waves` x [select batch_k leaves per game -> net(batch_k * B leaf slots) -> expand + backup in leaf order].
+// lp1 / lp2 / lpmc / values hold batch_k * B rows.  Afterwards *wave->unfinished tells whether some game could not
+// use its budget up (fewer open leaves than batch_k): the caller then runs further select / net / expand rounds.
+int lz_tree_search_waves(const LzTreeDesc* d, const LzTreeWaveDesc* w, const LzNetDesc* net, int64_t sims, int64_t waves,
+                         float* lp1, float* lp2, float* lpmc, float* values, const float* noise, int64_t noise_stride,
+                         float epsilon, int continue_trees, int skip_roots, void* stream) {
+    if (!tree_ok(d) || !wave_ok(w) || !net || sims < 0 || waves < 0 || !lp1 || !lp2 || !lpmc || !values) return LZ_ERR_ARG;
+    const int64_t B = d->num_games;
+    if (B == 0) return LZ_OK;
+    int rc = LZ_OK;
+    if (!skip_roots) {
+        if (!continue_trees) { rc = lz_tree_begin(d, stream); if (rc) return rc; }
+        rc = lz_net_forward_packed_f16(net, d->leaf_state, B, lp1, lp2, lpmc, nullptr, values, stream);
+        if (rc) return rc;
+        rc = lz_tree_expand(d, 1, lp1, lp2, lpmc, nullptr, values, noise, noise_stride, epsilon, stream);
+        if (rc) return rc;
+    }
+    for (int64_t i = 0; i < waves; ++i) {
+        rc = lz_tree_wave_select(d, w, sims, (!skip_roots && i == 0) ? 1 : 0, stream);
+        if (rc) return rc;
+        rc = lz_net_forward_packed_f16(net, w->leaf_state, (int64_t)w->batch_k * B, lp1, lp2, lpmc, nullptr, values, stream);
+        if (rc) return rc;
+        rc = lz_tree_wave_expand(d, w, lp1, lp2, lpmc, nullptr, values, stream);
+        if (rc) return rc;
+    }
+    return st();
 }
 
 }  // extern "C"

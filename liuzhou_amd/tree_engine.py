@@ -39,6 +39,13 @@ class LzTreeDesc(C.Structure):
                    "active", "leaf_edge", "leaf_parent")]
 
 
+class LzTreeWaveDesc(C.Structure):
+    _fields_ = [("batch_k", C.c_int32), ("path_cap", C.c_int32)] + \
+               [(n, C.c_void_p) for n in ("path", "path_len", "leaf_kind", "leaf_state", "leaf_value", "leaf_edge",
+                                          "leaf_parent", "sims_done", "unfinished")]
+
+
+WAVE_PATH_CAP = 64             # entries per leaf path of a wave (the kernel follows descents up to 48 levels)
 REUSE_EDGES_PER_NODE = 40      # arena sizing for kept subtrees (average fan-out is ~25; overflow drops the subtree)
 
 
@@ -58,8 +65,10 @@ def auto_reuse_factor(num_games: int, sims: int, device, memory_fraction: float 
 
 class TreeEngine:
     def __init__(self, num_games: int, max_sims: int, device, exploration_weight: float = 1.0,
-                 reuse_factor: float = 0.0) -> None:
-        """`reuse_factor` > 0 reserves room for kept subtrees of up to reuse_factor * max_sims nodes (advance())."""
+                 reuse_factor: float = 0.0, batch_k: int = 1) -> None:
+        """`reuse_factor` > 0 reserves room for kept subtrees of up to reuse_factor * max_sims nodes (advance()).
+        `batch_k` > 1: the legacy search's waves (src/mcts.py `batch_K`): up to batch_k distinct leaves per game are
+        collected, evaluated together and backed up per wave (select_wave / expand_wave / search)."""
         dev = torch.device(device)
         if dev.type != "cuda":
             raise RuntimeError("TreeEngine needs a HIP device (no CPU path)")
@@ -92,10 +101,29 @@ class TreeEngine:
         for name, t in self.buf.items():
             setattr(d, name, t.data_ptr())
         self.desc = d
-        # evaluator scratch (fused network inputs / outputs)
+        self.batch_k = max(1, int(batch_k))
+        if self.batch_k > 32:
+            raise ValueError(f"batch_k must be <= 32, got {self.batch_k}")
+        K = self.batch_k
+        self.wbuf: Dict[str, torch.Tensor] = {}
+        self.wdesc = None
+        if K > 1:                                                       # slot-major [K][B] per-leaf arrays of a wave
+            self.wbuf = {
+                "path": z((K * B * WAVE_PATH_CAP,), torch.int32), "path_len": z((K * B,), torch.int32),
+                "leaf_kind": z((K * B,), torch.int32), "leaf_state": z((K * B, 4), torch.int64),
+                "leaf_value": z((K * B,), torch.float32), "leaf_edge": z((K * B,), torch.int32),
+                "leaf_parent": z((K * B,), torch.int32), "sims_done": z((B,), torch.int32),
+                "unfinished": z((1,), torch.int32),
+            }
+            wd = LzTreeWaveDesc()
+            wd.batch_k, wd.path_cap = K, WAVE_PATH_CAP
+            for name, t in self.wbuf.items():
+                setattr(wd, name, t.data_ptr())
+            self.wdesc = wd
+        # evaluator scratch (fused network inputs / outputs): one row per leaf slot of a wave
         self.planes = z((B, 11, 6, 6), torch.float32)
-        self.lp1, self.lp2, self.lpm = (z((B, 36), torch.float32) for _ in range(3))
-        self.values = z((B,), torch.float32)
+        self.lp1, self.lp2, self.lpm = (z((K * B, 36), torch.float32) for _ in range(3))
+        self.values = z((K * B,), torch.float32)
         # finish outputs
         self.policy_dense = z((B, TOTAL_ACTION_DIM), torch.float32)
         self.chosen_index = z((B,), torch.int32)
@@ -152,6 +180,43 @@ class TreeEngine:
                                            L.ptr(lpm), L.ptr(priors220), L.ptr(values), L.ptr(noise), L.i64(nz_stride),
                                            C.c_float(float(epsilon)), self._stream()), "tree_expand")
 
+    # ---- waves of batch_k leaves (legacy search, src/mcts.py:318-497) ----
+    def select_wave(self, sims: int, reset_budget: bool = False) -> None:
+        """Up to min(batch_k, sims - used) distinct leaves per game into the [batch_k][B] slot arrays (wbuf)."""
+        with torch.cuda.device(self.device):
+            L.check(L.lib().lz_tree_wave_select(C.byref(self.desc), C.byref(self.wdesc), L.i64(sims),
+                                                C.c_int(1 if reset_budget else 0), self._stream()), "tree_wave_select")
+
+    def expand_wave(self, *, values: torch.Tensor, heads=None, priors220: Optional[torch.Tensor] = None) -> None:
+        """Back up / expand the wave's leaves in the reference's order; inputs hold batch_k * B rows (slot-major)."""
+        lp1 = lp2 = lpm = None
+        if priors220 is None:
+            lp1, lp2, lpm = heads
+        with torch.cuda.device(self.device):
+            L.check(L.lib().lz_tree_wave_expand(C.byref(self.desc), C.byref(self.wdesc), L.ptr(lp1), L.ptr(lp2),
+                                                L.ptr(lpm), L.ptr(priors220), L.ptr(values), self._stream()),
+                    "tree_wave_expand")
+
+    def search_waves(self, net: FusedNet, sims: int, waves: int, noise: Optional[torch.Tensor] = None,
+                     epsilon: float = 0.25, continue_trees: bool = False, skip_roots: bool = False) -> None:
+        """[roots ->] `waves` x (select batch_k leaves, evaluate batch_k * B slots, expand + backup); C++ loop."""
+        nz_stride = int(noise.shape[1]) if noise is not None else 0
+        with torch.cuda.device(self.device):
+            L.check(L.lib().lz_tree_search_waves(
+                C.byref(self.desc), C.byref(self.wdesc), C.byref(net.desc), L.i64(sims), L.i64(waves), L.ptr(self.lp1),
+                L.ptr(self.lp2), L.ptr(self.lpm), L.ptr(self.values), L.ptr(noise), L.i64(nz_stride),
+                C.c_float(float(epsilon)), C.c_int(1 if continue_trees else 0), C.c_int(1 if skip_roots else 0),
+                self._stream()), "tree_search_waves")
+
+    def finish_waves(self, net: FusedNet, sims: int, max_rounds: int = 4096) -> int:
+        """Games that found fewer open leaves than batch_k in some wave still have budget: further rounds until every
+        game has used `sims` simulations (one host read per round; rare outside tiny endgame trees)."""
+        rounds = 0
+        while int(self.wbuf["unfinished"].item()) > 0 and rounds < max_rounds:
+            self.search_waves(net, sims, 1, skip_roots=True)
+            rounds += 1
+        return rounds
+
     def finish(self, temperatures: torch.Tensor, uniforms: Optional[torch.Tensor],
                target_temperatures: Optional[torch.Tensor] = None, prior_pseudocount: float = 0.0,
                force_uniform: Optional[torch.Tensor] = None, sample_moves: Optional[bool] = None) -> None:
@@ -186,6 +251,9 @@ class TreeEngine:
         trees were prepared by advance() (kept subtrees / fresh roots), no begin."""
         if int(sims) > self.max_sims:
             raise ValueError(f"sims={sims} exceeds the arena capacity max_sims={self.max_sims}")
+        if self.batch_k > 1:
+            self.search_waves(net, sims, -(-int(sims) // self.batch_k), noise, epsilon, continue_trees)
+            return
         nz_stride = int(noise.shape[1]) if noise is not None else 0
         fn = L.lib().lz_tree_search_continue if continue_trees else L.lib().lz_tree_search
         with torch.cuda.device(self.device):

@@ -357,3 +357,34 @@ def test_auto_reuse_factor_is_bounded_by_memory_and_node_limit():
     assert 1.0 <= f_tight < 16.0
     eng = TreeEngine(64, 50, DEV, reuse_factor=-1.0)
     assert eng.reuse_factor == 16.0 and eng.node_cap == 50 + 2 + 16 * 50
+
+
+@pytest.mark.parametrize("batch_k,sims", [(16, 50), (4, 30), (16, 200)])
+def test_gpu_wave_batched_search_matches_oracle(batch_k, sims):
+    """The legacy search's waves (src/mcts.py `batch_K` leaves per tree and wave, no virtual loss; oracle pinned by
+    g13): same leaves in the same order in every wave, bit-exact visit counts / priors / picks over three moves with
+    subtree reuse."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from tests.tree_parity import run_injected_wave_parity
+    games = 24 if sims == 200 else 48
+    eng, waves, short = run_injected_wave_parity("cuda:0", num_games=games, sims=sims, batch_k=batch_k, moves=3,
+                                                 seed=batch_k + sims)
+    assert waves >= 3 * -(-sims // batch_k)
+
+
+def test_gpu_wave_batched_search_on_narrow_trees_needs_extra_rounds():
+    """Roots with at most three legal actions: a wave often finds fewer open leaves than batch_k, so the budget is used
+    up over more rounds than ceil(sims / batch_k) -- still leaf for leaf the oracle's waves."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from tests.tree_parity import run_injected_wave_parity
+    z = load("g1_rules.npz")
+    st = states(z, "s")
+    mask, _ = O.encode_actions(st)
+    narrow = np.flatnonzero((mask.sum(axis=1) >= 1) & (mask.sum(axis=1) <= 3))
+    assert narrow.size >= 16
+    pick = narrow[np.random.default_rng(2).permutation(narrow.size)[:32]]
+    sub = {f: np.ascontiguousarray(np.asarray(st[f])[pick]) for f in FIELDS}
+    eng, waves, short = run_injected_wave_parity("cuda:0", sims=40, batch_k=16, moves=2, seed=9, states=sub)
+    assert short > 0 and waves > 2 * 3

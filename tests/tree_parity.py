@@ -225,3 +225,109 @@ def run_injected_reuse_parity(device, num_games=48, sims=48, moves=4, seed=3, c=
                 trees[i] = O.OracleTree(cur[i], c)
     assert int(eng.reuse_dropped.item()) == 0
     return eng, kept_total
+
+
+def run_injected_wave_parity(device, num_games=48, sims=50, batch_k=16, moves=3, seed=5, c=1.0, with_noise=True, eps=0.25,
+                             reuse_factor=4.0, states=None):
+    """The legacy search's waves (src/mcts.py batch_K, oracle: lzo_tree_select_wave / complete_wave, pinned by g13) on
+    the GPU engine: `moves` consecutive searches with subtree reuse, both sides driven by `hash_evaluator`.  Every wave
+    must collect the same leaves in the same order (the leaf states are compared), and after every search the root
+    visit counts, priors, value and pick must agree bit for bit."""
+    from liuzhou_amd.tree_engine import TreeEngine, OUT_CAP
+    from oracle.selfplay_oracle import deterministic_pick
+    from tests.golden_utils import load, states as gstates
+    rng = np.random.default_rng(seed)
+    if states is None:
+        z = load("g1_rules.npz")
+        st_all = gstates(z, "s")
+        idx0 = rng.integers(0, st_all["board"].shape[0], num_games)
+        states = {f: np.ascontiguousarray(np.asarray(st_all[f])[idx0]) for f in FIELDS}
+    B, K = states["board"].shape[0], int(batch_k)
+    eng = TreeEngine(B, sims, device, c, reuse_factor=reuse_factor, batch_k=K)
+    cur = [O.state_from_batch(states, i) for i in range(B)]
+    trees = [O.OracleTree(cur[i], c) for i in range(B)]
+    waves_total = short_waves = 0
+    for mv in range(moves):
+        eng.set_roots(to_gpu_batch(O.batch_from_states(cur), device))
+        if mv == 0:
+            eng.begin()
+        else:
+            eng.advance()
+        noise = rng.gamma(0.3, 1.0, size=(B, OUT_CAP)).astype(np.float32) + np.float32(1e-6) if with_noise else None
+        nz_dev = None if noise is None else torch.from_numpy(noise).to(device)
+        kind = eng.buf["leaf_kind"].cpu().numpy()
+        leaf = unpack_packed(eng.buf["leaf_state"].cpu().numpy())
+        pend = [t.prepare_root() for t in trees]
+        assert np.array_equal(kind == 1, np.array(pend)), f"move {mv}: fresh / kept roots differ"
+        pri, val = hash_evaluator(leaf)
+        for i, t in enumerate(trees):
+            if pend[i]:
+                t.complete(pri[i], float(val[i]), None if noise is None else noise[i], eps)
+            elif noise is not None and t.root_children()[0].size > 0:
+                t.root_noise(noise[i], eps)
+        eng.expand(is_root=True, values=torch.from_numpy(val).to(device), priors220=torch.from_numpy(pri).to(device),
+                   noise=nz_dev, epsilon=eps)
+        done = [0] * B
+        first = True
+        while True:
+            eng.select_wave(sims, reset_budget=first)
+            first = False
+            kinds = eng.wbuf["leaf_kind"].cpu().numpy().reshape(K, B)
+            slots = unpack_packed(eng.wbuf["leaf_state"].cpu().numpy())            # [K*B] slot-major
+            pri, val = hash_evaluator(slots)
+            progressed = False
+            for i, t in enumerate(trees):
+                if done[i] >= sims or t.root_terminal():
+                    assert not kinds[:, i].any(), (mv, i)
+                    continue
+                got = t.select_wave(min(K, sims - done[i]))
+                found = int((kinds[:, i] != 0).sum())
+                assert found == got and kinds[:found, i].all(), (mv, i, found, got)
+                short_waves += int(got < min(K, sims - done[i]))
+                done[i] = sims if got == 0 else done[i] + got
+                progressed = progressed or got > 0
+                # the oracle's evaluation list = the GPU's "expand" slots that have a legal move, in slot order
+                ws = t.wave_states()
+                rows = []
+                for j in range(found):
+                    if kinds[j, i] == 1:
+                        cs = O.state_from_batch({f: np.asarray(slots[f])[j * B + i: j * B + i + 1] for f in FIELDS}, 0)
+                        if O.legal_indices_py(cs):
+                            rows.append(j * B + i)
+                assert len(rows) == len(ws), (mv, i, len(rows), len(ws))
+                if ws:
+                    want = O.batch_from_states(ws)
+                    for f in FIELDS:
+                        a = np.asarray(slots[f])[rows].reshape(len(rows), -1).astype(np.int64)
+                        b = np.asarray(want[f]).reshape(len(rows), -1).astype(np.int64)
+                        assert np.array_equal(a, b), f"move {mv} game {i}: wave leaf field {f} differs"
+                    t.complete_wave(pri[rows], val[rows])
+            waves_total += 1
+            assert (int(eng.wbuf["unfinished"].item()) > 0) == any(
+                done[i] < sims and not trees[i].root_terminal() for i in range(B)), mv
+            eng.expand_wave(values=torch.from_numpy(val).to(device), priors220=torch.from_numpy(pri).to(device))
+            if not progressed or all(done[i] >= sims or trees[i].root_terminal() for i in range(B)):
+                break
+        temps = torch.full((B,), 0.1, dtype=torch.float32, device=device)
+        eng.finish(temps, None)
+        got_v, got_p = engine_visits(eng)
+        chosen = eng.chosen_index.cpu().numpy()
+        rv = eng.root_value.cpu().numpy()
+        term = eng.terminal_mask.cpu().numpy()
+        for i, t in enumerate(trees):
+            if t.root_terminal():
+                assert term[i] and chosen[i] == -1, (mv, i)
+                continue
+            idx, vis, vs, pr, pl = t.root_children()
+            want = np.zeros(220, np.int32); want[idx] = vis
+            assert np.array_equal(got_v[i], want), (mv, i, np.abs(got_v[i] - want).sum())
+            wp = np.zeros(220, np.float32); wp[idx] = pr
+            assert np.array_equal(got_p[i], wp), (mv, i)
+            assert abs(float(rv[i]) - t.root_value_sum() / max(1, t.root_visits())) < 1e-6
+            pick = deterministic_pick(idx, vis, vs, pr, pl, t.root_player())
+            assert int(chosen[i]) == pick, (mv, i)
+            cur[i] = O.apply_index(cur[i], pick)
+            if not t.advance(pick):
+                trees[i] = O.OracleTree(cur[i], c)
+    assert int(eng.reuse_dropped.item()) == 0
+    return eng, waves_total, short_waves
