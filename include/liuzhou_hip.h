@@ -297,7 +297,8 @@ typedef struct LzTreeDesc {
 /* SoA batch -> packed records; packed records -> float32[B,11,6,6] model input (src/neural_network.py:15-65) */
 /* Wave-batched leaves: the legacy search of src/mcts.py:280-497 (`batch_K` distinct leaves per tree and wave, no
  * virtual loss; batch_K = 1 is the protocol above).  Per-leaf arrays are slot-major [batch_k][B]; `leaf_state` is the
- * network batch of a wave (batch_k * B packed states, inactive slots keep their previous content). */
+ * leaf of slot (j, g); the leaves that need the network are also appended to a compact list (`eval_state`, `eval_count`)
+ * whose rows the network evaluates (device-counted batch) and lz_tree_wave_expand reads back through `eval_row`. */
 typedef struct LzTreeWaveDesc {
     int32_t  batch_k;              /* leaves per game and wave, 1..32 */
     int32_t  path_cap;             /* entries per leaf path, > 48 (deeper descents are not followed) */
@@ -310,16 +311,21 @@ typedef struct LzTreeWaveDesc {
     int32_t* leaf_parent;          /* [batch_k][B] */
     int32_t* sims_done;            /* [B] simulations used by the current search */
     int32_t* unfinished;           /* [1] games with budget left after the last lz_tree_wave_select */
+    int32_t* eval_row;             /* [batch_k][B] row of the slot's leaf in the compact evaluation list */
+    void*    eval_state;           /* [batch_k * B] packed: the leaves of the wave that need the network, compacted */
+    int64_t* eval_count;           /* [1] length of that list (device-side batch size of the network launch) */
+    int64_t* eval_total;           /* [1] sum of eval_count over the previous waves (statistics) */
 } LzTreeWaveDesc;
 /* SelectLeaves for a wave: up to min(batch_k, sims - sims_done) distinct leaves per game, in the order the reference
  * collects them (src/mcts.py:333-425); sims_done += leaves found.  reset_budget != 0 starts a new search. */
 LZ_API int lz_tree_wave_select(const LzTreeDesc* tree, const LzTreeWaveDesc* wave, int64_t sims, int reset_budget,
                                void* stream);
 /* CompletePending for a wave (src/mcts.py:427-497): terminal / no-legal-move leaves are backed up first, then the
- * evaluated leaves are expanded and backed up, each group in leaf order.  Heads / priors220 / values: batch_k * B rows. */
+ * evaluated leaves are expanded and backed up, each group in leaf order.  Evaluator rows (heads or priors220, values)
+ * are the rows of the compact list, or slot-major [batch_k][B] when `slot_major` != 0 or priors220 is given. */
 LZ_API int lz_tree_wave_expand(const LzTreeDesc* tree, const LzTreeWaveDesc* wave, const float* log_p1,
                                const float* log_p2, const float* log_pmc, const float* priors220, const float* values,
-                               void* stream);
+                               int slot_major, void* stream);
 /* Whole search of one move in waves, enqueued from C++ (hipGraph-capturable); see lz_engine.hip. */
 LZ_API int lz_tree_search_waves(const LzTreeDesc* tree, const LzTreeWaveDesc* wave, const LzNetDesc* net, int64_t sims,
                                 int64_t waves, float* log_p1, float* log_p2, float* log_pmc, float* values,

@@ -567,6 +567,8 @@ struct WaveArrays {
     int K, cap;
     int* path; int* path_len; int* leaf_kind; Packed* leaf_state; float* leaf_value; int* leaf_edge; int* leaf_parent;
     int* sims_done; int* unfinished;
+    int* eval_row; Packed* eval_state; unsigned long long* eval_count;   // compact list of the leaves to evaluate
+    unsigned long long* eval_total;                                      // running sum of eval_count (statistics)
 };
 struct Level { int e0, ne_pl, parent_n, node; double last_sc; int last_k, in_edge; };
 static_assert(sizeof(Level) == 32, "level record is 32 bytes");
@@ -665,7 +667,11 @@ __device__ __forceinline__ void tree_select_wave(const Tree& t, const WaveArrays
                         int kd, p, q2, ex;
                         index_to_code(leaf.phase, c_meta & 0xFF, kd, p, q2, ex);
                         apply(leaf, kd, p, q2);
-                        w.leaf_state[slot] = pack(leaf);
+                        const Packed ps = pack(leaf);
+                        w.leaf_state[slot] = ps;
+                        const unsigned long long row = atomicAdd(w.eval_count, 1ull);   // next row of the network batch
+                        w.eval_row[slot] = (int)row;
+                        w.eval_state[row] = ps;
                     }
                 }
                 ++found;
@@ -708,7 +714,7 @@ __global__ __launch_bounds__(kBlock) void tree_select_wave_kernel(Tree t, WaveAr
 
 __global__ __launch_bounds__(kBlock) void wave_budget_reset_kernel(WaveArrays w, int B, int reset_done) {
     const int g = blockIdx.x * kBlock + threadIdx.x;
-    if (g == 0) *w.unfinished = 0;
+    if (g == 0) { *w.unfinished = 0; *w.eval_total += *w.eval_count; *w.eval_count = 0ull; }
     if (reset_done && g < B) w.sims_done[g] = 0;
 }
 
@@ -720,7 +726,7 @@ __global__ __launch_bounds__(kBlock) void tree_expand_wave_kernel(Tree t, WaveAr
                                                                   const float* __restrict__ lp2,
                                                                   const float* __restrict__ lpm,
                                                                   const float* __restrict__ priors220,
-                                                                  const float* __restrict__ values) {
+                                                                  const float* __restrict__ values, int slot_major) {
     const int g = wave_game();
     if (g >= t.B) return;
     const int lane = lane_id();
@@ -743,7 +749,10 @@ __global__ __launch_bounds__(kBlock) void tree_expand_wave_kernel(Tree t, WaveAr
                 run = (second >> j) & 1u;
             }
             if (!run) continue;
-            const size_t o = (size_t)j * t.B;
+            // evaluator rows: slot-major [batch_k][B], or the rows of the compact list the network evaluated
+            // (tree_expand indexes its inputs with g, so the base pointers are shifted by row - g)
+            const ptrdiff_t o = slot_major ? (ptrdiff_t)j * t.B
+                                                     : (ptrdiff_t)(w.leaf_kind[slot] == kLeafExpand ? w.eval_row[slot] : 0) - g;
             tree_expand<false>(slot_view(t, w, j), g, lane, lp1 ? lp1 + o * 36 : nullptr, lp2 ? lp2 + o * 36 : nullptr,
                                lpm ? lpm + o * 36 : nullptr, priors220 ? priors220 + o * 220 : nullptr, values + o,
                                nullptr, 0, 0.f);
@@ -1230,12 +1239,15 @@ WaveArrays make_wave(const LzTreeWaveDesc* w) {
     a.path = w->path; a.path_len = w->path_len; a.leaf_kind = w->leaf_kind;
     a.leaf_state = reinterpret_cast<Packed*>(w->leaf_state); a.leaf_value = w->leaf_value; a.leaf_edge = w->leaf_edge;
     a.leaf_parent = w->leaf_parent; a.sims_done = w->sims_done; a.unfinished = w->unfinished;
+    a.eval_row = w->eval_row; a.eval_state = reinterpret_cast<Packed*>(w->eval_state);
+    a.eval_count = reinterpret_cast<unsigned long long*>(w->eval_count);
+    a.eval_total = reinterpret_cast<unsigned long long*>(w->eval_total);
     return a;
 }
 bool wave_ok(const LzTreeWaveDesc* w) {
     return w && w->batch_k >= 1 && w->batch_k <= 32 && w->path_cap > kWaveDepth && w->path && w->path_len &&
            w->leaf_kind && w->leaf_state && w->leaf_value && w->leaf_edge && w->leaf_parent && w->sims_done &&
-           w->unfinished;
+           w->unfinished && w->eval_row && w->eval_state && w->eval_count && w->eval_total;
 }
 inline unsigned gw(int64_t n) { return (unsigned)((n + kWavesPerBlock - 1) / kWavesPerBlock); }
 inline unsigned gt(int64_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
@@ -1415,12 +1427,12 @@ int lz_tree_wave_select(const LzTreeDesc* d, const LzTreeWaveDesc* w, int64_t si
 }
 
 int lz_tree_wave_expand(const LzTreeDesc* d, const LzTreeWaveDesc* w, const float* lp1, const float* lp2,
-                        const float* lpmc, const float* priors220, const float* values, void* stream) {
+                        const float* lpmc, const float* priors220, const float* values, int slot_major, void* stream) {
     if (!tree_ok(d) || !wave_ok(w) || !values) return LZ_ERR_ARG;
     if (!priors220 && (!lp1 || !lp2 || !lpmc)) return LZ_ERR_ARG;
     if (d->num_games == 0) return LZ_OK;
     hipLaunchKernelGGL(tree_expand_wave_kernel, dim3(gw(d->num_games)), dim3(kBlock), 0, as_stream(stream), make_tree(d),
-                       make_wave(w), lp1, lp2, lpmc, priors220, values);
+                       make_wave(w), lp1, lp2, lpmc, priors220, values, (slot_major || priors220) ? 1 : 0);
     return st();
 }
 
@@ -1445,9 +1457,10 @@ int lz_tree_search_waves(const LzTreeDesc* d, const LzTreeWaveDesc* w, const LzN
     for (int64_t i = 0; i < waves; ++i) {
         rc = lz_tree_wave_select(d, w, sims, (!skip_roots && i == 0) ? 1 : 0, stream);
         if (rc) return rc;
-        rc = lz_net_forward_packed_f16(net, w->leaf_state, (int64_t)w->batch_k * B, lp1, lp2, lpmc, nullptr, values, stream);
+        rc = lz_net_forward_packed_counted_f16(net, w->eval_state, (int64_t)w->batch_k * B, w->eval_count, lp1, lp2, lpmc,
+                                               nullptr, values, stream);
         if (rc) return rc;
-        rc = lz_tree_wave_expand(d, w, lp1, lp2, lpmc, nullptr, values, stream);
+        rc = lz_tree_wave_expand(d, w, lp1, lp2, lpmc, nullptr, values, 0, stream);
         if (rc) return rc;
     }
     return st();

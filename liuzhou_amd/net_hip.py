@@ -105,6 +105,20 @@ class FusedNet:
         out = self(inputs)
         return out
 
+    def forward_packed(self, packed: torch.Tensor):
+        """The same forward on 32-byte packed bitboard states int64[N,4] (lz_pack_states): the model-input encode is
+        fused into the kernel's prologue.  Returns (log_p1, log_p2, log_pmc, None, value)."""
+        L.require_hip(packed, "net_forward_packed_f16")
+        x = packed.contiguous()
+        N, dev = int(x.shape[0]), x.device
+        lp1, lp2, lpm = (torch.empty((N, 36), dtype=torch.float32, device=dev) for _ in range(3))
+        val = torch.empty((N,), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            L.check(L.lib().lz_net_forward_packed_f16(C.byref(self.desc), L.ptr(x), L.i64(N), L.ptr(lp1), L.ptr(lp2),
+                                                      L.ptr(lpm), None, L.ptr(val), L.stream_ptr(dev)),
+                    "net_forward_packed_f16")
+        return lp1, lp2, lpm, None, val
+
     def values_only(self, planes: torch.Tensor) -> torch.Tensor:
         """Scalar values only: the kernel skips the policy head and writes nothing but `value`."""
         L.require_hip(planes, "net_forward_f16")

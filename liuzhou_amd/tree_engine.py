@@ -42,7 +42,8 @@ class LzTreeDesc(C.Structure):
 class LzTreeWaveDesc(C.Structure):
     _fields_ = [("batch_k", C.c_int32), ("path_cap", C.c_int32)] + \
                [(n, C.c_void_p) for n in ("path", "path_len", "leaf_kind", "leaf_state", "leaf_value", "leaf_edge",
-                                          "leaf_parent", "sims_done", "unfinished")]
+                                          "leaf_parent", "sims_done", "unfinished", "eval_row", "eval_state",
+                                          "eval_count", "eval_total")]
 
 
 WAVE_PATH_CAP = 64             # entries per leaf path of a wave (the kernel follows descents up to 48 levels)
@@ -113,7 +114,9 @@ class TreeEngine:
                 "leaf_kind": z((K * B,), torch.int32), "leaf_state": z((K * B, 4), torch.int64),
                 "leaf_value": z((K * B,), torch.float32), "leaf_edge": z((K * B,), torch.int32),
                 "leaf_parent": z((K * B,), torch.int32), "sims_done": z((B,), torch.int32),
-                "unfinished": z((1,), torch.int32),
+                "unfinished": z((1,), torch.int32), "eval_row": z((K * B,), torch.int32),
+                "eval_state": z((K * B, 4), torch.int64), "eval_count": z((1,), torch.int64),
+                "eval_total": z((1,), torch.int64),
             }
             wd = LzTreeWaveDesc()
             wd.batch_k, wd.path_cap = K, WAVE_PATH_CAP
@@ -187,14 +190,17 @@ class TreeEngine:
             L.check(L.lib().lz_tree_wave_select(C.byref(self.desc), C.byref(self.wdesc), L.i64(sims),
                                                 C.c_int(1 if reset_budget else 0), self._stream()), "tree_wave_select")
 
-    def expand_wave(self, *, values: torch.Tensor, heads=None, priors220: Optional[torch.Tensor] = None) -> None:
-        """Back up / expand the wave's leaves in the reference's order; inputs hold batch_k * B rows (slot-major)."""
+    def expand_wave(self, *, values: torch.Tensor, heads=None, priors220: Optional[torch.Tensor] = None,
+                    slot_major: bool = False) -> None:
+        """Back up / expand the wave's leaves in the reference's order.  Evaluator rows: the compact list
+        (wbuf eval_state / eval_row), or slot-major [batch_k][B] with `slot_major` / `priors220`."""
         lp1 = lp2 = lpm = None
         if priors220 is None:
             lp1, lp2, lpm = heads
         with torch.cuda.device(self.device):
             L.check(L.lib().lz_tree_wave_expand(C.byref(self.desc), C.byref(self.wdesc), L.ptr(lp1), L.ptr(lp2),
-                                                L.ptr(lpm), L.ptr(priors220), L.ptr(values), self._stream()),
+                                                L.ptr(lpm), L.ptr(priors220), L.ptr(values),
+                                                C.c_int(1 if slot_major else 0), self._stream()),
                     "tree_wave_expand")
 
     def search_waves(self, net: FusedNet, sims: int, waves: int, noise: Optional[torch.Tensor] = None,
@@ -211,10 +217,10 @@ class TreeEngine:
     def finish_waves(self, net: FusedNet, sims: int, max_rounds: int = 4096) -> int:
         """Games that found fewer open leaves than batch_k in some wave still have budget: further rounds until every
         game has used `sims` simulations (one host read per round; rare outside tiny endgame trees)."""
-        rounds = 0
+        rounds, chunk = 0, 8             # a round in which every game is done costs a few empty launches: 8 per host read
         while int(self.wbuf["unfinished"].item()) > 0 and rounds < max_rounds:
-            self.search_waves(net, sims, 1, skip_roots=True)
-            rounds += 1
+            self.search_waves(net, sims, chunk, skip_roots=True)
+            rounds += chunk
         return rounds
 
     def finish(self, temperatures: torch.Tensor, uniforms: Optional[torch.Tensor],
@@ -278,26 +284,32 @@ class PortableTreeMCTS:
                  add_dirichlet_noise: bool = True, dirichlet_alpha: float = 0.3, dirichlet_epsilon: float = 0.25,
                  sample_moves: bool = True, use_graph: Optional[bool] = None, reuse_tree: bool = False,
                  reuse_factor: float = -1.0, policy_target_temperature: Optional[float] = None,
-                 policy_target_prior_pseudocount: float = 0.0) -> None:
-        """`reuse_tree`: keep the played child's subtree between consecutive search_batch calls on the same games
+                 policy_target_prior_pseudocount: float = 0.0, batch_k: int = 1) -> None:
+        """`batch_k` > 1: the legacy search's waves (src/mcts.py `batch_K`, default 16 there): up to batch_k distinct
+        leaves per game are collected, evaluated in one network launch of batch_k * B positions and backed up per wave.
+        `reuse_tree`: keep the played child's subtree between consecutive search_batch calls on the same games
         (the reference's portable self-play does, v1/python/portable_self_play.py:191); the arenas then hold
         (1 + reuse_factor) * sims nodes per game (reuse_factor < 0: as much as a third of the free memory allows).  `policy_target_*`: portable_mcts.py:690-700."""
         self.net, self.sims = net, int(num_simulations)
         self.reuse_tree = bool(reuse_tree)
+        self.batch_k = max(1, int(batch_k))
         self.engine = TreeEngine(num_games, num_simulations, device, exploration_weight,
-                                 reuse_factor=float(reuse_factor) if self.reuse_tree else 0.0)
+                                 reuse_factor=float(reuse_factor) if self.reuse_tree else 0.0, batch_k=self.batch_k)
+        self._evals_dev = torch.zeros((1,), dtype=torch.int64, device=self.engine.device)
+        self.extra_rounds = 0
         self.target_temperature = None if policy_target_temperature is None else float(policy_target_temperature)
         self.prior_pseudocount = float(policy_target_prior_pseudocount)
         self._have_trees = False
         self.add_noise, self.alpha, self.eps = bool(add_dirichlet_noise), float(dirichlet_alpha), float(dirichlet_epsilon)
         self.sample_moves = bool(sample_moves)
-        self.leaf_evals = 0
+        self._root_evals = 0
         # hipGraph: the whole search of a move (1 + sims) x (select, fused net, expand) is captured once and
         # replayed every move; all buffers are static, noise / roots are refreshed in place before the replay.
         if use_graph is None:
             use_graph = os.environ.get("LZ_TREE_GRAPH", "on").strip().lower() not in ("off", "0", "false")
         self.use_graph = bool(use_graph)
         self._graphs = {}
+        self._tail_graph = None
         self._noise_buf = torch.zeros((self.engine.B, OUT_CAP), dtype=torch.float32, device=self.engine.device)
 
     def _search(self, add_noise: bool, continue_trees: bool) -> None:
@@ -320,6 +332,36 @@ class PortableTreeMCTS:
             self._graphs[key] = g
         g.replay()
 
+    @property
+    def leaf_evals(self) -> int:
+        """Network evaluations so far (batch_k > 1: one host read of the device-side counters)."""
+        n = self._root_evals
+        if self.batch_k > 1:
+            n += int(self.engine.wbuf["eval_total"].item()) + int(self.engine.wbuf["eval_count"].item())
+        return n
+
+    def _finish_waves(self) -> None:
+        """batch_k > 1: games whose waves found fewer open leaves than batch_k still have budget (narrow trees)."""
+        if self.batch_k <= 1:
+            return
+        e = self.engine
+        if not self.use_graph:
+            self.extra_rounds += e.finish_waves(self.net, self.sims)
+            return
+        # the leftover rounds are launch-bound (a handful of games, tiny network batches): replay them as a graph of
+        # 8 rounds per host read instead of 32 separate launches
+        rounds = 0
+        while int(e.wbuf["unfinished"].item()) > 0 and rounds < 4096:
+            if self._tail_graph is None:
+                torch.cuda.synchronize(e.device)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    e.search_waves(self.net, self.sims, 8, skip_roots=True)
+                self._tail_graph = g
+            self._tail_graph.replay()
+            rounds += 8
+        self.extra_rounds += rounds
+
     def reset_trees(self) -> None:
         """Forget the kept subtrees: the next search_batch starts every game from a fresh root."""
         self._have_trees = False
@@ -331,18 +373,37 @@ class PortableTreeMCTS:
         """`state`: the games' current positions.  With `reuse_tree`, games whose position is the child reached by
         `played_action` (default: the move this engine picked last time) keep that child's subtree; `reset` marks
         games that were re-seated.  Anything that does not match simply starts a fresh tree."""
+        self.launch_search(state, active=active, add_dirichlet_noise=add_dirichlet_noise, reset=reset,
+                           played_action=played_action)
+        return self.complete_search(state, temperatures=temperatures,
+                                    force_uniform_random_mask=force_uniform_random_mask)
+
+    def launch_search(self, state: GpuStateBatch, *, active: Optional[torch.Tensor] = None,
+                      add_dirichlet_noise: Optional[bool] = None, reset: Optional[torch.Tensor] = None,
+                      played_action: Optional[torch.Tensor] = None) -> None:
+        """First half of search_batch: everything up to the end of the captured search, nothing that waits for the
+        device (so that several engines on several streams can be launched back to back)."""
         e = self.engine
-        dev = e.device
         add_noise = self.add_noise if add_dirichlet_noise is None else bool(add_dirichlet_noise)
         e.set_roots(state, active)
         continue_trees = self.reuse_tree and self._have_trees
         if continue_trees:
             e.advance(played_action, reset, self.sims)
         if add_noise:
-            self._noise_buf.copy_(dirichlet_noise((e.B, OUT_CAP), self.alpha, dev))
+            self._noise_buf.copy_(dirichlet_noise((e.B, OUT_CAP), self.alpha, e.device))
         self._search(add_noise, continue_trees)
         self._have_trees = True
-        self.leaf_evals += e.B * (self.sims + 1)
+
+    def complete_search(self, state: GpuStateBatch, *, temperatures: torch.Tensor,
+                        force_uniform_random_mask: Optional[torch.Tensor] = None) -> RootSearchBatchOutput:
+        """Second half: leftover waves (batch_k > 1, one host read), policy / pick extraction, output record."""
+        e = self.engine
+        dev = e.device
+        if self.batch_k > 1:
+            self._finish_waves()
+            self._root_evals += e.B                                   # wave evaluations are counted on the device
+        else:
+            self._root_evals += e.B * (self.sims + 1)
         need_u = self.sample_moves or force_uniform_random_mask is not None
         uniforms = torch.rand((e.B,), dtype=torch.float32, device=dev) if need_u else None
         temps = temperatures.to(torch.float32).contiguous()
@@ -382,7 +443,9 @@ class DualStreamTreeMCTS:
         self.parts = []
         for n in sizes:
             base = model if isinstance(model, FusedNet) else FusedNet(model, dev)
-            self.parts.append(PortableTreeMCTS(base.variant(half_workgroups=True), n, num_simulations, dev, **kw))
+            # waves of batch_k leaves are large launches: full 8-wave workgroups (they fill the chip on their own)
+            half = int(kw.get("batch_k", 1)) <= 1
+            self.parts.append(PortableTreeMCTS(base.variant(half_workgroups=half), n, num_simulations, dev, **kw))
         self.sims = int(num_simulations)
         self.serialize = False        # measurement aid: run the halves one after the other on the caller's stream
 
@@ -410,15 +473,17 @@ class DualStreamTreeMCTS:
         main = torch.cuda.current_stream(self.device)
         cut = lambda t, a, b: None if t is None else t[a:b]
         outs = []
-        for (a, b), part, st in zip(self.bounds, self.parts,
-                                    (main,) * len(self.parts) if self.serialize else self.streams):
+        streams = (main,) * len(self.parts) if self.serialize else self.streams
+        subs = [state._map(lambda t, a=a, b=b: t[a:b]) for a, b in self.bounds]
+        for (a, b), part, st, sub in zip(self.bounds, self.parts, streams, subs):     # launch every part first ...
             st.wait_stream(main)
             with torch.cuda.stream(st):
-                outs.append(part.search_batch(state._map(lambda t, a=a, b=b: t[a:b]), temperatures=temperatures[a:b],
-                                              active=cut(active, a, b),
-                                              add_dirichlet_noise=add_dirichlet_noise, reset=cut(reset, a, b),
-                                              played_action=cut(played_action, a, b),
-                                              force_uniform_random_mask=cut(force_uniform_random_mask, a, b)))
+                part.launch_search(sub, active=cut(active, a, b), add_dirichlet_noise=add_dirichlet_noise,
+                                   reset=cut(reset, a, b), played_action=cut(played_action, a, b))
+        for (a, b), part, st, sub in zip(self.bounds, self.parts, streams, subs):     # ... then the parts that may wait
+            with torch.cuda.stream(st):
+                outs.append(part.complete_search(sub, temperatures=temperatures[a:b],
+                                                 force_uniform_random_mask=cut(force_uniform_random_mask, a, b)))
         if not self.serialize:
             for st in self.streams:
                 main.wait_stream(st)
@@ -433,7 +498,7 @@ class SteadyStateTreeSelfPlay:
     def __init__(self, model, num_games: int, sims: int, device, dtype: str = "float16", seed: int = 12345,
                  temperature_init: float = 1.0, temperature_final: float = 0.1, temperature_threshold: int = 10,
                  max_game_plies: int = 512, exploration_weight: float = 1.0, reuse_tree: bool = False,
-                 reuse_factor: float = -1.0, dual_stream: bool = False) -> None:
+                 reuse_factor: float = -1.0, dual_stream: bool = False, batch_k: int = 1) -> None:
         from .steady_state import SteadyStateRootSelfPlay
         from .mcts_gpu import V1RootMCTSConfig
         dev = torch.device(device)
@@ -447,10 +512,10 @@ class SteadyStateTreeSelfPlay:
         self.dual_stream = bool(dual_stream and self.net.pack.channels == 64 and int(num_games) >= 2)
         if self.dual_stream:
             self.mcts = DualStreamTreeMCTS(self.net, num_games, sims, dev, exploration_weight=exploration_weight,
-                                           reuse_tree=reuse_tree, reuse_factor=reuse_factor)
+                                           reuse_tree=reuse_tree, reuse_factor=reuse_factor, batch_k=batch_k)
         else:
             self.mcts = PortableTreeMCTS(self.net, num_games, sims, dev, exploration_weight, reuse_tree=reuse_tree,
-                                         reuse_factor=reuse_factor)
+                                         reuse_factor=reuse_factor, batch_k=batch_k)
         self._reseated = torch.zeros((self.B,), dtype=torch.uint8, device=dev)
         self.positions = 0
         self._nn_events = []
@@ -479,7 +544,7 @@ def self_play_tree_gpu(model, num_games: int, mcts_simulations: int, temperature
                        policy_target_temperature: Optional[float] = None,
                        policy_target_prior_pseudocount: float = 0.0, reuse_tree: bool = True,
                        reuse_factor: float = -1.0, dual_stream: Optional[bool] = None, continuous_waves: bool = True,
-                       device_tail: bool = True) -> Tuple[TensorSelfPlayBatch, SelfPlayV1Stats]:
+                       device_tail: bool = True, batch_k: int = 1) -> Tuple[TensorSelfPlayBatch, SelfPlayV1Stats]:
     """Tree-search twin of self_play_v1_gpu (same outputs); mirrors v1/python/portable_self_play.py:82-284,
     including the subtree reuse it performs on every move (:191, `reuse_tree`)."""
     dev = torch.device(device)
@@ -493,7 +558,7 @@ def self_play_tree_gpu(model, num_games: int, mcts_simulations: int, temperature
                add_dirichlet_noise=add_dirichlet_noise, dirichlet_alpha=dirichlet_alpha,
                dirichlet_epsilon=dirichlet_epsilon, sample_moves=sample_moves, reuse_tree=reuse_tree,
                reuse_factor=reuse_factor, policy_target_temperature=policy_target_temperature,
-               policy_target_prior_pseudocount=policy_target_prior_pseudocount)
+               policy_target_prior_pseudocount=policy_target_prior_pseudocount, batch_k=batch_k)
     buffer = TensorTrajectoryBuffer(dev, TOTAL_ACTION_DIM, max_steps_hint=max_game_plies, concurrent_games_hint=wave)
     outcome = torch.zeros((3,), dtype=torch.int64, device=dev)
     lengths = torch.zeros((int(num_games),), dtype=torch.int64, device=dev)
@@ -570,7 +635,8 @@ def self_play_tree_gpu(model, num_games: int, mcts_simulations: int, temperature
         step_timing_ms={k: 0.0 for k in keys}, step_timing_ratio={k: 0.0 for k in keys},
         step_timing_calls={k: 0 for k in keys},
         # the device-tail loop runs one fully masked ply per wave after the last game has ended (wave_tail.WaveTail.run)
-        mcts_counters={"leaf_eval_count": int(mcts.leaf_evals) - wasted_plies * wave * (int(mcts_simulations) + 1),
+        mcts_counters={"leaf_eval_count": int(mcts.leaf_evals) - (wasted_plies * wave * (int(mcts_simulations) + 1)
+                                                                  if int(batch_k) <= 1 else 0),
                        "masked_extra_plies": wasted_plies},
         piece_delta_buckets={str(d - 18): int(v) for d, v in enumerate(hist)}, device=str(dev))
     return batch, stats

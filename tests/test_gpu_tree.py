@@ -388,3 +388,47 @@ def test_gpu_wave_batched_search_on_narrow_trees_needs_extra_rounds():
     sub = {f: np.ascontiguousarray(np.asarray(st[f])[pick]) for f in FIELDS}
     eng, waves, short = run_injected_wave_parity("cuda:0", sims=40, batch_k=16, moves=2, seed=9, states=sub)
     assert short > 0 and waves > 2 * 3
+
+
+def test_gpu_wave_search_with_fused_network_compact_batch_equals_slot_major_protocol():
+    """lz_tree_search_waves (C++ loop; the leaves that need the network go through a compact, device-counted batch)
+    gives the same trees as the split-phase protocol in which the fused network evaluates all batch_k * B slots in
+    place: the compact list, its row indirection and the network's independence of the batch position."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from liuzhou_amd.net import ChessNet, MODEL_CONFIGS
+    from liuzhou_amd.net_hip import FusedNet
+    from liuzhou_amd.tree_engine import TreeEngine
+    dev, K, sims, B = "cuda:0", 16, 60, 96
+    torch.manual_seed(20260314)
+    net = FusedNet(ChessNet(**MODEL_CONFIGS["b6c64"]).eval().to(dev))
+    z = load("g1_rules.npz")
+    st = states(z, "s")
+    idx = np.random.default_rng(11).integers(0, st["board"].shape[0], B)
+    sub = {f: np.ascontiguousarray(np.asarray(st[f])[idx]) for f in FIELDS}
+    engines = [TreeEngine(B, sims, dev, 1.0, batch_k=K) for _ in range(2)]
+    for e in engines:
+        e.set_roots(to_gpu_batch(sub, dev))
+    a, b = engines
+    a.search(net, sims)
+    a.finish_waves(net, sims)
+    b.begin()
+    lp1, lp2, lpm, _, val = net.forward_packed(b.buf["leaf_state"])
+    b.expand(is_root=True, values=val, heads=(lp1, lp2, lpm))
+    first = True
+    for _ in range(4096):
+        b.select_wave(sims, reset_budget=first)
+        first = False
+        lp1, lp2, lpm, _, val = net.forward_packed(b.wbuf["leaf_state"])
+        b.expand_wave(values=val, heads=(lp1, lp2, lpm), slot_major=True)
+        if int(b.wbuf["unfinished"].item()) == 0:
+            break
+    temps = torch.ones((B,), dtype=torch.float32, device=dev)
+    for e in engines:
+        e.finish(temps, None)
+    va, pa = engine_visits(a)
+    vb, pb = engine_visits(b)
+    assert np.array_equal(va, vb) and np.array_equal(pa, pb)
+    live = ~a.terminal_mask.cpu().numpy()
+    assert live.any() and (va[live].sum(axis=1) == sims).all()
+    assert torch.equal(a.chosen_index, b.chosen_index) and torch.equal(a.root_value, b.root_value)
