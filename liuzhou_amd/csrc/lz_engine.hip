@@ -583,7 +583,8 @@ __device__ __forceinline__ Tree slot_view(const Tree& t, const WaveArrays& w, in
 }
 
 __device__ __forceinline__ void tree_select_wave(const Tree& t, const WaveArrays& w, int g, int lane,
-                                                 const RootInfo& root, int sims, Level* stack) {
+                                                 const RootInfo& root, int sims, Level* stack, int* leaf_node,
+                                                 int* leaf_act) {
     const int done = w.sims_done[g];
     int to_collect = sims - done;
     to_collect = to_collect < w.K ? to_collect : w.K;
@@ -596,30 +597,40 @@ __device__ __forceinline__ void tree_select_wave(const Tree& t, const WaveArrays
         int e0 = root.e0, ne = root.ne, parent_n = root.visits, node_player = root.player, node = 0;
         double last_sc = INFINITY;
         int last_k = -1;
-        Packed node_state = root.state;
+        // the current node's edge run and its scores stay in registers while the walk stays on this node
+        Edge mine[2];
+        double sc[2] = {0.0, 0.0};
+        bool loaded = false;
         while (found < to_collect) {
+            if (!loaded) {
+                const double sq = sqrt((double)(parent_n > 1 ? parent_n : 1));
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const int k = r * kWave + lane;
+                    sc[r] = __builtin_nan("");                          // no child: never a candidate
+                    if (k < ne) {
+                        mine[r] = load_edge(&edges[e0 + k]);
+                        const int n = edge_n(mine[r].n_info);
+                        double q = 0.0;
+                        if (n > 0) {
+                            const double mv = mine[r].W / (double)n;
+                            const int child_player = (edge_info(mine[r].n_info) & kInfoWhite) ? -1 : 1;
+                            q = child_player == node_player ? mv : -mv;
+                        }
+                        const double u = t.c_puct * (double)mine[r].P * sq / (1.0 + (double)n);
+                        sc[r] = q + u;
+                    }
+                }
+                loaded = true;
+            }
             // next child of the current node in descending (score, -index) order
-            const double sq = sqrt((double)(parent_n > 1 ? parent_n : 1));
             double best = -INFINITY;
             int best_k = -1;
-            Edge mine[2];
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
                 const int k = r * kWave + lane;
-                if (k < ne) {
-                    mine[r] = load_edge(&edges[e0 + k]);
-                    const int n = edge_n(mine[r].n_info);
-                    double q = 0.0;
-                    if (n > 0) {
-                        const double mv = mine[r].W / (double)n;
-                        const int child_player = (edge_info(mine[r].n_info) & kInfoWhite) ? -1 : 1;
-                        q = child_player == node_player ? mv : -mv;
-                    }
-                    const double u = t.c_puct * (double)mine[r].P * sq / (1.0 + (double)n);
-                    const double sc = q + u;
-                    const bool open = sc < last_sc || (sc == last_sc && k > last_k);    // not consumed yet
-                    if (open && sc > best) { best = sc; best_k = k; }
-                }
+                const bool open = sc[r] < last_sc || (sc[r] == last_sc && k > last_k);    // not consumed yet
+                if (open && sc[r] > best) { best = sc[r]; best_k = k; }
             }
             const double mx = lzw::wave_max(best);
             const uint64_t lo = __ballot(best_k >= 0 && best_k < kWave && best == mx);
@@ -635,7 +646,7 @@ __device__ __forceinline__ void tree_select_wave(const Tree& t, const WaveArrays
                 const Level up = stack[d];
                 e0 = up.e0; ne = up.ne_pl & 0xFF; node_player = (up.ne_pl & 0x100) ? -1 : 1; parent_n = up.parent_n;
                 node = up.node; last_sc = up.last_sc; last_k = up.last_k;
-                node_state = d == 0 ? root.state : load_state(&nodes[node].state);
+                loaded = false;
                 continue;
             }
             chosen = __builtin_amdgcn_readfirstlane(chosen);
@@ -662,17 +673,8 @@ __device__ __forceinline__ void tree_select_wave(const Tree& t, const WaveArrays
                     w.leaf_value[slot] = terminal ? (float)((int)((info >> 2) & 3) - 1) : 0.f;
                     w.leaf_edge[slot] = edge_id;
                     w.leaf_parent[slot] = node;
-                    if (!terminal) {
-                        State leaf = unpack(node_state);
-                        int kd, p, q2, ex;
-                        index_to_code(leaf.phase, c_meta & 0xFF, kd, p, q2, ex);
-                        apply(leaf, kd, p, q2);
-                        const Packed ps = pack(leaf);
-                        w.leaf_state[slot] = ps;
-                        const unsigned long long row = atomicAdd(w.eval_count, 1ull);   // next row of the network batch
-                        w.eval_row[slot] = (int)row;
-                        w.eval_state[row] = ps;
-                    }
+                    leaf_node[found] = node;
+                    leaf_act[found] = terminal ? -1 : (c_meta & 0xFF);
                 }
                 ++found;
                 continue;
@@ -691,7 +693,33 @@ __device__ __forceinline__ void tree_select_wave(const Tree& t, const WaveArrays
             ++d;
             e0 = c_begin; ne = c_meta >> 8; parent_n = edge_n(c_ni); node_player = child_player; node = c_child;
             last_sc = INFINITY; last_k = -1;
-            node_state = load_state(&nodes[node].state);
+            loaded = false;
+        }
+        // leaf positions for the network, one lane per leaf: parent position + action; the game's leaves take
+        // consecutive rows of the compact evaluation list (one counter update per game)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int act = lane < found ? leaf_act[lane] : -1;
+        const uint64_t need = __ballot(act >= 0);
+        if (need) {
+            unsigned long long base_row = 0ull;
+            if (lane == 0) base_row = atomicAdd(w.eval_count, (unsigned long long)__popcll(need));
+            base_row = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(base_row >> 32)) << 32) |
+                       (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(base_row & 0xFFFFFFFFull));
+            if (act >= 0) {
+                const int pn = leaf_node[lane];
+                State leaf = unpack(pn == 0 ? root.state : load_state(&nodes[pn].state));
+                int kd, p, q2, ex;
+                index_to_code(leaf.phase, act, kd, p, q2, ex);
+                apply(leaf, kd, p, q2);
+                const Packed ps = pack(leaf);
+                const size_t slot = (size_t)lane * t.B + g;
+                const unsigned long long row = base_row + (unsigned long long)__popcll(need & ((1ull << lane) - 1ull));
+                w.leaf_state[slot] = ps;
+                w.eval_row[slot] = (int)row;
+                w.eval_state[row] = ps;
+            }
         }
     }
     for (int j = found + lane; j < w.K; j += kWave) w.leaf_kind[(size_t)j * t.B + g] = kLeafInactive;
@@ -705,11 +733,12 @@ __device__ __forceinline__ void tree_select_wave(const Tree& t, const WaveArrays
 
 __global__ __launch_bounds__(kBlock) void tree_select_wave_kernel(Tree t, WaveArrays w, int sims) {
     __shared__ Level s_stack[kWavesPerBlock][kWaveDepth];
+    __shared__ int s_leaf_node[kWavesPerBlock][32], s_leaf_act[kWavesPerBlock][32];
     const int g = wave_game();
     if (g >= t.B) return;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     __builtin_amdgcn_s_setprio(3);
-    tree_select_wave(t, w, g, lane_id(), load_root_info(t, g), sims, s_stack[wv]);
+    tree_select_wave(t, w, g, lane_id(), load_root_info(t, g), sims, s_stack[wv], s_leaf_node[wv], s_leaf_act[wv]);
 }
 
 __global__ __launch_bounds__(kBlock) void wave_budget_reset_kernel(WaveArrays w, int B, int reset_done) {
@@ -720,8 +749,8 @@ __global__ __launch_bounds__(kBlock) void wave_budget_reset_kernel(WaveArrays w,
 
 // The wave's leaves in the reference's order (src/mcts.py:427-497): first every terminal leaf and every leaf whose
 // position has no legal move is backed up (leaf order), then the evaluated leaves are expanded and backed up (leaf
-// order).  Each step is the single-leaf expand of variant P on the slot's view of the per-leaf arrays; a device fence
-// between two steps keeps their updates of the same edges in order.
+// order).  Each step is the single-leaf expand of variant P on the slot's view of the per-leaf arrays; a workgroup
+// fence (wait for the acknowledgements) between two steps keeps their updates of the same edges in order.
 __global__ __launch_bounds__(kBlock) void tree_expand_wave_kernel(Tree t, WaveArrays w, const float* __restrict__ lp1,
                                                                   const float* __restrict__ lp2,
                                                                   const float* __restrict__ lpm,
@@ -756,7 +785,7 @@ __global__ __launch_bounds__(kBlock) void tree_expand_wave_kernel(Tree t, WaveAr
             tree_expand<false>(slot_view(t, w, j), g, lane, lp1 ? lp1 + o * 36 : nullptr, lp2 ? lp2 + o * 36 : nullptr,
                                lpm ? lpm + o * 36 : nullptr, priors220 ? priors220 + o * 220 : nullptr, values + o,
                                nullptr, 0, 0.f);
-            __threadfence();
+            __threadfence_block();       // the next leaf's loads / atomics come after this leaf's stores / atomics
         }
     }
 }
