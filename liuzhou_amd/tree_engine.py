@@ -310,6 +310,7 @@ class PortableTreeMCTS:
         self.use_graph = bool(use_graph)
         self._graphs = {}
         self._tail_graph = None
+        self._tail_rounds = 0
         self._noise_buf = torch.zeros((self.engine.B, OUT_CAP), dtype=torch.float32, device=self.engine.device)
 
     def _search(self, add_noise: bool, continue_trees: bool) -> None:
@@ -345,13 +346,20 @@ class PortableTreeMCTS:
         if self.batch_k <= 1:
             return
         e = self.engine
+        while self.tail_step():
+            pass
+
+    def tail_step(self) -> bool:
+        """One host read of `unfinished` (waits for this engine's stream only) and, if some game still has budget, 8
+        more rounds replayed as one graph (the leftover rounds are a handful of games with tiny network batches).
+        Returns whether rounds were launched -- several engines on several streams take turns calling this."""
+        e = self.engine
+        if self.batch_k <= 1 or int(e.wbuf["unfinished"].item()) == 0 or self._tail_rounds >= 4096:
+            self._tail_rounds = 0
+            return False
         if not self.use_graph:
-            self.extra_rounds += e.finish_waves(self.net, self.sims)
-            return
-        # the leftover rounds are launch-bound (a handful of games, tiny network batches): replay them as a graph of
-        # 8 rounds per host read instead of 32 separate launches
-        rounds = 0
-        while int(e.wbuf["unfinished"].item()) > 0 and rounds < 4096:
+            e.search_waves(self.net, self.sims, 8, skip_roots=True)
+        else:
             if self._tail_graph is None:
                 torch.cuda.synchronize(e.device)
                 g = torch.cuda.CUDAGraph()
@@ -359,8 +367,9 @@ class PortableTreeMCTS:
                     e.search_waves(self.net, self.sims, 8, skip_roots=True)
                 self._tail_graph = g
             self._tail_graph.replay()
-            rounds += 8
-        self.extra_rounds += rounds
+        self._tail_rounds += 8
+        self.extra_rounds += 8
+        return True
 
     def reset_trees(self) -> None:
         """Forget the kept subtrees: the next search_batch starts every game from a fresh root."""
@@ -395,12 +404,14 @@ class PortableTreeMCTS:
         self._have_trees = True
 
     def complete_search(self, state: GpuStateBatch, *, temperatures: torch.Tensor,
-                        force_uniform_random_mask: Optional[torch.Tensor] = None) -> RootSearchBatchOutput:
-        """Second half: leftover waves (batch_k > 1, one host read), policy / pick extraction, output record."""
+                        force_uniform_random_mask: Optional[torch.Tensor] = None,
+                        tails_done: bool = False) -> RootSearchBatchOutput:
+        """Second half: leftover waves (batch_k > 1, host reads), policy / pick extraction, output record."""
         e = self.engine
         dev = e.device
         if self.batch_k > 1:
-            self._finish_waves()
+            if not tails_done:
+                self._finish_waves()
             self._root_evals += e.B                                   # wave evaluations are counted on the device
         else:
             self._root_evals += e.B * (self.sims + 1)
@@ -480,10 +491,19 @@ class DualStreamTreeMCTS:
             with torch.cuda.stream(st):
                 part.launch_search(sub, active=cut(active, a, b), add_dirichlet_noise=add_dirichlet_noise,
                                    reset=cut(reset, a, b), played_action=cut(played_action, a, b))
+        todo = list(zip(self.parts, streams))                  # leftover rounds (batch_k > 1): the parts take turns,
+        while todo:                                            # so that their small rounds overlap on the device
+            nxt = []
+            for part, st in todo:
+                with torch.cuda.stream(st):
+                    if part.tail_step():
+                        nxt.append((part, st))
+            todo = nxt
         for (a, b), part, st, sub in zip(self.bounds, self.parts, streams, subs):     # ... then the parts that may wait
             with torch.cuda.stream(st):
                 outs.append(part.complete_search(sub, temperatures=temperatures[a:b],
-                                                 force_uniform_random_mask=cut(force_uniform_random_mask, a, b)))
+                                                 force_uniform_random_mask=cut(force_uniform_random_mask, a, b),
+                                                 tails_done=True))
         if not self.serialize:
             for st in self.streams:
                 main.wait_stream(st)
@@ -552,7 +572,7 @@ def self_play_tree_gpu(model, num_games: int, mcts_simulations: int, temperature
     wave = max(1, min(int(concurrent_games), int(num_games)))
     # two half-batches on two streams (see DualStreamTreeMCTS) once a wave is large enough to fill the chip twice over
     if dual_stream is None:
-        dual_stream = net.pack.channels == 64 and wave >= 1024
+        dual_stream = net.pack.channels == 64 and wave >= 1024 and int(batch_k) <= 1   # waves: large launches already
     cls = DualStreamTreeMCTS if (dual_stream and net.pack.channels == 64 and wave >= 2) else PortableTreeMCTS
     mcts = cls(net, wave, mcts_simulations, dev, exploration_weight=exploration_weight,
                add_dirichlet_noise=add_dirichlet_noise, dirichlet_alpha=dirichlet_alpha,
