@@ -273,7 +273,7 @@ def self_play_tree(model, num_games: int, sims: int, temperature_init: float = 1
                    temperature_threshold: int = 10, c: float = 1.0, soft_k: float = 2.0, max_game_plies: int = 512,
                    concurrent_games: Optional[int] = None, reuse_tree: bool = True,
                    policy_target_temperature: Optional[float] = None, policy_target_prior_pseudocount: float = 0.0,
-                   time_budget_s: Optional[float] = None, collect: bool = False):
+                   time_budget_s: Optional[float] = None, collect: bool = False, batch_k: int = 1):
     """variant-P deterministic self-play (sample_moves=False, no noise): v1/python/portable_self_play.py:82-284.
     The reference keeps the played child's subtree on every move (`advance_root`, :191); `reuse_tree=False`
     rebuilds the tree instead.  Returns a stats dict (+ the 5 trajectory tensors when `collect`)."""
@@ -297,7 +297,10 @@ def self_play_tree(model, num_games: int, sims: int, temperature_init: float = 1
                 out_of_time = True
                 break
             act = [i for i in range(n) if not done[i]]
-            evals += tree_search_batch(evaluate, [trees[i] for i in act], sims)
+            if int(batch_k) > 1:                    # the legacy search's waves (src/mcts.py batch_K)
+                evals += tree_search_waves(evaluate, [trees[i] for i in act], sims, int(batch_k))
+            else:
+                evals += tree_search_batch(evaluate, [trees[i] for i in act], sims)
             for i in act:
                 t = trees[i]
                 if t.root_terminal():
