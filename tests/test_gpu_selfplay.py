@@ -263,3 +263,28 @@ def test_root_self_play_runner_continuous_waves_start_next_games_in_finished_slo
     torch.manual_seed(77)
     c, sc = self_play_v1_gpu(net, continuous_waves=False, **{**kw, "num_games": 64})
     assert sc.black_wins + sc.white_wins + sc.draws == 64 and not torch.isnan(c.value_targets).any()
+
+
+def test_tree_self_play_runner_with_legacy_waves():
+    """self_play_tree_gpu(batch_k=8): the legacy search's waves inside the product runner -- same tensor contract,
+    every game played to the ply cap, every search spends its full budget (root visits = sims)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from liuzhou_amd.net import ChessNet, MODEL_CONFIGS
+    from liuzhou_amd.net_hip import FusedNet
+    from liuzhou_amd.tree_engine import self_play_tree_gpu, PortableTreeMCTS
+    from liuzhou_amd.mcts_gpu import GpuStateBatch
+    torch.manual_seed(2)
+    net = FusedNet(ChessNet(**MODEL_CONFIGS["b6c64"]).eval().to("cuda:0"))
+    batch, stats = self_play_tree_gpu(net, num_games=70, mcts_simulations=20, temperature_init=1.0,
+                                      temperature_final=0.1, temperature_threshold=10, exploration_weight=1.0,
+                                      device="cuda:0", max_game_plies=26, concurrent_games=35, batch_k=8)
+    assert batch.num_samples == 70 * 26 == stats.num_positions
+    assert torch.allclose(batch.policy_targets.sum(1), torch.ones(batch.num_samples, device="cuda:0"), atol=1e-4)
+    assert bool((batch.policy_targets[~batch.legal_masks] == 0).all()) and bool(torch.isfinite(batch.value_targets).all())
+    assert stats.mcts_counters["leaf_eval_count"] > 70 * 26 * 15
+    # one search on the empty boards: every root ends with exactly `sims` visits over its children
+    mcts = PortableTreeMCTS(net, 64, 50, "cuda:0", add_dirichlet_noise=False, sample_moves=False, batch_k=16)
+    st = GpuStateBatch.initial(torch.device("cuda:0"), 64)
+    mcts.search_batch(st, temperatures=torch.ones(64, device="cuda:0"))
+    assert bool((mcts.engine.child_visits.sum(dim=1) == 50).all())
