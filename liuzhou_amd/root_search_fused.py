@@ -20,7 +20,8 @@ CAP = 72
 class FusedRootSearch:
     def __init__(self, net: FusedNet, num_games: int, num_simulations: int, device, exploration_weight: float = 1.0,
                  add_dirichlet_noise: bool = True, dirichlet_alpha: float = 0.3, dirichlet_epsilon: float = 0.25,
-                 sample_moves: bool = True, soft_value_k: float = 2.0, use_graph: bool = True) -> None:
+                 sample_moves: bool = True, soft_value_k: float = 2.0, use_graph: bool = True, out=None) -> None:
+        """`out`: optional dict of preallocated output tensors (rows of a larger batch: DualStreamRootSearch)."""
         dev = torch.device(device)
         if dev.type != "cuda":
             raise RuntimeError("FusedRootSearch needs a HIP device (no CPU path)")
@@ -30,15 +31,17 @@ class FusedRootSearch:
         self.use_graph = bool(use_graph) and os.environ.get("LZ_ROOT_GRAPH", "on").strip().lower() not in ("off", "0", "false")
         B = self.B
         z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)
+        out = out or {}
+        o = lambda name, shape, dt: out[name] if name in out else z(shape, dt)
         self.root_packed = z((B, 4), torch.int64)
         self.lp1, self.lp2, self.lpm = (z((B, 36), torch.float32) for _ in range(3))
-        self.values = z((B,), torch.float32)
+        self.values = o("values", (B,), torch.float32)
         self.legal_index = z((B, CAP), torch.int64)
         self.priors = z((B, CAP), torch.float32)
         self.codes = z((B, CAP, 4), torch.int32)
         self.valid = z((B, CAP), torch.uint8)
-        self.counts = z((B,), torch.int32)
-        self.terminal = z((B,), torch.uint8)
+        self.counts = o("counts", (B,), torch.int32)
+        self.terminal = o("terminal", (B,), torch.uint8)
         self.leaf = z((B, CAP), torch.float32)
         self.child_states = z((B * CAP, 4), torch.int64)
         self.child_ref = z((B * CAP,), torch.int32)
@@ -51,11 +54,11 @@ class FusedRootSearch:
         self.temps = z((B,), torch.float32)
         self.noise = z((B, CAP), torch.float32)
         self.uniforms = z((B,), torch.float32)
-        self.policy_dense = z((B, TOTAL_ACTION_DIM), torch.float32)
-        self.chosen_idx = z((B,), torch.int64)
-        self.chosen_codes = z((B, 4), torch.int32)
-        self.chosen_valid = z((B,), torch.uint8)
-        self.root_value_vec = z((B,), torch.float32)
+        self.policy_dense = o("policy_dense", (B, TOTAL_ACTION_DIM), torch.float32)
+        self.chosen_idx = o("chosen_idx", (B,), torch.int64)
+        self.chosen_codes = o("chosen_codes", (B, 4), torch.int32)
+        self.chosen_valid = o("chosen_valid", (B,), torch.uint8)
+        self.root_value_vec = o("root_value_vec", (B,), torch.float32)
         self._graphs = {}
         self._evals_dev = z((1,), torch.int64)              # network evaluations so far, kept on the device
 
@@ -84,8 +87,8 @@ class FusedRootSearch:
                                             p(self.chosen_valid), p(self.root_value_vec), st), "root_finalize")
 
     def search_batch(self, state: GpuStateBatch, *, temperatures: torch.Tensor, add_dirichlet_noise: Optional[bool] = None,
-                     injected_noise: Optional[torch.Tensor] = None, injected_uniforms: Optional[torch.Tensor] = None
-                     ) -> RootSearchBatchOutput:
+                     injected_noise: Optional[torch.Tensor] = None, injected_uniforms: Optional[torch.Tensor] = None,
+                     want_output: bool = True) -> Optional[RootSearchBatchOutput]:
         B, dev = self.B, self.device
         if int(state.batch_size) != B:
             raise ValueError(f"FusedRootSearch was built for {B} games, got {int(state.batch_size)}")
@@ -119,6 +122,8 @@ class FusedRootSearch:
                     self._graphs[key] = g
                 g.replay()
         self._evals_dev.add_(self.n_children).add_(B)
+        if not want_output:
+            return None
         has_root = self.counts > 0
         root_values = torch.where(has_root, self.root_value_vec, self.values)
         model_input = states_to_model_input(state)
@@ -136,3 +141,69 @@ class FusedRootSearch:
     def children_evaluated(self) -> int:
         """Number of child evaluations of the last search (host read: not for the hot loop)."""
         return int(self.n_children.item())
+
+
+
+class DualStreamRootSearch:
+    """Two FusedRootSearch halves on two HIP streams, same interface.  The kernels around the network launches (legal
+    sets and priors, the bandit, the policy extraction: ~30 % of a search at C2) are latency-bound and leave the
+    matrix pipes idle; with the games split in two halves they overlap the other half's network launches.  The halves
+    write rows of shared output tensors, so the result is the one FusedRootSearch gives over all games."""
+
+    def __init__(self, net: FusedNet, num_games: int, num_simulations: int, device, **kw) -> None:
+        dev = torch.device(device)
+        self.B, self.device = int(num_games), dev
+        B = self.B
+        h = (B + 1) // 2
+        self.bounds = ((0, h), (h, B))
+        z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)
+        self.out = {"values": z((B,), torch.float32), "counts": z((B,), torch.int32), "terminal": z((B,), torch.uint8),
+                    "policy_dense": z((B, TOTAL_ACTION_DIM), torch.float32), "chosen_idx": z((B,), torch.int64),
+                    "chosen_codes": z((B, 4), torch.int32), "chosen_valid": z((B,), torch.uint8),
+                    "root_value_vec": z((B,), torch.float32)}
+        self.parts = [FusedRootSearch(net, b - a, num_simulations, dev, out={k: v[a:b] for k, v in self.out.items()}, **kw)
+                      for a, b in self.bounds]
+        self.streams = tuple(torch.cuda.Stream(dev) for _ in self.parts)
+        self.serialize = False        # measurement aid: run the halves one after the other on the caller's stream
+
+    @property
+    def use_graph(self) -> bool:
+        return self.parts[0].use_graph
+
+    @use_graph.setter
+    def use_graph(self, v: bool) -> None:
+        for p in self.parts:
+            p.use_graph = bool(v)
+
+    @property
+    def leaf_evals(self) -> int:
+        return sum(p.leaf_evals for p in self.parts)
+
+    @property
+    def overflow(self) -> torch.Tensor:
+        return self.parts[0].overflow + self.parts[1].overflow
+
+    def search_batch(self, state: GpuStateBatch, *, temperatures: torch.Tensor, add_dirichlet_noise: Optional[bool] = None,
+                     injected_noise: Optional[torch.Tensor] = None, injected_uniforms: Optional[torch.Tensor] = None
+                     ) -> RootSearchBatchOutput:
+        if int(state.batch_size) != self.B:
+            raise ValueError(f"DualStreamRootSearch was built for {self.B} games, got {int(state.batch_size)}")
+        main = torch.cuda.current_stream(self.device)
+        cut = lambda t, a, b: None if t is None else t[a:b]
+        for (a, b), part, st in zip(self.bounds, self.parts, (main, main) if self.serialize else self.streams):
+            st.wait_stream(main)
+            with torch.cuda.stream(st):
+                part.search_batch(state._map(lambda t, a=a, b=b: t[a:b]), temperatures=temperatures[a:b],
+                                  add_dirichlet_noise=add_dirichlet_noise, injected_noise=cut(injected_noise, a, b),
+                                  injected_uniforms=cut(injected_uniforms, a, b), want_output=False)
+        if not self.serialize:
+            for st in self.streams:
+                main.wait_stream(st)
+        o = self.out
+        root_values = torch.where(o["counts"] > 0, o["root_value_vec"], o["values"])
+        model_input = states_to_model_input(state)
+        legal_mask, _ = encode_actions_fast(state)
+        return RootSearchBatchOutput(
+            model_input=model_input, legal_mask=legal_mask, policy_dense=o["policy_dense"], root_value=root_values,
+            terminal_mask=o["terminal"].view(torch.bool), chosen_action_indices=o["chosen_idx"],
+            chosen_action_codes=o["chosen_codes"], chosen_valid_mask=o["chosen_valid"].view(torch.bool))

@@ -17,7 +17,7 @@ class SteadyStateRootSelfPlay:
     def __init__(self, model, num_games: int, config: V1RootMCTSConfig, device, *, temperature_init: float = 1.0,
                  temperature_final: float = 0.1, temperature_threshold: int = 10, max_game_plies: int = 512,
                  arena_rows: Optional[int] = None, seed: int = 12345, fused_search: bool = True,
-                 device_tail: bool = True) -> None:
+                 device_tail: bool = True, dual_stream: Optional[bool] = None) -> None:
         self.dev = torch.device(device)
         self.B = int(num_games)
         self.cfg = config
@@ -25,8 +25,14 @@ class SteadyStateRootSelfPlay:
         # fixed population + fused network: the whole search as one captured, sync-free launch sequence
         self.fused = None
         if fused_search and hasattr(model, "desc") and config.child_eval_mode == "value_only" and int(config.sparse_ply) <= 1:
-            from .root_search_fused import FusedRootSearch
-            self.fused = FusedRootSearch(model, self.B, config.num_simulations, self.dev,
+            from .root_search_fused import DualStreamRootSearch, FusedRootSearch
+            # dual_stream: two halves on two streams, so that the bandit / prepare kernels of one half overlap the network
+            # launches of the other -- measured 4 % SLOWER than one stream at C2 (two graphs, twice the small launches), so
+            # it is off unless asked for
+            dual = False if dual_stream is None else bool(dual_stream)
+            self.dual_stream = bool(dual and self.B >= 2)
+            self.fused = (DualStreamRootSearch if self.dual_stream else FusedRootSearch)(
+                model, self.B, config.num_simulations, self.dev,
                                          exploration_weight=config.exploration_weight,
                                          add_dirichlet_noise=config.add_dirichlet_noise,
                                          dirichlet_alpha=config.dirichlet_alpha,

@@ -177,9 +177,12 @@ def test_steady_state_root_population_fused_equals_operator_chain():
     # [0] fused search + device tail (record / move / finalise / re-seat without the host), [1] operator chain + host
     # bookkeeping, [2] operator chain + device tail
     # ([2] starts with room for two plies only: the arena grows under the device cursor several times)
+    # ([3]: the fused search as two halves on two streams, DualStreamRootSearch)
     pops = [SteadyStateRootSelfPlay(net, 300, cfg, dev, seed=5, max_game_plies=40, fused_search=f, device_tail=t,
-                                    arena_rows=r)
-            for f, t, r in ((True, True, None), (False, False, None), (False, True, 600))]
+                                    arena_rows=r, dual_stream=d)
+            for f, t, r, d in ((True, True, None, False), (False, False, None, False), (False, True, 600, False),
+                               (True, True, None, True))]
+    assert pops[3].dual_stream and not pops[0].dual_stream
     assert pops[0].fused is not None and pops[1].fused is None
     assert pops[0].tail is not None and pops[1].tail is None and pops[2].tail is not None
     for p in pops:
@@ -197,7 +200,11 @@ def test_steady_state_root_population_fused_equals_operator_chain():
     assert torch.equal(torch.nan_to_num(a.soft_value_targets, nan=9.0), torch.nan_to_num(b.soft_value_targets, nan=9.0))
     assert pops[0].games_finished == pops[1].games_finished == pops[2].games_finished > 0
     assert torch.equal(pops[0].outcome, pops[1].outcome) and torch.equal(pops[2].outcome, pops[1].outcome)
-    for q in (pops[0], pops[2]):
+    d = pops[3].buffer.build()
+    assert torch.equal(d.state_tensors, b.state_tensors) and torch.equal(d.policy_targets, b.policy_targets)
+    assert torch.equal(torch.nan_to_num(d.value_targets, nan=9.0), torch.nan_to_num(b.value_targets, nan=9.0))
+    assert pops[3].games_finished == pops[1].games_finished and pops[3].leaf_evals == pops[1].leaf_evals
+    for q in (pops[0], pops[2], pops[3]):
         q.tail.check_overflow()
         for t in ("plies", "step_counts"):
             assert torch.equal(getattr(q, t), getattr(pops[1], t)), t
