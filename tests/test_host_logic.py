@@ -88,3 +88,28 @@ def test_v1_helper_truth_tables():
     aligned = V1RootMCTS._child_values_to_parent_perspective(torch.tensor([0.2, -0.5, 0.8, -0.1]), torch.tensor([1, 1, -1, -1]),
                                                              torch.tensor([1, -1, -1, 1]))
     assert torch.allclose(aligned, torch.tensor([0.2, 0.5, 0.8, 0.1]), atol=1e-6)
+
+
+def test_trajectory_buffer_device_cursor_bookkeeping():
+    """Host side of the device-side appends (wave_tail.WaveTail): the row cursor is a tensor the device advances;
+    the host tracks an upper bound, reads it back only for growth / host appends / build, and growth keeps the rows."""
+    import torch
+    from liuzhou_amd.trajectory_buffer import TensorTrajectoryBuffer
+    buf = TensorTrajectoryBuffer("cpu", 220, max_steps_hint=1, concurrent_games_hint=1, initial_capacity=8)
+    cur = buf.reserve_rows(3)
+    assert int(cur.item()) == 0 and buf.capacity == 8
+    st, lg, pol, val, soft, sign = buf.arena()
+    st[:3] = 1.0; pol[:3] = 0.5; lg[:3] = True; sign[:3] = 1; val[:3] = 0.25; soft[:3] = 0.5
+    cur.add_(3)                                            # what lz_wave_record does on the device
+    cur2 = buf.reserve_rows(3)                             # upper bound 6 <= 8: no read-back, same arena
+    assert cur2 is cur and buf.arena()[0] is st
+    cur.add_(2)                                            # only two of the three slots were live
+    buf.reserve_rows(4)                                    # upper bound 10 > 8 -> read back 5, 5 + 4 > 8 -> grow
+    assert buf.capacity >= 9 and buf.sync_cursor() == 5
+    assert bool((buf.arena()[0][:3] == 1.0).all())          # rows survived the growth
+    # a host-side append goes behind the device's rows and moves the cursor with it
+    rows = buf.append_steps(torch.zeros(2, 11, 6, 6), torch.zeros(2, 220, dtype=torch.bool), torch.zeros(2, 220),
+                            torch.tensor([1, -1]))
+    assert rows.tolist() == [5, 6] and int(cur.item()) == 7
+    out = buf.build()
+    assert out.num_samples == 7 and float(out.value_targets[0]) == 0.25
