@@ -98,6 +98,12 @@ class SteadyStateRootSelfPlay:
                 self._reset_slots(fin)
         self.step_counts.zero_()
 
+    def prepare(self) -> None:
+        """Kernel loading and graph capture before anything is timed (one search whose result is discarded)."""
+        temps = torch.ones((self.B,), dtype=torch.float32, device=self.dev)
+        (self.fused or self.mcts).search_batch(self.states, temperatures=temps)
+        torch.cuda.synchronize(self.dev)
+
     def step(self) -> None:
         temps = torch.where(self.plies < self.t_thr, self.t_init, self.t_final).to(torch.float32)
         search = (self.fused or self.mcts).search_batch(self.states, temperatures=temps)

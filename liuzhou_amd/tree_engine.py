@@ -375,6 +375,18 @@ class PortableTreeMCTS:
         """Forget the kept subtrees: the next search_batch starts every game from a fresh root."""
         self._have_trees = False
 
+    def prepare(self, state: GpuStateBatch) -> None:
+        """Set-up outside any timed region: load every kernel and capture the graphs (a fresh search, and a continued
+        one with subtree reuse) by searching `state` once or twice; the trees built here are thrown away."""
+        temps = torch.ones((self.engine.B,), dtype=torch.float32, device=self.engine.device)
+        for _ in range(2 if self.reuse_tree else 1):
+            self.search_batch(state, temperatures=temps)
+        self._have_trees = False
+        self._root_evals = 0
+        self.extra_rounds = 0
+        if self.batch_k > 1:
+            self.engine.wbuf["eval_total"].zero_(); self.engine.wbuf["eval_count"].zero_()
+
     def search_batch(self, state: GpuStateBatch, *, temperatures: torch.Tensor, active: Optional[torch.Tensor] = None,
                      add_dirichlet_noise: Optional[bool] = None, reset: Optional[torch.Tensor] = None,
                      played_action: Optional[torch.Tensor] = None,
@@ -464,6 +476,11 @@ class DualStreamTreeMCTS:
     def leaf_evals(self) -> int:
         return sum(p.leaf_evals for p in self.parts)
 
+    def prepare(self, state: GpuStateBatch) -> None:
+        for (a, b), part in zip(self.bounds, self.parts):
+            part.prepare(state._map(lambda t, a=a, b=b: t[a:b]))
+        torch.cuda.synchronize(self.device)
+
     @property
     def use_graph(self) -> bool:
         return self.parts[0].use_graph
@@ -546,6 +563,12 @@ class SteadyStateTreeSelfPlay:
 
     def preroll(self, n: int = 120) -> None:
         self.pop.preroll(n)
+
+    def prepare(self) -> None:
+        """Kernel loading and graph capture before anything is timed (the searches run here are discarded)."""
+        self.mcts.prepare(self.pop.states)
+        self.mcts.engine.reuse_dropped.zero_() if hasattr(self.mcts, "engine") else [p.engine.reuse_dropped.zero_() for p in self.mcts.parts]
+        torch.cuda.synchronize(self.dev)
 
     def step(self) -> None:
         p = self.pop
