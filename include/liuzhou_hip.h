@@ -292,6 +292,15 @@ typedef struct LzTreeDesc {
     const uint8_t* active;         /* [B] or NULL (all active) */
     int32_t* leaf_edge;            /* [B] edge the pending leaf hangs from (select -> expand hand-off) */
     int32_t* leaf_parent;          /* [B] node that owns that edge */
+    /* Optional per-simulation trace of what the expand step consumed (parity tests of the production launch path:
+     * lz_tree_search / lz_tree_search_continue under a hipGraph).  Slot 0 is the root step, slot s the s-th simulation;
+     * steps beyond trace_cap are not recorded.  All NULL / 0 in production. */
+    int32_t* trace_kind;           /* [trace_cap][B] leaf_kind the step saw */
+    void*    trace_leaf;           /* [trace_cap][B] packed state that was evaluated */
+    float*   trace_heads;          /* [trace_cap][B][108] log_p1 | log_p2 | log_pmc rows the step read (heads mode) */
+    float*   trace_priors;         /* [trace_cap][B][220] softmax over the legal set before noise / renormalisation */
+    float*   trace_value;          /* [trace_cap][B] evaluator value the step read */
+    int64_t  trace_cap;
 } LzTreeDesc;
 
 /* SoA batch -> packed records; packed records -> float32[B,11,6,6] model input (src/neural_network.py:15-65) */
@@ -364,6 +373,21 @@ LZ_API int lz_tree_finish(const LzTreeDesc* tree, const float* temperatures, con
 LZ_API int lz_tree_search(const LzTreeDesc* tree, const LzNetDesc* net, int64_t sims, float* planes /*[B,11,36]*/,
                           float* log_p1, float* log_p2, float* log_pmc, float* values, const float* noise,
                           int64_t noise_stride, float epsilon, void* stream);
+/* ---- per-game counter RNG -----------------------------------------------------------------------------------
+ * Replaces the library generators behind the reference's root noise and move sampling
+ * (torch.distributions.Gamma / torch.multinomial on the device generator, v1/python/mcts_gpu.py:1329-1339,1410-1424;
+ * torch Dirichlet in v1/python/portable_mcts.py:302-317; np.random.dirichlet in src/mcts.py:488-491), whose streams
+ * depend on slot and batch composition.  Philox4x32-10 keyed by `seed`, counter = (game id, ply, purpose, index):
+ * every variate is a pure function of those, so a game plays the same moves whichever slot / stream / rank runs it.
+ *   lz_rng_gamma:   out[g*stride + k] = Gamma(alpha, 1) draw k of game_id[g] at ply[g], k < count (Marsaglia-Tsang);
+ *                   normalised over a game's legal children these are Dirichlet(alpha) noise.
+ *   lz_rng_uniform: out[g] = uniform [0,1) for `purpose` (1 = move pick, 2 = opening move) of game_id[g] at ply[g].
+ * game_id NULL: g itself; ply NULL: 0. */
+LZ_API int lz_rng_gamma(uint64_t seed, const int64_t* game_id, const int64_t* ply, int64_t batch, float alpha,
+                        int64_t count, float* out, int64_t stride, void* stream);
+LZ_API int lz_rng_uniform(uint64_t seed, const int64_t* game_id, const int64_t* ply, int64_t batch, int purpose,
+                          float* out, void* stream);
+
 /* ---- fused root-PUCT search (variant R) on packed states -------------------------------------------------
  * The host chain of v1/python/mcts_gpu.py:1249-1457 (encode -> project -> root_pack -> noise -> apply -> evaluate
  * children -> perspective / terminal / soft value -> leaf matrix) as two fixed-shape kernels around the network

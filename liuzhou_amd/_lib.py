@@ -24,14 +24,65 @@ class LzStateSoA(C.Structure):
         "forced_removals_done", "move_count", "moves_since_capture")]
 
 
-SYMBOLS = (
-    "lz_version", "lz_status_string", "lz_encode_actions_fast", "lz_batch_apply_moves",
-    "lz_batch_apply_moves_inplace", "lz_states_to_model_input", "lz_project_policy_logits_fast",
-    "lz_root_pack_rows", "lz_root_puct_allocate_visits", "lz_root_finalize_from_visits",
-    "lz_self_play_step_inplace", "lz_finalize_trajectory_inplace", "lz_net_forward_f16", "lz_net_forward_packed_f16", "lz_net_configure",
-    "lz_pack_states", "lz_packed_to_model_input", "lz_tree_begin", "lz_tree_select", "lz_tree_expand",
-    "lz_tree_finish", "lz_tree_search", "lz_tree_advance", "lz_tree_search_continue", "lz_policy_value_loss_fwd_bwd", "lz_pack_trajectory_rows", "lz_unpack_trajectory_rows", "lz_prof_enable", "lz_prof_net_summary", "lz_prof_net_busy", "lz_net_forward_packed_counted_f16", "lz_root_prepare", "lz_root_collect", "lz_wave_record", "lz_wave_step_finish", "lz_wave_reseat", "lz_tree_wave_select", "lz_tree_wave_expand", "lz_tree_search_waves",
-)
+HEADER = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "liuzhou_hip.h")
+
+def _int_param(ctype, lo: int, hi: int):
+    """Argument converter for an integer parameter of exact C width: accepts Python ints and any ctypes integer
+    (call sites wrap sizes in c_int64 / c_int), rejects values the C type cannot hold instead of truncating them."""
+    class _P(ctype):
+        @classmethod
+        def from_param(cls, v):
+            v = int(getattr(v, "value", v))
+            if not lo <= v <= hi:
+                raise OverflowError(f"{v} does not fit {ctype.__name__}")
+            return ctype(v)
+    _P.__name__ = f"checked_{ctype.__name__}"
+    return _P
+
+
+def _float_param(ctype):
+    class _P(ctype):
+        @classmethod
+        def from_param(cls, v):
+            return ctype(float(getattr(v, "value", v)))
+    _P.__name__ = f"checked_{ctype.__name__}"
+    return _P
+
+
+_I32 = _int_param(C.c_int32, -(1 << 31), (1 << 31) - 1)
+_SCALARS = {"int": _I32, "int32_t": _I32, "int64_t": _int_param(C.c_int64, -(1 << 63), (1 << 63) - 1),
+            "uint64_t": _int_param(C.c_uint64, 0, (1 << 64) - 1), "uint32_t": _int_param(C.c_uint32, 0, (1 << 32) - 1),
+            "float": _float_param(C.c_float), "double": _float_param(C.c_double)}
+
+
+def _parse_header(path: str):
+    """`LZ_API <ret> name(args);` declarations of include/liuzhou_hip.h -> {name: (restype, [argtypes])}.  Every pointer
+    is a c_void_p (callers pass tensor addresses / byref(struct)); scalars keep their exact C width, so a Python int
+    of the wrong size is converted or rejected by ctypes instead of being silently truncated at the call."""
+    import re
+    text = open(path).read()
+    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+    text = re.sub(r"//[^\n]*", " ", text)
+    out = {}
+    for m in re.finditer(r"LZ_API\s+(const\s+char\s*\*|int)\s+(lz_\w+)\s*\(([^;]*?)\)\s*;", text, flags=re.S):
+        ret, name, args = m.group(1), m.group(2), " ".join(m.group(3).split())
+        types = []
+        if args and args != "void":
+            for a in args.split(","):
+                a = a.strip()
+                if "*" in a:
+                    types.append(C.c_void_p)
+                    continue
+                base = [t for t in a.replace("const", " ").split() if t in _SCALARS]
+                if not base:
+                    raise RuntimeError(f"liuzhou_hip.h: cannot map argument '{a}' of {name}")
+                types.append(_SCALARS[base[0]])
+        out[name] = (C.c_char_p if "char" in ret else C.c_int, types)
+    return out
+
+
+DECLS = _parse_header(HEADER)
+SYMBOLS = tuple(sorted(DECLS))
 
 
 def lib() -> C.CDLL:
@@ -43,9 +94,9 @@ def lib() -> C.CDLL:
                 f"liuzhou_amd: HIP extension {path} is missing. Build it with "
                 "`python -m liuzhou_amd.build` (hipcc --offload-arch=gfx950); there is no CPU fallback.")
         L = C.CDLL(path)
-        L.lz_version.restype = C.c_char_p
-        L.lz_status_string.restype = C.c_char_p
-        L.lz_status_string.argtypes = [C.c_int]
+        for name, (restype, argtypes) in DECLS.items():
+            fn = getattr(L, name)                          # AttributeError: header and library disagree
+            fn.restype, fn.argtypes = restype, argtypes
         _lib = L
     return _lib
 

@@ -20,6 +20,7 @@
 #include <math.h>
 #include <stdint.h>
 
+#include "lz_rng.h"
 #include "lz_soa.h"
 #include "lz_wave.h"
 
@@ -73,6 +74,9 @@ struct Tree {
     uint8_t* root_terminal; const uint8_t* active;
     int* leaf_edge; int* leaf_parent;      // edge / node the pending leaf hangs from (written by select)
     double c_puct;
+    // optional trace of what every expand step consumed (LzTreeDesc.trace_*; nullptr in production)
+    int* trace_kind; Packed* trace_leaf; float* trace_heads; float* trace_priors; float* trace_value;
+    int trace_cap;
 };
 
 // Edge / node records are read with plain (L1 + L2 cached, normal retention) 16-byte loads.  This is safe next to the
@@ -291,7 +295,7 @@ __device__ __forceinline__ void tree_expand(const Tree& t, int g, int lane, cons
                                             const float* __restrict__ lp2, const float* __restrict__ lpm,
                                             const float* __restrict__ priors220, const float* __restrict__ values,
                                             const float* __restrict__ noise, int noise_stride, float epsilon,
-                                            RootInfo* root_after = nullptr) {
+                                            RootInfo* root_after = nullptr, int step = -1) {
     const int kind = t.leaf_kind[g];
     Node* nodes = t.nodes + (size_t)g * t.node_cap;
     Edge* edges = t.edges + (size_t)g * t.edge_cap;
@@ -315,6 +319,13 @@ __device__ __forceinline__ void tree_expand(const Tree& t, int g, int lane, cons
     ne_ld = t.n_edges[g];
     value_ld = values[g];
     if (root_after != nullptr) *root_after = root;
+    // trace slot of this step (parity tests only; wave-uniform)
+    const bool tracing = t.trace_kind != nullptr && step >= 0 && step < t.trace_cap;
+    const size_t tslot = tracing ? (size_t)step * (size_t)t.B + (size_t)g : 0;
+    if (tracing) {
+        if (lane == 0) { t.trace_kind[tslot] = kind; t.trace_leaf[tslot] = leaf_packed; t.trace_value[tslot] = value_ld; }
+        for (int a = lane; a < 220; a += kWave) t.trace_priors[tslot * 220 + a] = 0.f;
+    }
     if (kind == kLeafInactive) return;
     if (kind == kLeafReusedRoot) {
         // portable_mcts.py:302-317 / :617-621: a root kept by advance_root gets a fresh noise mix on its
@@ -370,6 +381,10 @@ __device__ __forceinline__ void tree_expand(const Tree& t, int g, int lane, cons
             const bool heads = priors220 == nullptr;
             if (heads && lane < kCells) {
                 h1 = lp1[(size_t)g * 36 + lane]; h2 = lp2[(size_t)g * 36 + lane]; hm = lpm[(size_t)g * 36 + lane];
+                if (tracing) {
+                    float* th = t.trace_heads + tslot * 108;
+                    th[lane] = h1; th[36 + lane] = h2; th[72 + lane] = hm;
+                }
             }
             // Phase A, per 64 action indices (skipped when none of them is legal): legality, compact slot, logit.
             // The legal actions are then compacted through LDS so that Phase B (child state, terminal test, edge
@@ -412,6 +427,11 @@ __device__ __forceinline__ void tree_expand(const Tree& t, int g, int lane, cons
                 sum = lzw::wave_sum(sum);
 #pragma unroll
                 for (int it = 0; it < 4; ++it) val[it] = val[it] / sum;
+            }
+            if (tracing) {
+#pragma unroll
+                for (int it = 0; it < 4; ++it)
+                    if (lg[it]) t.trace_priors[tslot * 220 + it * kWave + lane] = val[it];
             }
             // root noise mix (portable_mcts.py:451-459)
             if (IS_ROOT && noise != nullptr && n > 1) {
@@ -522,10 +542,10 @@ __global__ __launch_bounds__(kBlock) void tree_expand_kernel(Tree t, const float
                                                              const float* __restrict__ priors220,
                                                              const float* __restrict__ values,
                                                              const float* __restrict__ noise, int noise_stride,
-                                                             float epsilon) {
+                                                             float epsilon, int step) {
     const int g = wave_game();
     if (g >= t.B) return;
-    tree_expand<IS_ROOT>(t, g, lane_id(), lp1, lp2, lpm, priors220, values, noise, noise_stride, epsilon);
+    tree_expand<IS_ROOT>(t, g, lane_id(), lp1, lp2, lpm, priors220, values, noise, noise_stride, epsilon, nullptr, step);
 }
 
 // expand + backup of simulation s fused with the selection of simulation s+1 (same wave, same game: the edge
@@ -536,7 +556,7 @@ __global__ __launch_bounds__(kBlock) void tree_expand_select_kernel(Tree t, cons
                                                                     const float* __restrict__ lpm,
                                                                     const float* __restrict__ values,
                                                                     const float* __restrict__ noise, int noise_stride,
-                                                                    float epsilon) {
+                                                                    float epsilon, int step) {
 #ifndef LZ_EXP_NO_TREE_PRIO
     // The kernel is a chain of dependent loads with a few dozen instructions in between; in the two-stream search it
     // shares the SIMDs with the other half's network waves, which always have MFMAs to issue.  Raised wave priority
@@ -547,7 +567,7 @@ __global__ __launch_bounds__(kBlock) void tree_expand_select_kernel(Tree t, cons
     if (g >= t.B) return;
     const int lane = lane_id();
     RootInfo root;
-    tree_expand<IS_ROOT>(t, g, lane, lp1, lp2, lpm, nullptr, values, noise, noise_stride, epsilon, &root);
+    tree_expand<IS_ROOT>(t, g, lane, lp1, lp2, lpm, nullptr, values, noise, noise_stride, epsilon, &root, step);
     __threadfence_block();
     if (IS_ROOT) root = load_root_info(t, g);                  // the root record itself was just written
     tree_select(t, g, lane, root);
@@ -1238,6 +1258,24 @@ __global__ __launch_bounds__(kBlock) void root_collect_kernel(const Packed* __re
     }
 }
 
+// ---- per-game counter RNG (lz_rng.h): root noise Gammas and pick uniforms as pure functions of (seed, game, ply) ----
+__global__ __launch_bounds__(kBlock) void rng_gamma_kernel(uint64_t seed, const int64_t* __restrict__ game,
+                                                           const int64_t* __restrict__ ply, int64_t B, float alpha,
+                                                           int count, float* __restrict__ out, int stride) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t g = i / count;
+    const int k = (int)(i - g * count);
+    if (g >= B) return;
+    out[g * stride + k] = lzrng::gamma_draw(seed, game ? game[g] : g, ply ? ply[g] : 0, (uint32_t)k, alpha);
+}
+__global__ __launch_bounds__(kBlock) void rng_uniform_kernel(uint64_t seed, const int64_t* __restrict__ game,
+                                                             const int64_t* __restrict__ ply, int64_t B, int purpose,
+                                                             float* __restrict__ out) {
+    const int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (g >= B) return;
+    out[g] = lzrng::uniform_draw(seed, game ? game[g] : g, ply ? ply[g] : 0, (uint32_t)purpose);
+}
+
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 inline int st() { return hipGetLastError() == hipSuccess ? LZ_OK : LZ_ERR_LAUNCH; }
 
@@ -1254,6 +1292,13 @@ Tree make_tree(const LzTreeDesc* d) {
     t.root_terminal = d->root_terminal; t.active = d->active;
     t.leaf_edge = d->leaf_edge; t.leaf_parent = d->leaf_parent;
     t.c_puct = d->exploration_weight;
+    const bool tr = d->trace_cap > 0 && d->trace_kind && d->trace_leaf && d->trace_heads && d->trace_priors && d->trace_value;
+    t.trace_kind = tr ? d->trace_kind : nullptr;
+    t.trace_leaf = tr ? reinterpret_cast<Packed*>(d->trace_leaf) : nullptr;
+    t.trace_heads = tr ? d->trace_heads : nullptr;
+    t.trace_priors = tr ? d->trace_priors : nullptr;
+    t.trace_value = tr ? d->trace_value : nullptr;
+    t.trace_cap = tr ? (int)d->trace_cap : 0;
     return t;
 }
 bool tree_ok(const LzTreeDesc* d) {
@@ -1330,10 +1375,10 @@ int lz_tree_expand(const LzTreeDesc* d, int is_root, const float* lp1, const flo
     const Tree t = make_tree(d);
     if (is_root)
         hipLaunchKernelGGL(tree_expand_kernel<true>, dim3(gw(t.B)), dim3(kBlock), 0, as_stream(stream), t, lp1, lp2,
-                           lpmc, priors220, values, noise, (int)noise_stride, epsilon);
+                           lpmc, priors220, values, noise, (int)noise_stride, epsilon, -1);
     else
         hipLaunchKernelGGL(tree_expand_kernel<false>, dim3(gw(t.B)), dim3(kBlock), 0, as_stream(stream), t, lp1, lp2,
-                           lpmc, priors220, values, nullptr, 0, 0.f);
+                           lpmc, priors220, values, nullptr, 0, 0.f, -1);
     return st();
 }
 
@@ -1384,15 +1429,18 @@ static int tree_search_impl(const LzTreeDesc* d, const LzNetDesc* net, int64_t s
         rc = lz_net_forward_packed_f16(net, d->leaf_state, B, lp1, lp2, lpmc, nullptr, values, stream);
         if (rc) return rc;
         if (s == sims) {   // last simulation: nothing left to select
-            rc = lz_tree_expand(d, s == 0 ? 1 : 0, lp1, lp2, lpmc, nullptr, values, s == 0 ? noise : nullptr,
-                                noise_stride, epsilon, stream);
-            if (rc) return rc;
+            if (s == 0)
+                hipLaunchKernelGGL(tree_expand_kernel<true>, dim3(gw(t.B)), dim3(kBlock), 0, as_stream(stream), t, lp1, lp2,
+                                   lpmc, (const float*)nullptr, values, noise, (int)noise_stride, epsilon, (int)s);
+            else
+                hipLaunchKernelGGL(tree_expand_kernel<false>, dim3(gw(t.B)), dim3(kBlock), 0, as_stream(stream), t, lp1, lp2,
+                                   lpmc, (const float*)nullptr, values, (const float*)nullptr, 0, 0.f, (int)s);
         } else if (s == 0) {
             hipLaunchKernelGGL(tree_expand_select_kernel<true>, dim3(gw(t.B)), dim3(kBlock), 0, as_stream(stream), t, lp1,
-                               lp2, lpmc, values, noise, (int)noise_stride, epsilon);
+                               lp2, lpmc, values, noise, (int)noise_stride, epsilon, (int)s);
         } else {
             hipLaunchKernelGGL(tree_expand_select_kernel<false>, dim3(gw(t.B)), dim3(kBlock), 0, as_stream(stream), t, lp1,
-                               lp2, lpmc, values, nullptr, 0, 0.f);
+                               lp2, lpmc, values, nullptr, 0, 0.f, (int)s);
         }
     }
     return st();
@@ -1443,6 +1491,26 @@ int lz_tree_search_continue(const LzTreeDesc* d, const LzNetDesc* net, int64_t s
                             float* lp2, float* lpmc, float* values, const float* noise, int64_t noise_stride,
                             float epsilon, void* stream) {
     return tree_search_impl(d, net, sims, planes, lp1, lp2, lpmc, values, noise, noise_stride, epsilon, true, stream);
+}
+
+int lz_rng_gamma(uint64_t seed, const int64_t* game_id, const int64_t* ply, int64_t B, float alpha, int64_t count,
+                 float* out, int64_t stride, void* stream) {
+    if (B < 0 || count < 0 || count > 1024 || stride < count || !(alpha > 0.f)) return LZ_ERR_ARG;
+    if (B == 0 || count == 0) return LZ_OK;
+    if (!out) return LZ_ERR_ARG;
+    hipLaunchKernelGGL(rng_gamma_kernel, dim3(gt(B * count)), dim3(kBlock), 0, as_stream(stream), seed, game_id, ply, B,
+                       alpha, (int)count, out, (int)stride);
+    return st();
+}
+
+int lz_rng_uniform(uint64_t seed, const int64_t* game_id, const int64_t* ply, int64_t B, int purpose, float* out,
+                   void* stream) {
+    if (B < 0 || purpose < 0 || purpose > 3) return LZ_ERR_ARG;
+    if (B == 0) return LZ_OK;
+    if (!out) return LZ_ERR_ARG;
+    hipLaunchKernelGGL(rng_uniform_kernel, dim3(gt(B)), dim3(kBlock), 0, as_stream(stream), seed, game_id, ply, B, purpose,
+                       out);
+    return st();
 }
 
 int lz_tree_wave_select(const LzTreeDesc* d, const LzTreeWaveDesc* w, int64_t sims, int reset_budget, void* stream) {

@@ -35,21 +35,36 @@ def worker_seed(iteration_seed: int, worker_idx: int) -> int:
 
 def _gather_compact(batch: TensorSelfPlayBatch, dst: int, group) -> Optional[TensorSelfPlayBatch]:
     """HIP path: rows travel as exact 360-byte records (trajectory_codec.py), 7.5x less xGMI traffic than the five
-    tensors, packed / unpacked by one kernel each side."""
+    tensors, packed / unpacked by one kernel each side.  The row count and the number of rows the record format cannot
+    hold travel together in the one all-gather that precedes the transfers, so a bad row on any rank makes EVERY rank
+    raise before a single send / receive is posted (no rank is left waiting in a collective)."""
     from .trajectory_codec import RECORD_BYTES, pack_batch, unpack_records
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     dev = batch.state_tensors.device
-    n_local = torch.tensor([batch.num_samples], dtype=torch.int64, device=dev)
-    counts = [torch.zeros_like(n_local) for _ in range(world)]
-    dist.all_gather(counts, n_local, group=group)
-    counts = [int(c.item()) for c in counts]
-    rec = pack_batch(batch)
+    rec, bad = pack_batch(batch, return_bad=True)
+    mine = torch.stack([torch.tensor(batch.num_samples, dtype=torch.int64, device=dev), bad.to(torch.int64).view(())])
+    if dist.get_backend(group) != "nccl":
+        mine = mine.cpu()
+    every = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(every, mine, group=group)
+    every = torch.stack(every).cpu()
+    counts = [int(c) for c in every[:, 0]]
+    n_bad = [int(b) for b in every[:, 1]]
+    if any(n_bad):
+        raise RuntimeError(f"gather_trajectories: rows not representable as compact records on ranks "
+                           f"{[r for r, b in enumerate(n_bad) if b]} (counts {n_bad}): planes not 0/1, policy mass off "
+                           "the legal set, or more than 72 legal actions; every rank raises, nothing was sent")
+    # RCCL moves device memory directly (peer writes over xGMI); any other backend (gloo in the tests) stages the
+    # records through host memory -- same protocol, same kernels on both sides
+    direct = dist.get_backend(group) == "nccl"
+    wire_dev = dev if direct else torch.device("cpu")
     if rank != dst:
         if counts[rank] > 0:
-            for req in dist.batch_isend_irecv([dist.P2POp(dist.isend, rec, dst, group)]):
+            out = rec if direct else rec.cpu()
+            for req in dist.batch_isend_irecv([dist.P2POp(dist.isend, out, dst, group)]):
                 req.wait()
         return None
-    buf = torch.empty((sum(counts), RECORD_BYTES), dtype=torch.uint8, device=dev)
+    buf = torch.empty((sum(counts), RECORD_BYTES), dtype=torch.uint8, device=wire_dev)
     ops, start = [], 0
     for r in range(world):
         if r == dst:
@@ -60,6 +75,7 @@ def _gather_compact(batch: TensorSelfPlayBatch, dst: int, group) -> Optional[Ten
     if ops:
         for req in dist.batch_isend_irecv(ops):
             req.wait()
+    buf = buf.to(dev)
     return unpack_records(buf)
 
 
@@ -116,8 +132,19 @@ def gather_trajectories(batch: TensorSelfPlayBatch, dst: int = 0, group=None,
 
 
 def broadcast_checkpoint(model: torch.nn.Module, src: int = 0, group=None) -> None:
-    """Rank `src`'s parameters and buffers -> every rank (checkpoint hand-off each iteration)."""
+    """Rank `src`'s parameters and buffers -> every rank (checkpoint hand-off each iteration, v1/train.py:978 hands a
+    `model_state_cpu.pt` file to the workers).  One flat buffer per dtype (fp32 weights + the int64 BatchNorm counters:
+    12 MB for 10x128 in two collectives) instead of one tiny broadcast per tensor."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return
+    by_dtype: Dict[torch.dtype, List[torch.Tensor]] = {}
     for t in list(model.parameters()) + list(model.buffers()):
-        dist.broadcast(t.data, src=src, group=group)
+        by_dtype.setdefault(t.dtype, []).append(t.data)
+    for _dt, ts in sorted(by_dtype.items(), key=lambda kv: str(kv[0])):
+        flat = torch.cat([t.reshape(-1) for t in ts])
+        dist.broadcast(flat, src=src, group=group)
+        off = 0
+        for t in ts:
+            n = t.numel()
+            t.copy_(flat[off:off + n].view_as(t))
+            off += n

@@ -11,6 +11,7 @@ from typing import Optional
 import torch
 
 from . import _lib as L
+from .game_rng import GameRng, PURPOSE_PICK
 from .mcts_gpu import GpuStateBatch, RootSearchBatchOutput, TOTAL_ACTION_DIM, encode_actions_fast, states_to_model_input
 from .net_hip import FusedNet
 
@@ -20,8 +21,11 @@ CAP = 72
 class FusedRootSearch:
     def __init__(self, net: FusedNet, num_games: int, num_simulations: int, device, exploration_weight: float = 1.0,
                  add_dirichlet_noise: bool = True, dirichlet_alpha: float = 0.3, dirichlet_epsilon: float = 0.25,
-                 sample_moves: bool = True, soft_value_k: float = 2.0, use_graph: bool = True, out=None) -> None:
-        """`out`: optional dict of preallocated output tensors (rows of a larger batch: DualStreamRootSearch)."""
+                 sample_moves: bool = True, soft_value_k: float = 2.0, use_graph: bool = True, out=None,
+                 seed: int = 12345, game_offset: int = 0, game_stride: Optional[int] = None) -> None:
+        """`out`: optional dict of preallocated output tensors (rows of a larger batch: DualStreamRootSearch).
+        `seed` / `game_offset` / `game_stride`: keys of the per-game counter RNG (game_rng.GameRng) that replaces the
+        reference's draws from the device generator (v1/python/mcts_gpu.py:1329-1339,1410-1424)."""
         dev = torch.device(device)
         if dev.type != "cuda":
             raise RuntimeError("FusedRootSearch needs a HIP device (no CPU path)")
@@ -54,6 +58,7 @@ class FusedRootSearch:
         self.temps = z((B,), torch.float32)
         self.noise = z((B, CAP), torch.float32)
         self.uniforms = z((B,), torch.float32)
+        self.rng = GameRng(B, dev, seed=seed, game_offset=game_offset, game_stride=game_stride)
         self.policy_dense = o("policy_dense", (B, TOTAL_ACTION_DIM), torch.float32)
         self.chosen_idx = o("chosen_idx", (B,), torch.int64)
         self.chosen_codes = o("chosen_codes", (B, 4), torch.int32)
@@ -88,7 +93,11 @@ class FusedRootSearch:
 
     def search_batch(self, state: GpuStateBatch, *, temperatures: torch.Tensor, add_dirichlet_noise: Optional[bool] = None,
                      injected_noise: Optional[torch.Tensor] = None, injected_uniforms: Optional[torch.Tensor] = None,
-                     want_output: bool = True) -> Optional[RootSearchBatchOutput]:
+                     want_output: bool = True, reset: Optional[torch.Tensor] = None,
+                     rng_game_ids: Optional[torch.Tensor] = None,
+                     rng_plies: Optional[torch.Tensor] = None) -> Optional[RootSearchBatchOutput]:
+        """`reset` uint8[B]: slots whose game was re-seated since the last search (their RNG key moves on to the next
+        game id); `rng_game_ids` / `rng_plies`: the runner's own numbering instead."""
         B, dev = self.B, self.device
         if int(state.batch_size) != B:
             raise ValueError(f"FusedRootSearch was built for {B} games, got {int(state.batch_size)}")
@@ -97,16 +106,20 @@ class FusedRootSearch:
         with torch.cuda.device(dev):
             L.check(L.lib().lz_pack_states(C.byref(L.soa(ts)), L.i64(B), L.ptr(self.root_packed), L.stream_ptr(dev)), "pack_states")
         self.temps.copy_(temperatures.to(torch.float32).reshape(-1))
+        self.rng.begin_move(reset, rng_game_ids, rng_plies)
         if add_noise:
             if injected_noise is not None:
                 self.noise.zero_()
                 self.noise[:, : injected_noise.shape[1]].copy_(injected_noise.to(torch.float32))
             else:
-                self.noise.copy_(torch._standard_gamma(torch.full((B, CAP), self.alpha, dtype=torch.float32, device=dev)))
+                self.rng.gamma_into(self.noise, self.alpha, CAP)
         sample = self.sample_moves
         if sample:
-            self.uniforms.copy_(injected_uniforms.to(torch.float32) if injected_uniforms is not None
-                                else torch.rand((B,), dtype=torch.float32, device=dev))
+            if injected_uniforms is not None:
+                self.uniforms.copy_(injected_uniforms.to(torch.float32))
+            else:
+                self.rng.uniform_into(self.uniforms, PURPOSE_PICK)
+        self.rng.end_move(rng_plies is not None)
         key = (add_noise, sample)
         with torch.cuda.device(dev):
             if not self.use_graph:
@@ -161,7 +174,9 @@ class DualStreamRootSearch:
                     "policy_dense": z((B, TOTAL_ACTION_DIM), torch.float32), "chosen_idx": z((B,), torch.int64),
                     "chosen_codes": z((B, 4), torch.int32), "chosen_valid": z((B,), torch.uint8),
                     "root_value_vec": z((B,), torch.float32)}
-        self.parts = [FusedRootSearch(net, b - a, num_simulations, dev, out={k: v[a:b] for k, v in self.out.items()}, **kw)
+        kw.pop("game_offset", None); kw.pop("game_stride", None)
+        self.parts = [FusedRootSearch(net, b - a, num_simulations, dev, out={k: v[a:b] for k, v in self.out.items()},
+                                      game_offset=a, game_stride=B, **kw)
                       for a, b in self.bounds]
         self.streams = tuple(torch.cuda.Stream(dev) for _ in self.parts)
         self.serialize = False        # measurement aid: run the halves one after the other on the caller's stream
@@ -184,8 +199,9 @@ class DualStreamRootSearch:
         return self.parts[0].overflow + self.parts[1].overflow
 
     def search_batch(self, state: GpuStateBatch, *, temperatures: torch.Tensor, add_dirichlet_noise: Optional[bool] = None,
-                     injected_noise: Optional[torch.Tensor] = None, injected_uniforms: Optional[torch.Tensor] = None
-                     ) -> RootSearchBatchOutput:
+                     injected_noise: Optional[torch.Tensor] = None, injected_uniforms: Optional[torch.Tensor] = None,
+                     reset: Optional[torch.Tensor] = None, rng_game_ids: Optional[torch.Tensor] = None,
+                     rng_plies: Optional[torch.Tensor] = None) -> RootSearchBatchOutput:
         if int(state.batch_size) != self.B:
             raise ValueError(f"DualStreamRootSearch was built for {self.B} games, got {int(state.batch_size)}")
         main = torch.cuda.current_stream(self.device)
@@ -195,7 +211,9 @@ class DualStreamRootSearch:
             with torch.cuda.stream(st):
                 part.search_batch(state._map(lambda t, a=a, b=b: t[a:b]), temperatures=temperatures[a:b],
                                   add_dirichlet_noise=add_dirichlet_noise, injected_noise=cut(injected_noise, a, b),
-                                  injected_uniforms=cut(injected_uniforms, a, b), want_output=False)
+                                  injected_uniforms=cut(injected_uniforms, a, b), want_output=False,
+                                  reset=cut(reset, a, b), rng_game_ids=cut(rng_game_ids, a, b),
+                                  rng_plies=cut(rng_plies, a, b))
         if not self.serialize:
             for st in self.streams:
                 main.wait_stream(st)

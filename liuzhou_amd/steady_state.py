@@ -37,7 +37,7 @@ class SteadyStateRootSelfPlay:
                                          add_dirichlet_noise=config.add_dirichlet_noise,
                                          dirichlet_alpha=config.dirichlet_alpha,
                                          dirichlet_epsilon=config.dirichlet_epsilon, sample_moves=config.sample_moves,
-                                         soft_value_k=config.soft_value_k)
+                                         soft_value_k=config.soft_value_k, seed=int(seed))
         self.t_init, self.t_final, self.t_thr = float(temperature_init), float(temperature_final), int(temperature_threshold)
         self.max_plies = int(max_game_plies)
         self.states = GpuStateBatch.initial(self.dev, self.B)
@@ -51,6 +51,7 @@ class SteadyStateRootSelfPlay:
         self.gen = torch.Generator(device=self.dev)
         self.gen.manual_seed(int(seed))
         self._games_finished = 0
+        self._reseated = torch.zeros((self.B,), dtype=torch.uint8, device=self.dev)   # slots re-seated by the last step
         self.positions = 0
         # device_tail: record / move / finalise / re-seat on the device (wave_tail.WaveTail), no host round trip per step
         self.tail = None
@@ -106,7 +107,12 @@ class SteadyStateRootSelfPlay:
 
     def step(self) -> None:
         temps = torch.where(self.plies < self.t_thr, self.t_init, self.t_final).to(torch.float32)
-        search = (self.fused or self.mcts).search_batch(self.states, temperatures=temps)
+        if self.fused is not None:       # per-game RNG keys: the slot's game generation and the game's ply
+            search = self.fused.search_batch(self.states, temperatures=temps, reset=self._reseated, rng_plies=self.plies)
+            self._reseated.zero_()
+            self.finish_step(search, reseated=self._reseated)
+            return
+        search = self.mcts.search_batch(self.states, temperatures=temps)
         self.finish_step(search)
 
     def finish_step(self, search, reseated: Optional[torch.Tensor] = None) -> None:

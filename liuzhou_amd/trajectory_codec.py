@@ -11,8 +11,10 @@ from .trajectory_buffer import TensorSelfPlayBatch
 RECORD_BYTES = 360
 
 
-def pack_batch(batch: TensorSelfPlayBatch) -> torch.Tensor:
-    """TensorSelfPlayBatch on a HIP device -> uint8[n, 360]."""
+def pack_batch(batch: TensorSelfPlayBatch, return_bad: bool = False):
+    """TensorSelfPlayBatch on a HIP device -> uint8[n, 360].  `return_bad`: do not read the count of non-representable
+    rows back (no host synchronisation, nothing raised here) but return it as a device int32[1] next to the records,
+    for callers that must decide collectively (distributed._gather_compact)."""
     L.require_hip(batch.state_tensors, "pack_trajectory_rows")
     dev = batch.state_tensors.device
     n = int(batch.num_samples)
@@ -27,6 +29,8 @@ def pack_batch(batch: TensorSelfPlayBatch) -> torch.Tensor:
     with torch.cuda.device(dev):
         L.check(L.lib().lz_pack_trajectory_rows(L.ptr(planes), L.ptr(legal), L.ptr(pol), L.ptr(val), L.ptr(soft), L.i64(n),
                                                 L.ptr(out), L.ptr(bad), L.stream_ptr(dev)), "pack_trajectory_rows")
+    if return_bad:
+        return out, bad
     if n and int(bad.item()) != 0:
         raise RuntimeError(f"{int(bad.item())} trajectory rows are not representable as compact records "
                            "(planes not 0/1, policy mass off the legal set, or more than 72 legal actions)")

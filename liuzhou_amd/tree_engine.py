@@ -18,8 +18,11 @@ from typing import Dict, Optional, Tuple
 
 import torch
 
+from contextlib import contextmanager
+
 from . import _lib as L
 from . import v0_core
+from .game_rng import GameRng, PURPOSE_PICK
 from .mcts_gpu import GpuStateBatch, RootSearchBatchOutput, TOTAL_ACTION_DIM, states_to_model_input, \
     encode_actions_fast
 from .net_hip import FusedNet, LzNetDesc
@@ -36,7 +39,9 @@ class LzTreeDesc(C.Structure):
                [(n, C.c_void_p) for n in (
                    "root_state", "nodes", "edges", "n_nodes", "n_edges", "root_visits", "root_w",
                    "root_init_value", "path", "path_len", "leaf_kind", "leaf_state", "leaf_value", "root_terminal",
-                   "active", "leaf_edge", "leaf_parent")]
+                   "active", "leaf_edge", "leaf_parent",
+                   "trace_kind", "trace_leaf", "trace_heads", "trace_priors", "trace_value")] + \
+               [("trace_cap", C.c_int64)]
 
 
 class LzTreeWaveDesc(C.Structure):
@@ -139,6 +144,21 @@ class TreeEngine:
         self.child_visits = z((B, OUT_CAP), torch.int32)
         self.child_prior = z((B, OUT_CAP), torch.float32)
         self.reuse_dropped = z((1,), torch.int32)
+
+    def enable_trace(self, steps: Optional[int] = None) -> Dict[str, torch.Tensor]:
+        """Parity tests: record, per step of a search (slot 0 = root step, slot s = s-th simulation), what the expand
+        kernel consumed -- leaf kind / state, head rows, the softmax over the legal set, the value (LzTreeDesc.trace_*).
+        Must be called before the search is captured into a graph (kernel arguments are frozen at capture)."""
+        n = (self.max_sims + 1) if steps is None else int(steps)
+        B, dev = self.B, self.device
+        z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)
+        self.trace = {"trace_kind": z((n, B), torch.int32), "trace_leaf": z((n, B, 4), torch.int64),
+                      "trace_heads": z((n, B, 108), torch.float32), "trace_priors": z((n, B, 220), torch.float32),
+                      "trace_value": z((n, B), torch.float32)}
+        for name, t in self.trace.items():
+            setattr(self.desc, name, t.data_ptr())
+        self.desc.trace_cap = n
+        return self.trace
 
     def hbm_bytes(self) -> int:
         return sum(t.numel() * t.element_size() for t in self.buf.values())
@@ -284,19 +304,43 @@ class PortableTreeMCTS:
                  add_dirichlet_noise: bool = True, dirichlet_alpha: float = 0.3, dirichlet_epsilon: float = 0.25,
                  sample_moves: bool = True, use_graph: Optional[bool] = None, reuse_tree: bool = False,
                  reuse_factor: float = -1.0, policy_target_temperature: Optional[float] = None,
-                 policy_target_prior_pseudocount: float = 0.0, batch_k: int = 1) -> None:
-        """`batch_k` > 1: the legacy search's waves (src/mcts.py `batch_K`, default 16 there): up to batch_k distinct
+                 policy_target_prior_pseudocount: float = 0.0, batch_k: int = 1, seed: int = 12345,
+                 game_offset: int = 0, game_stride: Optional[int] = None, trace: bool = False,
+                 collect_timing: bool = False) -> None:
+        """`net`: a FusedNet (the production path: the whole search of a move is enqueued from C++ with the fused network
+        kernel in the loop, one hipGraph per move), or any module returning `ChessNet.forward`'s 4-tuple -- then the search
+        runs the split-phase protocol (select -> planes -> module -> expand) with that module as an external fp32
+        evaluator, on its own device (the reference's `PortableMCTS` with an arbitrary model, portable_mcts.py:381-386).
+        `seed` / `game_offset` / `game_stride`: keys of the per-game counter RNG (game_rng.GameRng) behind the root noise
+        and the move sampling.  `trace`: record what every expand step consumed (TreeEngine.enable_trace; parity tests).
+        `batch_k` > 1: the legacy search's waves (src/mcts.py `batch_K`, default 16 there): up to batch_k distinct
         leaves per game are collected, evaluated in one network launch of batch_k * B positions and backed up per wave.
         `reuse_tree`: keep the played child's subtree between consecutive search_batch calls on the same games
         (the reference's portable self-play does, v1/python/portable_self_play.py:191); the arenas then hold
         (1 + reuse_factor) * sims nodes per game (reuse_factor < 0: as much as a third of the free memory allows).  `policy_target_*`: portable_mcts.py:690-700."""
         self.net, self.sims = net, int(num_simulations)
+        self.fused = isinstance(net, FusedNet)
         self.reuse_tree = bool(reuse_tree)
         self.batch_k = max(1, int(batch_k))
         self.engine = TreeEngine(num_games, num_simulations, device, exploration_weight,
                                  reuse_factor=float(reuse_factor) if self.reuse_tree else 0.0, batch_k=self.batch_k)
+        if trace:
+            self.engine.enable_trace()
+        if not self.fused:
+            if self.batch_k > 1:
+                raise ValueError("an external evaluator supports batch_k = 1 only")
+            self._eval_device = next(net.parameters()).device
+        self.rng = GameRng(num_games, device, seed=seed, game_offset=game_offset, game_stride=game_stride)
+        self._uniforms = torch.zeros((self.engine.B,), dtype=torch.float32, device=self.engine.device)
+        self.injected_noise: Optional[torch.Tensor] = None       # parity runs: [B, <= OUT_CAP] instead of the RNG's draws
+        self.injected_uniforms: Optional[torch.Tensor] = None
         self._evals_dev = torch.zeros((1,), dtype=torch.int64, device=self.engine.device)
         self.extra_rounds = 0
+        self.graph_retry_off = False                             # a failed graph capture made this engine launch directly
+        self._collect_timing = bool(collect_timing)
+        self._timing_events = []
+        self._timing_ms: Dict[str, float] = {}
+        self._timing_calls: Dict[str, int] = {}
         self.target_temperature = None if policy_target_temperature is None else float(policy_target_temperature)
         self.prior_pseudocount = float(policy_target_prior_pseudocount)
         self._have_trees = False
@@ -313,9 +357,69 @@ class PortableTreeMCTS:
         self._tail_rounds = 0
         self._noise_buf = torch.zeros((self.engine.B, OUT_CAP), dtype=torch.float32, device=self.engine.device)
 
+    # ---- tracing: roctx ranges (torch.cuda.nvtx is roctx on ROCm) + HIP-event timing buckets, as the reference's
+    # V1RootMCTS._nvtx_range / _timed (v1/python/mcts_gpu.py:565-602); bucket names follow its runner
+    # (self_play_gpu_runner.py:276-281): root_puct_ms = the search, pack_writeback_ms = policy / pick extraction ----
+    @contextmanager
+    def _timed(self, name: str):
+        torch.cuda.nvtx.range_push(f"lz.tree.{name}")
+        if not self._collect_timing:
+            try:
+                yield
+            finally:
+                torch.cuda.nvtx.range_pop()
+            return
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(torch.cuda.current_stream(self.engine.device))
+        try:
+            yield
+        finally:
+            b.record(torch.cuda.current_stream(self.engine.device))
+            self._timing_events.append((name, a, b))
+            torch.cuda.nvtx.range_pop()
+
+    def get_timing(self, reset: bool = False) -> Dict[str, Dict[str, float]]:
+        """{"timing_ms": {...}, "timing_calls": {...}} like V1RootMCTS.get_timing (one device synchronisation)."""
+        if self._timing_events:
+            torch.cuda.synchronize(self.engine.device)
+            for name, a, b in self._timing_events:
+                self._timing_ms[name] = self._timing_ms.get(name, 0.0) + float(a.elapsed_time(b))
+                self._timing_calls[name] = self._timing_calls.get(name, 0) + 1
+            self._timing_events = []
+        out = {"timing_ms": dict(self._timing_ms), "timing_calls": dict(self._timing_calls)}
+        if reset:
+            self._timing_ms, self._timing_calls = {}, {}
+        return out
+
+    def _evaluate_external(self, planes: torch.Tensor):
+        """External fp32 evaluator: module(planes) -> (log_p1, log_p2, log_pmc, value_logits); scalar value = bucket
+        expectation (src/neural_network.py:201-210), everything back on the engine's device."""
+        dev = self.engine.device
+        with torch.inference_mode():
+            lp1, lp2, lpm, raw = self.net(planes.to(self._eval_device))
+            probs = torch.softmax(raw.float(), dim=-1)
+            centers = torch.linspace(-1.0, 1.0, steps=raw.shape[-1], dtype=probs.dtype, device=probs.device)
+            val = (probs * centers).sum(-1)
+        f = lambda t: t.float().to(dev).contiguous()
+        return f(lp1), f(lp2), f(lpm), f(val)
+
+    def _search_split(self, noise: Optional[torch.Tensor], continue_trees: bool) -> None:
+        e = self.engine
+        if not continue_trees:
+            e.begin()
+        for s in range(self.sims + 1):
+            if s > 0:
+                e.select()
+            lp1, lp2, lpm, val = self._evaluate_external(e.leaf_planes())
+            e.expand(is_root=(s == 0), values=val, heads=(lp1, lp2, lpm), noise=noise if s == 0 else None,
+                     epsilon=self.eps)
+
     def _search(self, add_noise: bool, continue_trees: bool) -> None:
         e = self.engine
         noise = self._noise_buf if add_noise else None
+        if not self.fused:
+            self._search_split(noise, continue_trees)
+            return
         if not self.use_graph:
             e.search(self.net, self.sims, noise, self.eps, continue_trees)
             return
@@ -327,9 +431,24 @@ class PortableTreeMCTS:
                 # is harmless); a continued search must run exactly once and is only reached after a fresh one
                 e.search(self.net, self.sims, noise, self.eps, False)
             torch.cuda.synchronize(e.device)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            try:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    e.search(self.net, self.sims, noise, self.eps, continue_trees)
+                if os.environ.get("LZ_TREE_GRAPH_FAULT", "") == "capture":      # test hook: pretend the capture failed
+                    raise RuntimeError("injected stream capture failure (LZ_TREE_GRAPH_FAULT=capture)")
+            except RuntimeError as exc:
+                # Capture failed (the reference's worker retries a failed finalize-graph capture once with the graph off,
+                # v1/python/self_play_worker.py:24-30,434-442): nothing of the captured search has run, so the same search
+                # is launched directly, and this engine stays on direct launches.  Recorded in the manifest.
+                torch.cuda.synchronize(e.device)
+                self.use_graph = False
+                self.graph_retry_off = True
+                self._graphs.clear()
+                print(f"[liuzhou_amd] hipGraph capture of the tree search failed ({exc!r}); falling back to direct launches",
+                      flush=True)
                 e.search(self.net, self.sims, noise, self.eps, continue_trees)
+                return
             self._graphs[key] = g
         g.replay()
 
@@ -379,40 +498,56 @@ class PortableTreeMCTS:
         """Set-up outside any timed region: load every kernel and capture the graphs (a fresh search, and a continued
         one with subtree reuse) by searching `state` once or twice; the trees built here are thrown away."""
         temps = torch.ones((self.engine.B,), dtype=torch.float32, device=self.engine.device)
+        game0 = self.rng.game.clone()
         for _ in range(2 if self.reuse_tree else 1):
             self.search_batch(state, temperatures=temps)
+        self.rng.game.copy_(game0)
+        self.rng.ply.zero_()
         self._have_trees = False
         self._root_evals = 0
         self.extra_rounds = 0
+        self.get_timing(reset=True)
         if self.batch_k > 1:
             self.engine.wbuf["eval_total"].zero_(); self.engine.wbuf["eval_count"].zero_()
 
     def search_batch(self, state: GpuStateBatch, *, temperatures: torch.Tensor, active: Optional[torch.Tensor] = None,
                      add_dirichlet_noise: Optional[bool] = None, reset: Optional[torch.Tensor] = None,
                      played_action: Optional[torch.Tensor] = None,
-                     force_uniform_random_mask: Optional[torch.Tensor] = None) -> RootSearchBatchOutput:
+                     force_uniform_random_mask: Optional[torch.Tensor] = None,
+                     rng_game_ids: Optional[torch.Tensor] = None,
+                     rng_plies: Optional[torch.Tensor] = None) -> RootSearchBatchOutput:
         """`state`: the games' current positions.  With `reuse_tree`, games whose position is the child reached by
         `played_action` (default: the move this engine picked last time) keep that child's subtree; `reset` marks
-        games that were re-seated.  Anything that does not match simply starts a fresh tree."""
+        games that were re-seated.  Anything that does not match simply starts a fresh tree.  `rng_game_ids` /
+        `rng_plies` int64[B]: the runner's own game numbering and ply counters as RNG keys (default: slot-derived ids
+        that advance on `reset`, plies counted per search)."""
         self.launch_search(state, active=active, add_dirichlet_noise=add_dirichlet_noise, reset=reset,
-                           played_action=played_action)
+                           played_action=played_action, rng_game_ids=rng_game_ids, rng_plies=rng_plies)
         return self.complete_search(state, temperatures=temperatures,
                                     force_uniform_random_mask=force_uniform_random_mask)
 
     def launch_search(self, state: GpuStateBatch, *, active: Optional[torch.Tensor] = None,
                       add_dirichlet_noise: Optional[bool] = None, reset: Optional[torch.Tensor] = None,
-                      played_action: Optional[torch.Tensor] = None) -> None:
+                      played_action: Optional[torch.Tensor] = None, rng_game_ids: Optional[torch.Tensor] = None,
+                      rng_plies: Optional[torch.Tensor] = None) -> None:
         """First half of search_batch: everything up to the end of the captured search, nothing that waits for the
         device (so that several engines on several streams can be launched back to back)."""
         e = self.engine
         add_noise = self.add_noise if add_dirichlet_noise is None else bool(add_dirichlet_noise)
         e.set_roots(state, active)
         continue_trees = self.reuse_tree and self._have_trees
-        if continue_trees:
-            e.advance(played_action, reset, self.sims)
-        if add_noise:
-            self._noise_buf.copy_(dirichlet_noise((e.B, OUT_CAP), self.alpha, e.device))
-        self._search(add_noise, continue_trees)
+        self.rng.begin_move(reset if self._have_trees else None, rng_game_ids, rng_plies)
+        self._explicit_plies = rng_plies is not None
+        with self._timed("root_puct_ms"):
+            if continue_trees:
+                e.advance(played_action, reset, self.sims)
+            if add_noise:
+                if self.injected_noise is not None:
+                    self._noise_buf.zero_()
+                    self._noise_buf[:, : int(self.injected_noise.shape[1])].copy_(self.injected_noise.to(torch.float32))
+                else:
+                    self.rng.gamma_into(self._noise_buf, self.alpha, MAX_CHILDREN)
+            self._search(add_noise, continue_trees)
         self._have_trees = True
 
     def complete_search(self, state: GpuStateBatch, *, temperatures: torch.Tensor,
@@ -428,12 +563,20 @@ class PortableTreeMCTS:
         else:
             self._root_evals += e.B * (self.sims + 1)
         need_u = self.sample_moves or force_uniform_random_mask is not None
-        uniforms = torch.rand((e.B,), dtype=torch.float32, device=dev) if need_u else None
-        temps = temperatures.to(torch.float32).contiguous()
-        tt = None if self.target_temperature is None else torch.full_like(temps, self.target_temperature)
-        e.finish(temps, uniforms, tt, self.prior_pseudocount, force_uniform_random_mask, self.sample_moves)
-        model_input = states_to_model_input(state)
-        legal_mask, _ = encode_actions_fast(state)
+        uniforms = None
+        with self._timed("pack_writeback_ms"):
+            if need_u:
+                uniforms = self._uniforms
+                if self.injected_uniforms is not None:
+                    uniforms.copy_(self.injected_uniforms.to(torch.float32))
+                else:
+                    self.rng.uniform_into(uniforms, PURPOSE_PICK)
+            self.rng.end_move(getattr(self, "_explicit_plies", False))
+            temps = temperatures.to(torch.float32).contiguous()
+            tt = None if self.target_temperature is None else torch.full_like(temps, self.target_temperature)
+            e.finish(temps, uniforms, tt, self.prior_pseudocount, force_uniform_random_mask, self.sample_moves)
+            model_input = states_to_model_input(state)
+            legal_mask, _ = encode_actions_fast(state)
         return RootSearchBatchOutput(
             model_input=model_input, legal_mask=legal_mask, policy_dense=e.policy_dense, root_value=e.root_value,
             terminal_mask=e.terminal_mask, chosen_action_indices=e.chosen_index.to(torch.int64),
@@ -464,11 +607,14 @@ class DualStreamTreeMCTS:
         self.device = dev
         self.streams = tuple(torch.cuda.Stream(dev) for _ in range(k))
         self.parts = []
-        for n in sizes:
-            base = model if isinstance(model, FusedNet) else FusedNet(model, dev)
+        base = model if isinstance(model, FusedNet) else FusedNet(model, dev)
+        kw.pop("game_offset", None); kw.pop("game_stride", None)
+        for (a, _b), n in zip(self.bounds, sizes):
             # waves of batch_k leaves are large launches: full 8-wave workgroups (they fill the chip on their own)
             half = int(kw.get("batch_k", 1)) <= 1
-            self.parts.append(PortableTreeMCTS(base.variant(half_workgroups=half), n, num_simulations, dev, **kw))
+            # global game ids: slot a + g of the whole batch, so that a game's RNG stream does not depend on the split
+            self.parts.append(PortableTreeMCTS(base.variant(half_workgroups=half), n, num_simulations, dev,
+                                               game_offset=a, game_stride=self.B, **kw))
         self.sims = int(num_simulations)
         self.serialize = False        # measurement aid: run the halves one after the other on the caller's stream
 
@@ -494,10 +640,26 @@ class DualStreamTreeMCTS:
         for p in self.parts:
             p.reset_trees()
 
+    @property
+    def graph_retry_off(self) -> bool:
+        return any(p.graph_retry_off for p in self.parts)
+
+    def get_timing(self, reset: bool = False) -> Dict[str, Dict[str, float]]:
+        """Sum over the parts (their searches overlap on the device, so these are stream-busy times, not wall time)."""
+        out: Dict[str, Dict[str, float]] = {"timing_ms": {}, "timing_calls": {}}
+        for p in self.parts:
+            t = p.get_timing(reset)
+            for k in out:
+                for name, v in t[k].items():
+                    out[k][name] = out[k].get(name, 0) + v
+        return out
+
     def search_batch(self, state: GpuStateBatch, *, temperatures: torch.Tensor, active: Optional[torch.Tensor] = None,
                      add_dirichlet_noise: Optional[bool] = None, reset: Optional[torch.Tensor] = None,
                      played_action: Optional[torch.Tensor] = None,
-                     force_uniform_random_mask: Optional[torch.Tensor] = None) -> RootSearchBatchOutput:
+                     force_uniform_random_mask: Optional[torch.Tensor] = None,
+                     rng_game_ids: Optional[torch.Tensor] = None,
+                     rng_plies: Optional[torch.Tensor] = None) -> RootSearchBatchOutput:
         main = torch.cuda.current_stream(self.device)
         cut = lambda t, a, b: None if t is None else t[a:b]
         outs = []
@@ -507,7 +669,8 @@ class DualStreamTreeMCTS:
             st.wait_stream(main)
             with torch.cuda.stream(st):
                 part.launch_search(sub, active=cut(active, a, b), add_dirichlet_noise=add_dirichlet_noise,
-                                   reset=cut(reset, a, b), played_action=cut(played_action, a, b))
+                                   reset=cut(reset, a, b), played_action=cut(played_action, a, b),
+                                   rng_game_ids=cut(rng_game_ids, a, b), rng_plies=cut(rng_plies, a, b))
         todo = list(zip(self.parts, streams))                  # leftover rounds (batch_k > 1): the parts take turns,
         while todo:                                            # so that their small rounds overlap on the device
             nxt = []
@@ -535,7 +698,10 @@ class SteadyStateTreeSelfPlay:
     def __init__(self, model, num_games: int, sims: int, device, dtype: str = "float16", seed: int = 12345,
                  temperature_init: float = 1.0, temperature_final: float = 0.1, temperature_threshold: int = 10,
                  max_game_plies: int = 512, exploration_weight: float = 1.0, reuse_tree: bool = False,
-                 reuse_factor: float = -1.0, dual_stream: bool = False, batch_k: int = 1) -> None:
+                 reuse_factor: float = -1.0, dual_stream: bool = False, batch_k: int = 1,
+                 arena_rows: Optional[int] = None) -> None:
+        """`arena_rows`: trajectory rows to preallocate (one per game and step; the arena doubles -- one host sync and a
+        copy -- when it runs out, so timed runs size it for all their steps)."""
         from .steady_state import SteadyStateRootSelfPlay
         from .mcts_gpu import V1RootMCTSConfig
         dev = torch.device(device)
@@ -545,14 +711,14 @@ class SteadyStateTreeSelfPlay:
         self.pop = SteadyStateRootSelfPlay(self.net, num_games, V1RootMCTSConfig(num_simulations=1), dev, seed=seed,
                                            temperature_init=temperature_init, temperature_final=temperature_final,
                                            temperature_threshold=temperature_threshold, max_game_plies=max_game_plies,
-                                           fused_search=False)
+                                           fused_search=False, arena_rows=arena_rows)
         self.dual_stream = bool(dual_stream and self.net.pack.channels == 64 and int(num_games) >= 2)
         if self.dual_stream:
             self.mcts = DualStreamTreeMCTS(self.net, num_games, sims, dev, exploration_weight=exploration_weight,
-                                           reuse_tree=reuse_tree, reuse_factor=reuse_factor, batch_k=batch_k)
+                                           reuse_tree=reuse_tree, reuse_factor=reuse_factor, batch_k=batch_k, seed=seed)
         else:
             self.mcts = PortableTreeMCTS(self.net, num_games, sims, dev, exploration_weight, reuse_tree=reuse_tree,
-                                         reuse_factor=reuse_factor, batch_k=batch_k)
+                                         reuse_factor=reuse_factor, batch_k=batch_k, seed=seed)
         self._reseated = torch.zeros((self.B,), dtype=torch.uint8, device=dev)
         self.positions = 0
         self._nn_events = []
@@ -573,7 +739,7 @@ class SteadyStateTreeSelfPlay:
     def step(self) -> None:
         p = self.pop
         temps = torch.where(p.plies < p.t_thr, p.t_init, p.t_final).to(torch.float32)
-        search = self.mcts.search_batch(p.states, temperatures=temps, reset=self._reseated)
+        search = self.mcts.search_batch(p.states, temperatures=temps, reset=self._reseated, rng_plies=p.plies)
         self._reseated.zero_()
         p.finish_step(search, reseated=self._reseated)
         self.positions += self.B
@@ -587,21 +753,34 @@ def self_play_tree_gpu(model, num_games: int, mcts_simulations: int, temperature
                        policy_target_temperature: Optional[float] = None,
                        policy_target_prior_pseudocount: float = 0.0, reuse_tree: bool = True,
                        reuse_factor: float = -1.0, dual_stream: Optional[bool] = None, continuous_waves: bool = True,
-                       device_tail: bool = True, batch_k: int = 1) -> Tuple[TensorSelfPlayBatch, SelfPlayV1Stats]:
+                       device_tail: bool = True, batch_k: int = 1, evaluator: str = "auto", seed: int = 12345,
+                       collect_timing: bool = False) -> Tuple[TensorSelfPlayBatch, SelfPlayV1Stats]:
     """Tree-search twin of self_play_v1_gpu (same outputs); mirrors v1/python/portable_self_play.py:82-284,
-    including the subtree reuse it performs on every move (:191, `reuse_tree`)."""
+    including the subtree reuse it performs on every move (:191, `reuse_tree`).
+    `evaluator`: "fused" = the hand-written fp16 network kernel inside the captured search (6x64 / 10x128 nets);
+    "module" = `model` itself as an external fp32 evaluator behind the split-phase protocol, whatever its size or
+    device (what the reference's portable runner does with its `model`); "auto" = fused when the net has a fused
+    kernel.  `seed`: key of the per-game counter RNG (noise, sampled moves); game ids are the runner's game numbers."""
     dev = torch.device(device)
-    net = model if isinstance(model, FusedNet) else FusedNet(model, dev)
+    if evaluator not in ("auto", "fused", "module"):
+        raise ValueError(f"evaluator must be auto / fused / module, got {evaluator!r}")
+    if isinstance(model, FusedNet):
+        net, use_fused = model, True
+    else:
+        chans = int(model.stem_conv.out_channels) if hasattr(model, "stem_conv") else -1
+        use_fused = evaluator == "fused" or (evaluator == "auto" and chans in (64, 128))
+        net = FusedNet(model, dev) if use_fused else model.eval()
     wave = max(1, min(int(concurrent_games), int(num_games)))
     # two half-batches on two streams (see DualStreamTreeMCTS) once a wave is large enough to fill the chip twice over
     if dual_stream is None:
-        dual_stream = net.pack.channels == 64 and wave >= 1024 and int(batch_k) <= 1   # waves: large launches already
-    cls = DualStreamTreeMCTS if (dual_stream and net.pack.channels == 64 and wave >= 2) else PortableTreeMCTS
+        dual_stream = use_fused and net.pack.channels == 64 and wave >= 1024 and int(batch_k) <= 1   # waves: large launches already
+    cls = DualStreamTreeMCTS if (dual_stream and use_fused and net.pack.channels == 64 and wave >= 2) else PortableTreeMCTS
     mcts = cls(net, wave, mcts_simulations, dev, exploration_weight=exploration_weight,
                add_dirichlet_noise=add_dirichlet_noise, dirichlet_alpha=dirichlet_alpha,
                dirichlet_epsilon=dirichlet_epsilon, sample_moves=sample_moves, reuse_tree=reuse_tree,
                reuse_factor=reuse_factor, policy_target_temperature=policy_target_temperature,
-               policy_target_prior_pseudocount=policy_target_prior_pseudocount, batch_k=batch_k)
+               policy_target_prior_pseudocount=policy_target_prior_pseudocount, batch_k=batch_k, seed=seed,
+               collect_timing=collect_timing)
     buffer = TensorTrajectoryBuffer(dev, TOTAL_ACTION_DIM, max_steps_hint=max_game_plies, concurrent_games_hint=wave)
     outcome = torch.zeros((3,), dtype=torch.int64, device=dev)
     lengths = torch.zeros((int(num_games),), dtype=torch.int64, device=dev)
@@ -612,6 +791,7 @@ def self_play_tree_gpu(model, num_games: int, mcts_simulations: int, temperature
     if device_tail:
         from .wave_tail import WaveTail
         tail = WaveTail(buffer, wave, int(max_game_plies), dev, soft_value_k=float(soft_value_k))
+        tail.collect_timing = bool(collect_timing)
         outcome, delta_hist = tail.outcome, tail.delta_hist
     continuous = tail is not None and bool(continuous_waves)
     wasted_plies = 0
@@ -626,11 +806,13 @@ def self_play_tree_gpu(model, num_games: int, mcts_simulations: int, temperature
         if g < wave:
             done[g:] = True
         mcts.reset_trees()
+        slot_ids = torch.arange(wave, dtype=torch.int64, device=dev)
         if tail is not None:
             force_n = int(opening_random_moves)
             tail.run(lambda st, temps, dn, reseated: mcts.search_batch(
                          st, temperatures=temps, active=~dn, reset=reseated,
-                         force_uniform_random_mask=(plies < force_n) if force_n > 0 else None),
+                         force_uniform_random_mask=(plies < force_n) if force_n > 0 else None,
+                         rng_game_ids=tail.slot_game + (0 if continuous else base), rng_plies=plies),
                      states, plies, done, step_index, step_counts, lengths if continuous else lengths[base:base + g],
                      temperature_init, temperature_final, temperature_threshold,
                      games_to_start=int(num_games) - wave if continuous else 0)
@@ -643,7 +825,8 @@ def self_play_tree_gpu(model, num_games: int, mcts_simulations: int, temperature
             temps = torch.where(plies < int(temperature_threshold), float(temperature_init),
                                 float(temperature_final)).to(torch.float32)
             force = (plies < int(opening_random_moves)) if int(opening_random_moves) > 0 else None
-            out = mcts.search_batch(states, temperatures=temps, active=~done, force_uniform_random_mask=force)
+            out = mcts.search_batch(states, temperatures=temps, active=~done, force_uniform_random_mask=force,
+                                    rng_game_ids=slot_ids + base, rng_plies=plies)
             rows = buffer.append_steps(out.model_input.index_select(0, active), out.legal_mask.index_select(0, active),
                                        out.policy_dense.index_select(0, active),
                                        states.current_player.index_select(0, active))
@@ -671,15 +854,22 @@ def self_play_tree_gpu(model, num_games: int, mcts_simulations: int, temperature
     o = outcome.tolist()
     hist = delta_hist.tolist() if delta_hist is not None else []
     keys = ("root_puct_ms", "pack_writeback_ms", "self_play_step_ms", "finalize_ms")
+    timing = mcts.get_timing() if collect_timing else {"timing_ms": {}, "timing_calls": {}}
+    if tail is not None and collect_timing:
+        for k, v in tail.get_timing().items():
+            timing["timing_ms"][k] = timing["timing_ms"].get(k, 0.0) + v["ms"]
+            timing["timing_calls"][k] = timing["timing_calls"].get(k, 0) + v["calls"]
+    t_ms = {k: float(timing["timing_ms"].get(k, 0.0)) for k in keys}
+    t_total = sum(t_ms.values())
     stats = SelfPlayV1Stats(
         num_games=num_games, num_positions=batch.num_samples, black_wins=int(o[0]), white_wins=int(o[1]), draws=int(o[2]),
         avg_game_length=float(lengths.to(torch.float32).mean().item()), elapsed_sec=elapsed,
         positions_per_sec=float(batch.num_samples / elapsed), games_per_sec=float(num_games / elapsed),
-        step_timing_ms={k: 0.0 for k in keys}, step_timing_ratio={k: 0.0 for k in keys},
-        step_timing_calls={k: 0 for k in keys},
+        step_timing_ms=t_ms, step_timing_ratio={k: (t_ms[k] / t_total if t_total > 0 else 0.0) for k in keys},
+        step_timing_calls={k: int(timing["timing_calls"].get(k, 0)) for k in keys},
         # the device-tail loop runs one fully masked ply per wave after the last game has ended (wave_tail.WaveTail.run)
         mcts_counters={"leaf_eval_count": int(mcts.leaf_evals) - (wasted_plies * wave * (int(mcts_simulations) + 1)
                                                                   if int(batch_k) <= 1 else 0),
-                       "masked_extra_plies": wasted_plies},
+                       "masked_extra_plies": wasted_plies, "graph_retry_off": int(bool(mcts.graph_retry_off))},
         piece_delta_buckets={str(d - 18): int(v) for d, v in enumerate(hist)}, device=str(dev))
     return batch, stats

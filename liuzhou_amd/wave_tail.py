@@ -32,6 +32,38 @@ class WaveTail:
         self.outcome = z(3, torch.int64)
         self.delta_hist = z(DELTA_BINS, torch.int64)
         self.finished = z(1, torch.int64)
+        self.slot_game = torch.arange(self.G, dtype=torch.int64, device=dev)   # game number played in each slot (run())
+        self.collect_timing = False
+        self._timing_events = []
+
+    def _bracket(self, name: str):
+        """HIP-event bracket + roctx range for one tail kernel sequence (bucket names of the reference's runner,
+        v1/python/self_play_gpu_runner.py:276-281)."""
+        from contextlib import contextmanager
+
+        @contextmanager
+        def cm():
+            torch.cuda.nvtx.range_push(f"lz.tail.{name}")
+            if self.collect_timing:
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(torch.cuda.current_stream(self.device))
+            try:
+                yield
+            finally:
+                if self.collect_timing:
+                    b.record(torch.cuda.current_stream(self.device))
+                    self._timing_events.append((name, a, b))
+                torch.cuda.nvtx.range_pop()
+        return cm()
+
+    def get_timing(self):
+        torch.cuda.synchronize(self.device)
+        out = {}
+        for name, a, b in self._timing_events:
+            d = out.setdefault(name, {"ms": 0.0, "calls": 0})
+            d["ms"] += float(a.elapsed_time(b)); d["calls"] += 1
+        self._timing_events = []
+        return out
 
     def record(self, states: GpuStateBatch, done: torch.Tensor, step_index: torch.Tensor, step_counts: torch.Tensor,
                search: RootSearchBatchOutput) -> None:
@@ -91,7 +123,8 @@ class WaveTail:
         events = [torch.cuda.Event() for _ in range(2)]
         budget = torch.full((1,), int(games_to_start), dtype=torch.int64, device=dev)
         next_game = torch.full((1,), g, dtype=torch.int64, device=dev)
-        slot_game = torch.arange(g, dtype=torch.int64, device=dev)
+        slot_game = self.slot_game
+        slot_game.copy_(torch.arange(g, dtype=torch.int64, device=dev))
         reseated = torch.zeros((g,), dtype=torch.uint8, device=dev)
         ply = 0
         while True:
@@ -105,8 +138,10 @@ class WaveTail:
             temps = torch.where(plies < int(t_threshold), float(t_init), float(t_final)).to(torch.float32)
             search = search_fn(states, temps, done, reseated)
             reseated.zero_()
-            self.record(states, done, step_index, step_counts, search)
-            self.step_finish(states, plies, done, step_index, step_counts, search, lengths=lengths, slot_game=slot_game)
+            with self._bracket("finalize_ms"):
+                self.record(states, done, step_index, step_counts, search)
+            with self._bracket("self_play_step_ms"):
+                self.step_finish(states, plies, done, step_index, step_counts, search, lengths=lengths, slot_game=slot_game)
             # all finished and nothing left to start (a finished slot restarts at the top of the next ply otherwise)
             flags[k].copy_((done.all() & (budget <= 0).all()).view(1), non_blocking=True)
             events[k].record(torch.cuda.current_stream(dev))

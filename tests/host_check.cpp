@@ -4,6 +4,7 @@
 #include <cstdint>
 #include <cstring>
 #include "../liuzhou_amd/csrc/lz_soa.h"
+#include "../liuzhou_amd/csrc/lz_rng.h"
 
 using namespace lz;
 
@@ -78,5 +79,19 @@ void hc_status(const LzStateSoA* s, int64_t B, int32_t* status, int32_t* nlegal_
         status[i] = game_status(st);
         nlegal_py[i] = legal_count(legal_actions(st, 0));
     }
+}
+// per-game counter RNG header (lz_rng.h), host build
+void hc_philox(const uint32_t* ctr, uint32_t k0, uint32_t k1, int64_t n, uint32_t* out) {
+    for (int64_t i = 0; i < n; ++i) {
+        const lzrng::U4 r = lzrng::philox4x32_10({ctr[i * 4], ctr[i * 4 + 1], ctr[i * 4 + 2], ctr[i * 4 + 3]}, k0, k1);
+        out[i * 4] = r.x; out[i * 4 + 1] = r.y; out[i * 4 + 2] = r.z; out[i * 4 + 3] = r.w;
+    }
+}
+void hc_rng_gamma(uint64_t seed, const int64_t* game, const int64_t* ply, int64_t B, float alpha, int64_t count, float* out) {
+    for (int64_t g = 0; g < B; ++g)
+        for (int64_t k = 0; k < count; ++k) out[g * count + k] = lzrng::gamma_draw(seed, game[g], ply[g], (uint32_t)k, alpha);
+}
+void hc_rng_uniform(uint64_t seed, const int64_t* game, const int64_t* ply, int64_t B, int purpose, float* out) {
+    for (int64_t g = 0; g < B; ++g) out[g] = lzrng::uniform_draw(seed, game[g], ply[g], (uint32_t)purpose);
 }
 }

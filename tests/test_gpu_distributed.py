@@ -1,0 +1,113 @@
+"""GPU, world_size 2: the compact 360-byte trajectory gather (`distributed._gather_compact`: the path RCCL takes
+between the GPUs of a node) and the flat checkpoint broadcast under a real process group.  Both ranks share cuda:0
+(a 1-GPU box); RCCL refuses two ranks on one device, so the group is gloo and the records are staged through host
+memory -- the count / bad-row protocol and the pack / unpack kernels are exactly those of the RCCL path."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+FIELDS = ("state_tensors", "legal_masks", "policy_targets", "value_targets", "soft_value_targets")
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _play(rank, games, plies):
+    """Real trajectory rows: a few plies of root-PUCT self-play on the HIP operators (tiny net), on cuda:0."""
+    from liuzhou_amd.net import ChessNet, MODEL_CONFIGS
+    from liuzhou_amd.self_play_gpu_runner import self_play_v1_gpu
+    torch.manual_seed(7)
+    model = ChessNet(**MODEL_CONFIGS["tiny"]).eval().to("cuda:0")
+    torch.manual_seed(100 + rank)
+    batch, _ = self_play_v1_gpu(model, num_games=games, mcts_simulations=8, temperature_init=1.0, temperature_final=0.1,
+                                temperature_threshold=10, exploration_weight=1.0, device="cuda:0",
+                                add_dirichlet_noise=True, sample_moves=True, concurrent_games=games,
+                                max_game_plies=plies, autocast_dtype="float32")
+    return batch
+
+
+def _worker(rank, world, port, mode, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from liuzhou_amd.distributed import broadcast_checkpoint, gather_trajectories
+        from liuzhou_amd.net import ChessNet, MODEL_CONFIGS
+        from liuzhou_amd.trajectory_buffer import TensorSelfPlayBatch
+        mine = _play(rank, games=3 + 2 * rank, plies=10 + rank) if mode != "empty" or rank == 0 else _play(rank, 1, 1)
+        if mode == "empty" and rank == 1:
+            mine = TensorSelfPlayBatch(*(getattr(mine, f)[:0] for f in FIELDS))
+        if mode == "bad" and rank == 1:                         # policy mass on an illegal action: not representable
+            pol = mine.policy_targets.clone()
+            illegal = (~mine.legal_masks[0]).nonzero().view(-1)[0]
+            pol[0, illegal] = 0.25
+            mine = TensorSelfPlayBatch(mine.state_tensors, mine.legal_masks, pol, mine.value_targets, mine.soft_value_targets)
+        raised = None
+        try:
+            got = gather_trajectories(mine, dst=0, compact=True)
+        except RuntimeError as exc:
+            raised, got = str(exc), None
+        if mode == "bad":
+            q.put((rank, "raised", raised is not None and "not representable" in raised))
+            return
+        assert raised is None, raised
+        # the reference layout of the same rows, through the five-tensor path on host tensors
+        cpu = TensorSelfPlayBatch(*(getattr(mine, f).cpu() for f in FIELDS))
+        want = gather_trajectories(cpu, dst=0, compact=False)
+        if rank == 0:
+            ok = got is not None and got.num_samples == want.num_samples and got.state_tensors.is_cuda
+            for f in FIELDS:
+                a, b = getattr(got, f).cpu(), getattr(want, f)
+                same = torch.equal(a, b) if a.dtype == torch.bool else torch.equal(a.view(torch.int32), b.view(torch.int32))
+                ok = ok and same
+            q.put((rank, "gather", bool(ok)))
+        else:
+            q.put((rank, "gather", got is None))
+        torch.manual_seed(rank)
+        model = ChessNet(**MODEL_CONFIGS["b6c64"]).to("cuda:0")
+        broadcast_checkpoint(model.cpu(), src=0)                 # gloo: host tensors (RCCL broadcasts device tensors)
+        q.put((rank, "digest", float(sum(p.double().sum() for p in model.parameters())) +
+               float(sum(b.double().sum() for b in model.buffers()))))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run(mode, n_items):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, mode, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    items = [q.get(timeout=300) for _ in range(n_items)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    return items
+
+
+def test_compact_gather_under_a_process_group_is_bit_exact():
+    items = _run("normal", 4)
+    assert all(v is True for _, k, v in items if k == "gather") and sum(k == "gather" for _, k, _ in items) == 2
+    d = [v for _, k, v in items if k == "digest"]
+    assert len(d) == 2 and abs(d[0] - d[1]) < 1e-9
+
+
+def test_compact_gather_with_an_empty_rank():
+    items = _run("empty", 4)
+    assert all(v is True for _, k, v in items if k == "gather")
+
+
+def test_unrepresentable_row_makes_every_rank_raise():
+    items = _run("bad", 2)
+    assert sorted(r for r, _, _ in items) == [0, 1] and all(v is True for _, _, v in items)

@@ -295,3 +295,43 @@ def test_tree_self_play_runner_with_legacy_waves():
     st = GpuStateBatch.initial(torch.device("cuda:0"), 64)
     mcts.search_batch(st, temperatures=torch.ones(64, device="cuda:0"))
     assert bool((mcts.engine.child_visits.sum(dim=1) == 50).all())
+
+
+def _check_tree_trace(batch, stats, z, tag):
+    n = z[f"{tag}_policy_targets"].shape[0]
+    assert batch.num_samples == n
+    want_states = np.unpackbits(z[f"{tag}_state_tensors"], axis=1)[:, :11 * 36].reshape(n, 11, 6, 6).astype(np.float32)
+    assert np.array_equal(batch.state_tensors.cpu().numpy(), want_states)
+    assert np.array_equal(batch.legal_masks.cpu().numpy(), np.unpackbits(z[f"{tag}_legal_masks"], axis=1)[:, :220].astype(bool))
+    np.testing.assert_allclose(batch.policy_targets.cpu().numpy(), z[f"{tag}_policy_targets"], atol=1e-5, rtol=0)
+    np.testing.assert_array_equal(batch.value_targets.cpu().numpy(), z[f"{tag}_value_targets"])
+    np.testing.assert_allclose(batch.soft_value_targets.cpu().numpy(), z[f"{tag}_soft_value_targets"], atol=1e-6, rtol=0)
+    assert [stats.black_wins, stats.white_wins, stats.draws] == [int(x) for x in z[f"{tag}_outcome"]]
+
+
+@pytest.mark.parametrize("tag,extra", [("a", {}), ("b", dict(policy_target_temperature=1.0,
+                                                              policy_target_prior_pseudocount=0.5))])
+def test_tree_runner_reproduces_reference_portable_selfplay_trace(tag, extra):
+    """g10: the reference's own portable full-tree runner (v1/python/portable_self_play.py, tiny net seed 7, subtree
+    reuse on every move, deterministic picks) recorded on CPU; `self_play_tree_gpu` -- device trees, device tail, the
+    same tiny network as an external fp32 evaluator behind the split-phase protocol -- must produce the same samples."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from liuzhou_amd.net import ChessNet, MODEL_CONFIGS
+    from liuzhou_amd.tree_engine import self_play_tree_gpu
+    z = load("g10_tree_selfplay.npz")
+    games, sims, max_plies = (int(x) for x in z[f"{tag}_config"])
+    torch.manual_seed(7)
+    model = ChessNet(**MODEL_CONFIGS["tiny"]).eval()          # evaluated on the host in fp32, like the recorded run
+    for tail in (True, False):
+        batch, stats = self_play_tree_gpu(model, num_games=games, mcts_simulations=sims, temperature_init=1.0,
+                                          temperature_final=0.1, temperature_threshold=10, exploration_weight=1.0,
+                                          device="cuda:0", add_dirichlet_noise=False, soft_value_k=2.0,
+                                          opening_random_moves=0, max_game_plies=max_plies, sample_moves=False,
+                                          concurrent_games=games, reuse_tree=True, evaluator="module",
+                                          device_tail=tail, collect_timing=tail, **extra)
+        _check_tree_trace(batch, stats, z, tag)
+        if tail:      # timing buckets of the reference's runner are filled (self_play_gpu_runner.py:276-281)
+            assert stats.step_timing_ms["root_puct_ms"] > 0 and stats.step_timing_calls["root_puct_ms"] > 0
+            assert stats.step_timing_ms["self_play_step_ms"] > 0 and stats.step_timing_ms["finalize_ms"] > 0
+            assert abs(sum(stats.step_timing_ratio.values()) - 1.0) < 1e-6

@@ -432,3 +432,102 @@ def test_gpu_wave_search_with_fused_network_compact_batch_equals_slot_major_prot
     live = ~a.terminal_mask.cpu().numpy()
     assert live.any() and (va[live].sum(axis=1) == sims).all()
     assert torch.equal(a.chosen_index, b.chosen_index) and torch.equal(a.root_value, b.root_value)
+
+
+# ---- the production launch path (what bench.py and the product runners execute) vs the oracle ------------------------
+@pytest.mark.parametrize("dual", [False, True])
+def test_production_search_path_replayed_in_oracle(dual):
+    """lz_tree_search + lz_tree_search_continue exactly as bench.py drives them: fused expand + select kernel with the
+    priors formed in the kernel from the three head rows, fused b6c64 network in the loop, one hipGraph per move,
+    subtree reuse, Philox root noise, sampled moves; one engine and two engines on two streams.  128 games x 200 sims
+    x 3 consecutive moves: same leaf at every simulation, bit-identical visit counts / W sums / priors at the root,
+    in-kernel softmax within 1e-6 of the oracle's projection of the same head rows."""
+    _need_gpu()
+    from tests.tree_parity import run_production_parity
+    mcts, tot = run_production_parity(DEV, "b6c64", num_games=128, sims=200, moves=3, dual=dual, seed=21)
+    assert mcts.use_graph and not mcts.graph_retry_off
+    assert tot["kept"] > 0, "no game kept a subtree: the continued search was not exercised"
+    assert tot["evals"] > 128 * 200 * 2
+    print(f"production parity dual={dual}: {tot}")
+
+
+def test_production_search_path_c3_arithmetic():
+    """C3's arithmetic and arena sizes on a small population: 10x128 network, 800 simulations per move, 64 games, two
+    consecutive moves (the second one continues kept subtrees of several hundred nodes)."""
+    _need_gpu()
+    from tests.tree_parity import run_production_parity
+    mcts, tot = run_production_parity(DEV, "b10c128", num_games=64, sims=800, moves=2, dual=False, seed=22,
+                                      reuse_factor=4.0)
+    assert mcts.use_graph and tot["kept"] > 0
+    print(f"production parity C3 arithmetic: {tot}")
+
+
+def test_production_search_direct_launches_equal_graph_replay():
+    """The same search with direct launches (LZ_TREE_GRAPH=off path) and as a replayed hipGraph: identical trees."""
+    _need_gpu()
+    from tests.tree_parity import run_production_parity, root_edges
+    a, _ = run_production_parity(DEV, "b6c64", num_games=48, sims=64, moves=2, seed=23, use_graph=True)
+    b, _ = run_production_parity(DEV, "b6c64", num_games=48, sims=64, moves=2, seed=23, use_graph=False)
+    for x, y in zip(root_edges(a.engine), root_edges(b.engine)):
+        assert x.tobytes() == y.tobytes()
+
+
+def test_graph_capture_failure_falls_back_to_direct_launches(monkeypatch):
+    """A failed capture (the reference retries a failed finalize-graph capture with the graph off,
+    v1/python/self_play_worker.py:434-442) must not lose the move: same result as the direct path, flag recorded."""
+    _need_gpu()
+    from tests.tree_parity import run_production_parity, root_edges
+    ref, _ = run_production_parity(DEV, "b6c64", num_games=32, sims=32, moves=2, seed=24, use_graph=False)
+    monkeypatch.setenv("LZ_TREE_GRAPH_FAULT", "capture")
+    got, _ = run_production_parity(DEV, "b6c64", num_games=32, sims=32, moves=2, seed=24, use_graph=True)
+    assert got.graph_retry_off and not got.use_graph
+    for x, y in zip(root_edges(got.engine), root_edges(ref.engine)):
+        assert x.tobytes() == y.tobytes()
+
+
+def test_device_rng_equals_oracle_and_is_independent_of_the_batch_split():
+    """lz_rng_gamma / lz_rng_uniform (Philox4x32-10 keyed by seed, counter = game id / ply / purpose / index) against
+    the numpy oracle; and the search built on them plays the SAME moves with noise and sampling on whether the games run
+    as one batch on one stream or as two halves on two streams."""
+    _need_gpu()
+    from oracle import rng_oracle as R
+    from liuzhou_amd.game_rng import GameRng, PURPOSE_PICK
+    rng = GameRng(300, DEV, seed=(5 << 32) | 99, game_offset=1000)
+    rng.ply.copy_(torch.arange(300, device=DEV) % 144)
+    out = torch.zeros((300, 80), device=DEV); u = torch.zeros((300,), device=DEV)
+    rng.gamma_into(out, 0.3, 72); rng.uniform_into(u, PURPOSE_PICK)
+    game, ply = rng.game.cpu().numpy(), rng.ply.cpu().numpy()
+    assert np.array_equal(u.cpu().numpy(), R.uniform(rng.seed, game, ply, R.PURPOSE_PICK))
+    np.testing.assert_allclose(out[:, :72].cpu().numpy(), R.gamma(rng.seed, game, ply, 72, 0.3), rtol=1e-4, atol=1e-30)
+    assert not out[:, 72:].any()
+
+    from liuzhou_amd.net import ChessNet, MODEL_CONFIGS
+    from liuzhou_amd.net_hip import FusedNet
+    from liuzhou_amd.tree_engine import DualStreamTreeMCTS, PortableTreeMCTS
+    torch.manual_seed(20260314)
+    net = FusedNet(ChessNet(**MODEL_CONFIGS["b6c64"]).eval().to(DEV))
+    z = load("g1_rules.npz")
+    st = states(z, "s")
+    idx = np.random.default_rng(9).integers(0, st["board"].shape[0], 96)
+    batch = to_gpu_batch({f: np.ascontiguousarray(np.asarray(st[f])[idx]) for f in FIELDS}, DEV)
+    temps = torch.ones(96, device=DEV)
+    kw = dict(add_dirichlet_noise=True, sample_moves=True, seed=4242, reuse_tree=True, reuse_factor=2.0)
+    one = PortableTreeMCTS(net.variant(half_workgroups=True), 96, 40, DEV, **kw)
+    two = DualStreamTreeMCTS(net, 96, 40, DEV, **kw)
+    from liuzhou_amd import v0_core
+    s1 = batch._map(lambda t: t.clone()); s2 = batch._map(lambda t: t.clone())
+    for mv in range(3):
+        o1 = one.search_batch(s1, temperatures=temps)
+        o2 = two.search_batch(s2, temperatures=temps)
+        assert torch.equal(o1.chosen_action_indices, o2.chosen_action_indices), mv
+        assert torch.equal(o1.policy_dense, o2.policy_dense), mv
+        for s, o in ((s1, o1), (s2, o2)):
+            plies = torch.zeros(96, dtype=torch.int64, device=DEV); done = torch.zeros(96, dtype=torch.bool, device=DEV)
+            v0_core.self_play_step_inplace(*s.tensors(), plies, done, torch.arange(96, device=DEV),
+                                           o.chosen_action_codes.clone(), o.terminal_mask.clone(),
+                                           o.chosen_valid_mask.clone(), 512, 2.0)
+    # another seed plays other games
+    a = PortableTreeMCTS(net, 96, 40, DEV, **kw).search_batch(batch, temperatures=temps).chosen_action_indices.clone()
+    b = PortableTreeMCTS(net, 96, 40, DEV, **kw).search_batch(batch, temperatures=temps).chosen_action_indices.clone()
+    c = PortableTreeMCTS(net, 96, 40, DEV, **{**kw, "seed": 4243}).search_batch(batch, temperatures=temps).chosen_action_indices
+    assert torch.equal(a, b) and not torch.equal(a, c)      # same seed: same games; another seed: other games

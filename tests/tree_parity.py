@@ -331,3 +331,174 @@ def run_injected_wave_parity(device, num_games=48, sims=50, batch_k=16, moves=3,
                 trees[i] = O.OracleTree(cur[i], c)
     assert int(eng.reuse_dropped.item()) == 0
     return eng, waves_total, short_waves
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Production launch path: lz_tree_search / lz_tree_search_continue (fused expand + select kernel, priors formed in the
+# kernel from the three head rows, fused network kernel in the loop, hipGraph replay, one or two streams, subtree reuse,
+# Philox root noise and pick uniforms) replayed in the oracle from the trace the expand kernel leaves (LzTreeDesc.trace_*).
+# ---------------------------------------------------------------------------------------------------------------------
+EDGE_DT = np.dtype([("W", "<f8"), ("P", "<f4"), ("n_info", "<u4"), ("child", "<i4"), ("cbegin", "<i4"), ("act", "u1"),
+                    ("cn", "u1"), ("owner", "<u2"), ("pad", "V4")])
+NODE_DT = np.dtype([("state", "<i8", (4,)), ("edge_begin", "<i4"), ("nedges", "<i4"), ("parent", "<i4"), ("pad", "<i4")])
+
+
+def root_edges(engine):
+    """Root edge records of every game, read straight from the arena: list of structured arrays (EDGE_DT)."""
+    B = engine.B
+    nodes = engine.buf["nodes"].view(B, engine.node_cap, 6)[:, 0].contiguous().cpu().numpy().view(NODE_DT).reshape(B)
+    e_dev = engine.buf["edges"].view(B, engine.edge_cap, 4)
+    out = []
+    for g in range(B):
+        ne, e0 = int(nodes["nedges"][g]), int(nodes["edge_begin"][g])
+        if ne <= 0:
+            out.append(np.zeros(0, EDGE_DT))
+            continue
+        out.append(e_dev[g, e0:e0 + ne].contiguous().cpu().numpy().view(EDGE_DT).reshape(ne))
+    return out
+
+
+def _states_equal(leaf, rows, want_states, what):
+    want = O.batch_from_states(want_states)
+    for f in FIELDS:
+        a = np.asarray(leaf[f])[rows].reshape(len(rows), -1).astype(np.int64)
+        b = np.asarray(want[f]).reshape(len(rows), -1).astype(np.int64)
+        assert np.array_equal(a, b), f"{what}: leaf state field {f} differs from the oracle's pending state"
+
+
+def replay_part_in_oracle(part, trees, move, c_eps, check_net=None, float_tol=1e-6):
+    """One searched move of one engine (`part`: PortableTreeMCTS built with trace=True) against the oracle trees of its
+    games.  Float part: the priors the kernel formed from the head rows are within `float_tol` of the oracle's
+    projection of the same rows.  Integer part: fed the kernel's own per-step priors and values, the oracle must ask for
+    the same leaf state at every step and end with bit-identical visit counts, value sums (f64) and priors at the root."""
+    e = part.engine
+    S, n = part.sims, e.B
+    tr = {k: v.cpu().numpy() for k, v in e.trace.items()}
+    kind, val = tr["trace_kind"], tr["trace_value"]
+    leaf = unpack_packed(tr["trace_leaf"].reshape(-1, 4))
+    heads, pri = tr["trace_heads"], tr["trace_priors"]
+    noise = part._noise_buf.cpu().numpy()
+    stats = dict(evals=0, kept=0, max_prior_err=0.0)
+    for s in range(S + 1):
+        pend = [t.prepare_root() if s == 0 else t.select() for t in trees]
+        assert np.array_equal(kind[s] == 1, np.array(pend)), \
+            f"move {move} step {s}: GPU and oracle disagree on which games need an evaluation"
+        if s == 0:
+            kept = np.array([(not p) and (not t.root_terminal()) and t.root_children()[0].size > 0
+                             for p, t in zip(pend, trees)])
+            assert np.array_equal(kind[0] == 3, kept), f"move {move}: kept roots differ"
+            stats["kept"] += int(kept.sum())
+        need = np.nonzero(pend)[0]
+        if need.size:
+            ps = [trees[i].pending_state() for i in need]
+            _states_equal(leaf, s * n + need, ps, f"move {move} step {s}")
+            mask = np.zeros((need.size, 220), bool)
+            for k, cs in enumerate(ps):
+                mask[k, O.legal_indices_py(cs)] = True
+            has = mask.any(1)
+            want, _ = O.project_policy(heads[s, need, 0:36], heads[s, need, 36:72], heads[s, need, 72:108], mask)
+            err = np.abs(pri[s, need][has] - want[has]).max() if has.any() else 0.0
+            stats["max_prior_err"] = max(stats["max_prior_err"], float(err))
+            assert err <= float_tol, f"move {move} step {s}: in-kernel head -> prior softmax off by {err}"
+            assert not pri[s, need][~mask].any(), "prior mass on an illegal action"
+            if check_net is not None:
+                check_net(s, need, tr["trace_leaf"][s, need], heads[s, need], val[s, need])
+            stats["evals"] += int(need.size)
+        for i in need:
+            trees[i].complete(pri[s, i], float(val[s, i]), noise[i] if (s == 0 and c_eps is not None) else None,
+                              0.25 if c_eps is None else c_eps)
+        if s == 0 and c_eps is not None:
+            for i in np.nonzero(kept)[0]:
+                trees[i].root_noise(noise[i], c_eps)
+    # ---- after the search: the root's statistics, bit for bit ----
+    edges = root_edges(e)
+    term = e.terminal_mask.cpu().numpy()
+    rv = e.root_value.cpu().numpy()
+    for i, t in enumerate(trees):
+        if t.root_terminal():
+            assert term[i], (move, i)
+            continue
+        idx, vis, vs, pr, _pl = t.root_children()
+        E = edges[i]
+        assert np.array_equal(E["act"].astype(np.int64), idx.astype(np.int64)), (move, i)
+        assert np.array_equal((E["n_info"] & 0xFFFFFF).astype(np.int64), vis.astype(np.int64)), \
+            (move, i, "visit counts differ")
+        assert np.array_equal(E["W"].view(np.uint64), vs.astype(np.float64).view(np.uint64)), (move, i, "W sums differ")
+        assert np.array_equal(E["P"].view(np.uint32), pr.astype(np.float32).view(np.uint32)), (move, i, "priors differ")
+        assert abs(float(rv[i]) - t.root_value_sum() / max(1, t.root_visits())) < 1e-6
+    return stats
+
+
+def run_production_parity(device, model_name="b6c64", num_games=128, sims=200, moves=3, dual=False, seed=0, use_graph=True,
+                          noise=True, temperature=1.0, reuse_factor=4.0, rng_seed=777):
+    """bench.py's search (PortableTreeMCTS / DualStreamTreeMCTS with the fused network, hipGraph, subtree reuse, Philox
+    noise and sampled moves) over `moves` consecutive moves from a mixed-phase batch, replayed in the oracle."""
+    from liuzhou_amd.net import ChessNet, MODEL_CONFIGS
+    from liuzhou_amd.net_hip import FusedNet
+    from liuzhou_amd.tree_engine import DualStreamTreeMCTS, PortableTreeMCTS
+    from tests.golden_utils import load, states as gstates
+    dev = torch.device(device)
+    torch.manual_seed(20260314)
+    net = FusedNet(ChessNet(**MODEL_CONFIGS[model_name]).eval().to(dev))
+    z = load("g1_rules.npz")
+    st_all = gstates(z, "s")
+    rng = np.random.default_rng(seed)
+    idx0 = rng.integers(0, st_all["board"].shape[0], num_games)
+    states = {f: np.ascontiguousarray(np.asarray(st_all[f])[idx0]) for f in FIELDS}
+    B = num_games
+    kw = dict(exploration_weight=1.0, add_dirichlet_noise=noise, dirichlet_alpha=0.3, dirichlet_epsilon=0.25,
+              sample_moves=True, use_graph=use_graph, reuse_tree=True, reuse_factor=reuse_factor, trace=True, seed=rng_seed)
+    mcts = (DualStreamTreeMCTS if dual else PortableTreeMCTS)(net, B, sims, dev, **kw)
+    parts = list(zip(mcts.bounds, mcts.parts)) if dual else [((0, B), mcts)]
+    cur = [O.state_from_batch(states, i) for i in range(B)]
+    trees = [O.OracleTree(cur[i], 1.0) for i in range(B)]
+    totals = dict(evals=0, kept=0, max_prior_err=0.0, net_max_err=0.0)
+
+    def check_net_factory(part):
+        def check(s, need, packed, heads, values):
+            # the network launch inside the captured search evaluated exactly these states: an independent launch of the
+            # same kernel configuration on them gives the same head rows and values
+            lp1, lp2, lpm, _, v = part.net.forward_packed(torch.from_numpy(np.ascontiguousarray(packed)).to(dev))
+            got = torch.cat([lp1, lp2, lpm], dim=1).cpu().numpy()
+            d = max(float(np.abs(got - heads).max()), float(np.abs(v.cpu().numpy() - values).max()))
+            totals["net_max_err"] = max(totals["net_max_err"], d)
+            assert d <= 1e-6, f"step {s}: network rows inside the captured search differ from a direct launch by {d}"
+        return check
+
+    for mv in range(moves):
+        batch = to_gpu_batch(O.batch_from_states(cur), dev)
+        temps = torch.full((B,), float(temperature), dtype=torch.float32, device=dev)
+        out = mcts.search_batch(batch, temperatures=temps)
+        torch.cuda.synchronize(dev)
+        chosen = out.chosen_action_indices.cpu().numpy()
+        pol = out.policy_dense.cpu().numpy()
+        for (a, b), part in parts:
+            st = replay_part_in_oracle(part, trees[a:b], mv, 0.25 if noise else None,
+                                       check_net=check_net_factory(part) if mv == 0 else None)
+            for k in ("evals", "kept"):
+                totals[k] += st[k]
+            totals["max_prior_err"] = max(totals["max_prior_err"], st["max_prior_err"])
+            assert int(part.engine.reuse_dropped.item()) == 0
+            u = part._uniforms.cpu().numpy()
+            for i in range(a, b):
+                t = trees[i]
+                if t.root_terminal():
+                    assert chosen[i] == -1
+                    continue
+                idx, vis, _vs, _pr, _pl = t.root_children()
+                assert int(vis.sum()) == t.root_visits()
+                want = np.zeros(220, np.float32); want[idx] = O.policy_from_visits(vis, temperature)
+                np.testing.assert_allclose(pol[i], want, atol=1e-6, rtol=0)
+                # sampled pick: inverse CDF of the selection policy over the children in ascending action order
+                k = int(np.nonzero(idx == chosen[i])[0][0])
+                cum = np.cumsum(want[idx].astype(np.float64))
+                assert want[idx][k] > 0 and cum[k] > u[i - a] - 1e-6 and (k == 0 or cum[k - 1] <= u[i - a] + 1e-6), \
+                    (mv, i, "pick is not the inverse-CDF sample of the policy")
+        for i in range(B):
+            if trees[i].root_terminal():
+                continue
+            pick = int(chosen[i])
+            cur[i] = O.apply_index(cur[i], pick)
+            if not trees[i].advance(pick):
+                trees[i] = O.OracleTree(cur[i], 1.0)
+    return mcts, totals
