@@ -297,6 +297,19 @@ def dirichlet_noise(shape, alpha: float, device, generator=None) -> torch.Tensor
     return g
 
 
+class PriorEvaluator:
+    """External evaluator of the split-phase protocol in the reference's own form (`PortableCppTreeBatch`:
+    prepare roots -> evaluate -> complete(priors, values), v1/python/portable_cpp_mcts.py:270-282):
+    `fn(planes float32[B,11,6,6], packed_states int64[B,4]) -> (priors float32[B,220], values float32[B])`, both on the
+    engine's device; the priors are used as given (renormalised over the legal set by the expand kernel)."""
+
+    def __init__(self, fn) -> None:
+        self.fn = fn
+
+    def __call__(self, planes: torch.Tensor, packed: torch.Tensor):
+        return self.fn(planes, packed)
+
+
 class PortableTreeMCTS:
     """Full-tree search with the V1RootMCTS calling convention (search_batch -> RootSearchBatchOutput)."""
 
@@ -329,7 +342,7 @@ class PortableTreeMCTS:
         if not self.fused:
             if self.batch_k > 1:
                 raise ValueError("an external evaluator supports batch_k = 1 only")
-            self._eval_device = next(net.parameters()).device
+            self._eval_device = None if isinstance(net, PriorEvaluator) else next(net.parameters()).device
         self.rng = GameRng(num_games, device, seed=seed, game_offset=game_offset, game_stride=game_stride)
         self._uniforms = torch.zeros((self.engine.B,), dtype=torch.float32, device=self.engine.device)
         self.injected_noise: Optional[torch.Tensor] = None       # parity runs: [B, <= OUT_CAP] instead of the RNG's draws
@@ -410,6 +423,11 @@ class PortableTreeMCTS:
         for s in range(self.sims + 1):
             if s > 0:
                 e.select()
+            if isinstance(self.net, PriorEvaluator):
+                pri, val = self.net(e.leaf_planes(), e.buf["leaf_state"])
+                e.expand(is_root=(s == 0), values=val.to(torch.float32).contiguous(),
+                         priors220=pri.to(torch.float32).contiguous(), noise=noise if s == 0 else None, epsilon=self.eps)
+                continue
             lp1, lp2, lpm, val = self._evaluate_external(e.leaf_planes())
             e.expand(is_root=(s == 0), values=val, heads=(lp1, lp2, lpm), noise=noise if s == 0 else None,
                      epsilon=self.eps)
@@ -757,7 +775,8 @@ def self_play_tree_gpu(model, num_games: int, mcts_simulations: int, temperature
                        collect_timing: bool = False) -> Tuple[TensorSelfPlayBatch, SelfPlayV1Stats]:
     """Tree-search twin of self_play_v1_gpu (same outputs); mirrors v1/python/portable_self_play.py:82-284,
     including the subtree reuse it performs on every move (:191, `reuse_tree`).
-    `evaluator`: "fused" = the hand-written fp16 network kernel inside the captured search (6x64 / 10x128 nets);
+    `model` may also be a `PriorEvaluator` (states -> priors over the 220 actions + values, the reference's own
+    split-phase hand-off).  `evaluator`: "fused" = the hand-written fp16 network kernel inside the captured search (6x64 / 10x128 nets);
     "module" = `model` itself as an external fp32 evaluator behind the split-phase protocol, whatever its size or
     device (what the reference's portable runner does with its `model`); "auto" = fused when the net has a fused
     kernel.  `seed`: key of the per-game counter RNG (noise, sampled moves); game ids are the runner's game numbers."""
@@ -766,6 +785,8 @@ def self_play_tree_gpu(model, num_games: int, mcts_simulations: int, temperature
         raise ValueError(f"evaluator must be auto / fused / module, got {evaluator!r}")
     if isinstance(model, FusedNet):
         net, use_fused = model, True
+    elif isinstance(model, PriorEvaluator):
+        net, use_fused = model, False
     else:
         chans = int(model.stem_conv.out_channels) if hasattr(model, "stem_conv") else -1
         use_fused = evaluator == "fused" or (evaluator == "auto" and chans in (64, 128))

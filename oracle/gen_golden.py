@@ -660,10 +660,38 @@ def gen_tree_selfplay():
     ):
         model = small_model()
         torch.manual_seed(0); np.random.seed(0); random.seed(0)
-        batch, stats = self_play_v1_portable(
-            model=model, temperature_init=1.0, temperature_final=0.1, temperature_threshold=10,
-            exploration_weight=1.0, device="cpu", add_dirichlet_noise=False, soft_value_k=2.0,
-            opening_random_moves=0, sample_moves=False, **kw)
+        # Every network evaluation of the run (planes -> priors over the 220 actions, value), recorded at the reference's
+        # own hand-off (PortableMCTS.evaluate_states).  The tiny random net's priors are nearly uniform and the games
+        # turn on their last bits (a 1-ulp change alters the trace), and a CPU with another vector ISA rounds the
+        # convolutions differently -- a parity test on another host replays this table instead of re-evaluating.
+        from v1.python import portable_mcts as _pm
+        rec = {}
+        orig = _pm.PortableMCTS.evaluate_states
+
+        def recording(self, states, _orig=orig, _rec=rec):
+            ev = _orig(self, states)
+            planes = np.packbits(ev.model_inputs.numpy().astype(bool).reshape(len(states), -1), axis=1)
+            for i in range(len(states)):
+                key = planes[i].tobytes()
+                val = (ev.priors[i].numpy().copy(), float(ev.values[i]))
+                if key in _rec:
+                    assert np.array_equal(_rec[key][0], val[0]) and _rec[key][1] == val[1], "evaluation is not batch-invariant"
+                _rec[key] = val
+            return ev
+
+        _pm.PortableMCTS.evaluate_states = recording
+        try:
+            batch, stats = self_play_v1_portable(
+                model=model, temperature_init=1.0, temperature_final=0.1, temperature_threshold=10,
+                exploration_weight=1.0, device="cpu", add_dirichlet_noise=False, soft_value_k=2.0,
+                opening_random_moves=0, sample_moves=False, **kw)
+        finally:
+            _pm.PortableMCTS.evaluate_states = orig
+        keys = sorted(rec)
+        out[f"{tag}_eval_planes"] = np.frombuffer(b"".join(keys), np.uint8).reshape(len(keys), -1).copy()
+        out[f"{tag}_eval_priors"] = np.stack([rec[k][0] for k in keys]).astype(np.float32)
+        out[f"{tag}_eval_values"] = np.asarray([rec[k][1] for k in keys], np.float32)
+        print(f"[g10/{tag}] {len(keys)} distinct evaluated positions recorded")
         n = batch.num_samples
         out.update({
             f"{tag}_state_tensors": np.packbits(batch.state_tensors.numpy().astype(bool).reshape(n, -1), axis=1),

@@ -260,6 +260,19 @@ def make_net_evaluator(model):
     return evaluate
 
 
+def make_table_evaluator(planes_bits: np.ndarray, priors: np.ndarray, values: np.ndarray):
+    """Evaluator that replays recorded network outputs (tests/golden/g10: every position the reference run evaluated,
+    keyed by its packed input planes) -- host-independent, unlike re-evaluating the module."""
+    table = {planes_bits[i].tobytes(): i for i in range(planes_bits.shape[0])}
+
+    def evaluate(states):
+        planes = O.states_to_model_input(states)
+        keys = np.packbits(planes.astype(bool).reshape(planes.shape[0], -1), axis=1)
+        rows = [table[keys[i].tobytes()] for i in range(keys.shape[0])]
+        return priors[rows].astype(np.float32), values[rows].astype(np.float32)
+    return evaluate
+
+
 def deterministic_pick(idx, vis, vs, pr, pl, root_player: int) -> int:
     """portable_mcts.py:208-261: most visits, then Q (atol 1e-6), then prior (atol 1e-8), then lowest index."""
     q = np.where(vis > 0, np.where(pl == root_player, vs, -vs) / np.maximum(vis, 1), 0.0).astype(np.float32)
@@ -273,11 +286,12 @@ def self_play_tree(model, num_games: int, sims: int, temperature_init: float = 1
                    temperature_threshold: int = 10, c: float = 1.0, soft_k: float = 2.0, max_game_plies: int = 512,
                    concurrent_games: Optional[int] = None, reuse_tree: bool = True,
                    policy_target_temperature: Optional[float] = None, policy_target_prior_pseudocount: float = 0.0,
-                   time_budget_s: Optional[float] = None, collect: bool = False, batch_k: int = 1):
+                   time_budget_s: Optional[float] = None, collect: bool = False, batch_k: int = 1,
+                   evaluate: Optional[Callable] = None):
     """variant-P deterministic self-play (sample_moves=False, no noise): v1/python/portable_self_play.py:82-284.
     The reference keeps the played child's subtree on every move (`advance_root`, :191); `reuse_tree=False`
     rebuilds the tree instead.  Returns a stats dict (+ the 5 trajectory tensors when `collect`)."""
-    evaluate = make_net_evaluator(model)
+    evaluate = make_net_evaluator(model) if evaluate is None else evaluate     # states -> (priors220, values)
     wave = num_games if concurrent_games is None else max(1, min(int(concurrent_games), int(num_games)))
     rows: Dict[str, list] = dict(S=[], L=[], P=[], V=[], SV=[])
     positions = evals = 0

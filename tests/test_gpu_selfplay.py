@@ -314,24 +314,59 @@ def _check_tree_trace(batch, stats, z, tag):
 def test_tree_runner_reproduces_reference_portable_selfplay_trace(tag, extra):
     """g10: the reference's own portable full-tree runner (v1/python/portable_self_play.py, tiny net seed 7, subtree
     reuse on every move, deterministic picks) recorded on CPU; `self_play_tree_gpu` -- device trees, device tail, the
-    same tiny network as an external fp32 evaluator behind the split-phase protocol -- must produce the same samples."""
+    split-phase protocol with an external evaluator -- must produce the same samples.  The tiny random net gives
+    near-uniform priors, and the recorded games turn on last-bit differences of the priors (a 1-ulp perturbation changes
+    the trace at sample 12; a host CPU with another vector ISA already rounds the convolutions differently), so the
+    evaluator replays the network outputs the reference run itself produced, recorded at its own hand-off
+    (`PortableMCTS.evaluate_states` -> `PriorEvaluator`; oracle/gen_golden.py)."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     from liuzhou_amd.net import ChessNet, MODEL_CONFIGS
-    from liuzhou_amd.tree_engine import self_play_tree_gpu
+    from liuzhou_amd.tree_engine import PriorEvaluator, self_play_tree_gpu
+    from oracle import lz_oracle as O
+    from oracle import selfplay_oracle as SO
+    from tests.tree_parity import unpack_packed
     z = load("g10_tree_selfplay.npz")
     games, sims, max_plies = (int(x) for x in z[f"{tag}_config"])
-    torch.manual_seed(7)
-    model = ChessNet(**MODEL_CONFIGS["tiny"]).eval()          # evaluated on the host in fp32, like the recorded run
+    evaluate = SO.make_table_evaluator(z[f"{tag}_eval_planes"], z[f"{tag}_eval_priors"], z[f"{tag}_eval_values"])
+
+    def fn(planes, packed):
+        pri, val = evaluate(unpack_packed(packed.cpu().numpy()))
+        return torch.from_numpy(pri).to(planes.device), torch.from_numpy(val).to(planes.device)
+
     for tail in (True, False):
-        batch, stats = self_play_tree_gpu(model, num_games=games, mcts_simulations=sims, temperature_init=1.0,
+        batch, stats = self_play_tree_gpu(PriorEvaluator(fn), num_games=games, mcts_simulations=sims, temperature_init=1.0,
                                           temperature_final=0.1, temperature_threshold=10, exploration_weight=1.0,
                                           device="cuda:0", add_dirichlet_noise=False, soft_value_k=2.0,
                                           opening_random_moves=0, max_game_plies=max_plies, sample_moves=False,
-                                          concurrent_games=games, reuse_tree=True, evaluator="module",
-                                          device_tail=tail, collect_timing=tail, **extra)
+                                          concurrent_games=games, reuse_tree=True, device_tail=tail,
+                                          collect_timing=tail, **extra)
         _check_tree_trace(batch, stats, z, tag)
         if tail:      # timing buckets of the reference's runner are filled (self_play_gpu_runner.py:276-281)
             assert stats.step_timing_ms["root_puct_ms"] > 0 and stats.step_timing_calls["root_puct_ms"] > 0
             assert stats.step_timing_ms["self_play_step_ms"] > 0 and stats.step_timing_ms["finalize_ms"] > 0
             assert abs(sum(stats.step_timing_ratio.values()) - 1.0) < 1e-6
+
+
+def test_tree_runner_with_a_module_as_external_evaluator():
+    """Any module with ChessNet.forward's outputs can drive the device trees (heads -> priors formed by the expand
+    kernel): the tiny net, for which no fused kernel exists, plays whole games; samples are well-formed and the first
+    plies -- before last-bit differences of the softmax can matter -- equal the reference trace."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from liuzhou_amd.net import ChessNet, MODEL_CONFIGS
+    from liuzhou_amd.tree_engine import self_play_tree_gpu
+    z = load("g10_tree_selfplay.npz")
+    games, sims, max_plies = (int(x) for x in z["a_config"])
+    torch.manual_seed(7)
+    model = ChessNet(**MODEL_CONFIGS["tiny"]).eval().to("cuda:0")
+    batch, stats = self_play_tree_gpu(model, num_games=games, mcts_simulations=sims, temperature_init=1.0,
+                                      temperature_final=0.1, temperature_threshold=10, exploration_weight=1.0,
+                                      device="cuda:0", add_dirichlet_noise=False, sample_moves=False,
+                                      max_game_plies=max_plies, concurrent_games=games, evaluator="module")
+    assert batch.num_samples == games * max_plies
+    n = z["a_policy_targets"].shape[0]
+    want = np.unpackbits(z["a_state_tensors"], axis=1)[:, :11 * 36].reshape(n, 11, 6, 6).astype(np.float32)
+    assert np.array_equal(batch.state_tensors[:games].cpu().numpy(), want[:games])      # the opening position rows
+    assert torch.allclose(batch.policy_targets.sum(1), torch.ones(batch.num_samples, device="cuda:0"), atol=1e-5)
+    assert bool((batch.policy_targets[~batch.legal_masks] == 0).all())

