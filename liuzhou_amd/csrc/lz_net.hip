@@ -848,6 +848,10 @@ static int net_forward_impl(const LzNetDesc* d, const float* planes, const uint6
     P.fp = d->fparams;
     for (int i = 0; i < d->num_layers; ++i) P.layer_off[i] = d->layer_offsets[i];
     P.blocks = d->blocks;
+    // timing experiment only (results are wrong): every trunk conv reads the first block's weights, so the weight set
+    // fits the 4 MB XCD L2 -- bounds what L2 misses on the 5.9 MB weight set of 10x128 cost (scripts/exp_c3.py)
+    if (getenv("LZ_EXP_SAME_LAYER") && atoi(getenv("LZ_EXP_SAME_LAYER")) == 1)
+        for (int i = 3; i < 1 + 2 * d->blocks; ++i) P.layer_off[i] = d->layer_offsets[1 + ((i - 1) & 1)];
     P.n_dev = reinterpret_cast<const long long*>(n_dev);
     P.wfrag_bytes = (int)d->wfrag_bytes; P.fparams_bytes = (int)d->fparams_bytes;
     P.debug_stop = getenv("LZ_NET_DEBUG_STOP") ? atoi(getenv("LZ_NET_DEBUG_STOP")) : 0;

@@ -268,8 +268,11 @@ def make_table_evaluator(planes_bits: np.ndarray, priors: np.ndarray, values: np
     def evaluate(states):
         planes = O.states_to_model_input(states)
         keys = np.packbits(planes.astype(bool).reshape(planes.shape[0], -1), axis=1)
-        rows = [table[keys[i].tobytes()] for i in range(keys.shape[0])]
-        return priors[rows].astype(np.float32), values[rows].astype(np.float32)
+        rows = np.array([table.get(keys[i].tobytes(), -1) for i in range(keys.shape[0])], np.int64)
+        known = rows >= 0                # positions the recorded run never evaluated (finished / masked slots): zeros
+        pri = np.zeros((rows.size, priors.shape[1]), np.float32); val = np.zeros(rows.size, np.float32)
+        pri[known] = priors[rows[known]]; val[known] = values[rows[known]]
+        return pri, val
     return evaluate
 
 

@@ -298,14 +298,20 @@ def test_tree_self_play_runner_with_legacy_waves():
 
 
 def _check_tree_trace(batch, stats, z, tag):
+    """The reference's portable runner emits a game's samples when the game ends (game-major rows); the device arena
+    records ply by ply (the order of the reference's v1 GPU runner).  Every game of the fixtures runs to the ply cap,
+    so row (ply, game) of ours is row (game, ply) of the recording."""
     n = z[f"{tag}_policy_targets"].shape[0]
-    assert batch.num_samples == n
+    games, _sims, plies = (int(x) for x in z[f"{tag}_config"])
+    assert batch.num_samples == n == games * plies and stats.avg_game_length == float(plies)
+    order = torch.arange(n).view(plies, games).t().reshape(-1)              # game-major view of ply-major rows
+    g = lambda t: t.cpu()[order].numpy()
     want_states = np.unpackbits(z[f"{tag}_state_tensors"], axis=1)[:, :11 * 36].reshape(n, 11, 6, 6).astype(np.float32)
-    assert np.array_equal(batch.state_tensors.cpu().numpy(), want_states)
-    assert np.array_equal(batch.legal_masks.cpu().numpy(), np.unpackbits(z[f"{tag}_legal_masks"], axis=1)[:, :220].astype(bool))
-    np.testing.assert_allclose(batch.policy_targets.cpu().numpy(), z[f"{tag}_policy_targets"], atol=1e-5, rtol=0)
-    np.testing.assert_array_equal(batch.value_targets.cpu().numpy(), z[f"{tag}_value_targets"])
-    np.testing.assert_allclose(batch.soft_value_targets.cpu().numpy(), z[f"{tag}_soft_value_targets"], atol=1e-6, rtol=0)
+    assert np.array_equal(g(batch.state_tensors), want_states)
+    assert np.array_equal(g(batch.legal_masks), np.unpackbits(z[f"{tag}_legal_masks"], axis=1)[:, :220].astype(bool))
+    np.testing.assert_allclose(g(batch.policy_targets), z[f"{tag}_policy_targets"], atol=1e-6, rtol=0)
+    np.testing.assert_array_equal(g(batch.value_targets), z[f"{tag}_value_targets"])
+    np.testing.assert_allclose(g(batch.soft_value_targets), z[f"{tag}_soft_value_targets"], atol=1e-6, rtol=0)
     assert [stats.black_wins, stats.white_wins, stats.draws] == [int(x) for x in z[f"{tag}_outcome"]]
 
 
@@ -367,6 +373,6 @@ def test_tree_runner_with_a_module_as_external_evaluator():
     assert batch.num_samples == games * max_plies
     n = z["a_policy_targets"].shape[0]
     want = np.unpackbits(z["a_state_tensors"], axis=1)[:, :11 * 36].reshape(n, 11, 6, 6).astype(np.float32)
-    assert np.array_equal(batch.state_tensors[:games].cpu().numpy(), want[:games])      # the opening position rows
+    assert np.array_equal(batch.state_tensors[0].cpu().numpy(), want[0])      # the opening position
     assert torch.allclose(batch.policy_targets.sum(1), torch.ones(batch.num_samples, device="cuda:0"), atol=1e-5)
     assert bool((batch.policy_targets[~batch.legal_masks] == 0).all())
