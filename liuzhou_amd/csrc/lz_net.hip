@@ -276,8 +276,13 @@ struct GemmSteps {
         // weight fragments (L2) are prefetched one K step ahead into the other register pair
         if (STEP + 1 < NSTEPS) {
             constexpr int nx = STEP + 1 < NSTEPS ? STEP + 1 : STEP;
+#ifndef LZ_EXP_NO_ALOAD     /* timing experiment only: without the weight-fragment loads the results are wrong */
 #pragma unroll
             for (int j = 0; j < 2; ++j) A1[j] = load_wfrag(rw, lane16, wrow[T::row(nx)] + T::w_imm(nx, CTN) + j * 1024);
+#else
+#pragma unroll
+            for (int j = 0; j < 2; ++j) A1[j] = A0[j];
+#endif
         }
         gemm_step<C, S, TAPS9, STEM, STEP>(acc, A0, B, lds, base, row_step);
         GemmSteps<C, S, TAPS9, STEM, CTN, STEP + 1, NSTEPS>::run(acc, A1, A0, B, rw, wrow, lane16, lds, base, row_step);
