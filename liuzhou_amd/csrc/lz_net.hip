@@ -73,10 +73,14 @@ struct Cfg {
     static constexpr int NT = NPOS / 16;
     static constexpr int WAVES = W;
     static constexpr int THREADS = WAVES * 64;
-    static constexpr int CTW = 2;                   // 16-channel output tiles per wave
     static constexpr int PG = NT / 9;               // cell groups (4 or 2)
     static constexpr int CG = WAVES / PG;           // channel groups (2 or 4)
     static constexpr int CT = C / 16;               // 16-channel output tiles
+    // 16-channel output tiles per wave.  2 with 8 waves (two waves per SIMD, 256 registers each); 4 for the 4-wave
+    // workgroup of the 128-channel net (one wave per SIMD, 512 registers): every activation fragment read from LDS then
+    // feeds 4 MFMAs instead of 2, which halves the LDS operand traffic of the trunk.
+    static constexpr int CTW = CT / CG;
+    static constexpr int WAVES_PER_SIMD = (WAVES == 4 && CTW == 4) ? 1 : 2;
     static constexpr int KB = C / 32;               // 32-channel K blocks
     static constexpr int KBLOG = (KB == 1) ? 0 : (KB == 2) ? 1 : 2;
     // bytes per cell row: an ODD number of 16-byte slots (9 or 17), part of the conflict-free operand layout below
@@ -215,7 +219,7 @@ __device__ __forceinline__ int act_addr(int n, int chunk) {
 // Register budget (one wave per SIMD, 512 registers): 288 accumulators (residual stream + conv1 output),
 // weight fragments double-buffered across K steps (2 x 4 x 4), activation fragments in a 2-deep ring
 // that runs one cell tile ahead of the MFMAs.
-typedef f4 Acc[9][2];
+template <int NW> using AccT = f4[9][NW];      // [cell tile][channel tile of the wave]
 
 // Compile-time schedule of the K steps of one conv.  3x3: rows in the order {own, towards the centre, towards the
 // edge} (the walk starts and ends on the cell's own row, where `base` points for the 1x1 convs and the stores), three
@@ -246,8 +250,8 @@ struct Steps {
 // two MFMAs) and overlap the matrix pipe instead of forming a separate read phase.  The counted lgkmcnt waits
 // the compiler derives from this order leave 8 reads in flight.  Tile-taps that are out of board for the whole
 // tile issue neither the MFMAs nor the read.
-template <int C, int S, bool TAPS9, bool STEM, int STEP>
-__device__ __forceinline__ void gemm_step(Acc& acc, const h8 (&A)[2], h8 (&B)[9], const unsigned char* lds,
+template <int C, int S, bool TAPS9, bool STEM, int STEP, int NW>
+__device__ __forceinline__ void gemm_step(AccT<NW>& acc, const h8 (&A)[NW], h8 (&B)[9], const unsigned char* lds,
                                           int (&base)[9], int row_step) {
     using T = Steps<C, S, TAPS9, STEM>;
     constexpr bool more = STEP + 1 < T::N;
@@ -256,7 +260,7 @@ __device__ __forceinline__ void gemm_step(Acc& acc, const h8 (&A)[2], h8 (&B)[9]
     for (int i = 0; i < 9; ++i) {
         if (T::live(i, STEP)) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[j], B[i], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < NW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[j], B[i], acc[i][j], 0, 0, 0);
         }
         if (shift != 0) base[i] += shift * row_step;
 #ifndef LZ_EXP_NO_BRELOAD   /* timing experiment only: without the LDS operand reloads the results are wrong */
@@ -267,9 +271,9 @@ __device__ __forceinline__ void gemm_step(Acc& acc, const h8 (&A)[2], h8 (&B)[9]
     }
 }
 
-template <int C, int S, bool TAPS9, bool STEM, int CTN, int STEP, int NSTEPS>
+template <int C, int S, bool TAPS9, bool STEM, int CTN, int STEP, int NSTEPS, int NW>
 struct GemmSteps {
-    static __device__ __forceinline__ void run(Acc& acc, h8 (&A0)[2], h8 (&A1)[2], h8 (&B)[9], __amdgpu_buffer_rsrc_t rw,
+    static __device__ __forceinline__ void run(AccT<NW>& acc, h8 (&A0)[NW], h8 (&A1)[NW], h8 (&B)[9], __amdgpu_buffer_rsrc_t rw,
                                                const int (&wrow)[3], int lane16, const unsigned char* lds,
                                                int (&base)[9], int row_step) {
         using T = Steps<C, S, TAPS9, STEM>;
@@ -278,19 +282,19 @@ struct GemmSteps {
             constexpr int nx = STEP + 1 < NSTEPS ? STEP + 1 : STEP;
 #ifndef LZ_EXP_NO_ALOAD     /* timing experiment only: without the weight-fragment loads the results are wrong */
 #pragma unroll
-            for (int j = 0; j < 2; ++j) A1[j] = load_wfrag(rw, lane16, wrow[T::row(nx)] + T::w_imm(nx, CTN) + j * 1024);
+            for (int j = 0; j < NW; ++j) A1[j] = load_wfrag(rw, lane16, wrow[T::row(nx)] + T::w_imm(nx, CTN) + j * 1024);
 #else
 #pragma unroll
-            for (int j = 0; j < 2; ++j) A1[j] = A0[j];
+            for (int j = 0; j < NW; ++j) A1[j] = A0[j];
 #endif
         }
-        gemm_step<C, S, TAPS9, STEM, STEP>(acc, A0, B, lds, base, row_step);
-        GemmSteps<C, S, TAPS9, STEM, CTN, STEP + 1, NSTEPS>::run(acc, A1, A0, B, rw, wrow, lane16, lds, base, row_step);
+        gemm_step<C, S, TAPS9, STEM, STEP, NW>(acc, A0, B, lds, base, row_step);
+        GemmSteps<C, S, TAPS9, STEM, CTN, STEP + 1, NSTEPS, NW>::run(acc, A1, A0, B, rw, wrow, lane16, lds, base, row_step);
     }
 };
-template <int C, int S, bool TAPS9, bool STEM, int CTN, int NSTEPS>
-struct GemmSteps<C, S, TAPS9, STEM, CTN, NSTEPS, NSTEPS> {
-    static __device__ __forceinline__ void run(Acc&, h8 (&)[2], h8 (&)[2], h8 (&)[9], __amdgpu_buffer_rsrc_t,
+template <int C, int S, bool TAPS9, bool STEM, int CTN, int NSTEPS, int NW>
+struct GemmSteps<C, S, TAPS9, STEM, CTN, NSTEPS, NSTEPS, NW> {
+    static __device__ __forceinline__ void run(AccT<NW>&, h8 (&)[NW], h8 (&)[NW], h8 (&)[9], __amdgpu_buffer_rsrc_t,
                                                const int (&)[3], int, const unsigned char*, int (&)[9], int) {}
 };
 
@@ -302,29 +306,29 @@ struct GemmSteps<C, S, TAPS9, STEM, CTN, NSTEPS, NSTEPS> {
 // first two weight fragments of a layer (own row, left tap -- the same for both mirror states): issued a whole
 // phase early (before the barrier / LDS store phase that precedes the conv) so their L2 latency never sits on the
 // critical path
-template <int C, int S, bool TAPS9, bool STEM, int CTN>
+template <int C, int S, bool TAPS9, bool STEM, int CTN, int NW>
 __device__ __forceinline__ void load_first_frags(__amdgpu_buffer_rsrc_t rw, int layer_half_off, int ct0, int lane,
-                                                 h8 (&A0)[2]) {
+                                                 h8 (&A0)[NW]) {
     using T = Steps<C, S, TAPS9, STEM>;
     const int wbyte = __builtin_amdgcn_readfirstlane(layer_half_off * 2 + ct0 * 1024) + T::w_row_bytes(CTN);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) A0[j] = load_wfrag(rw, lane * 16, wbyte + j * 1024);
+    for (int j = 0; j < NW; ++j) A0[j] = load_wfrag(rw, lane * 16, wbyte + j * 1024);
 }
 
-template <int C, int S, bool TAPS9, bool STEM, int CTN>
-__device__ __forceinline__ void conv_gemm(Acc& acc, __amdgpu_buffer_rsrc_t rw, int layer_half_off, int ct0,
-                                          const unsigned char* lds, int (&base)[9], int lane, h8 (&A0)[2],
+template <int C, int S, bool TAPS9, bool STEM, int CTN, int NW>
+__device__ __forceinline__ void conv_gemm(AccT<NW>& acc, __amdgpu_buffer_rsrc_t rw, int layer_half_off, int ct0,
+                                          const unsigned char* lds, int (&base)[9], int lane, h8 (&A0)[NW],
                                           bool mirror, int row_step) {
     using T = Steps<C, S, TAPS9, STEM>;
     const int wbyte = __builtin_amdgcn_readfirstlane(layer_half_off * 2 + ct0 * 1024);
     const int wrow[3] = {wbyte + (mirror ? 2 : 0) * T::w_row_bytes(CTN), wbyte + T::w_row_bytes(CTN),
                          wbyte + (mirror ? 0 : 2) * T::w_row_bytes(CTN)};
     const int lane16 = lane * 16;
-    h8 A1[2], B[9];
+    h8 A1[NW], B[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i)
         if (T::live(i, 0)) B[i] = *reinterpret_cast<const h8*>(lds + base[i] + T::lds_imm(0));
-    GemmSteps<C, S, TAPS9, STEM, CTN, 0, T::N>::run(acc, A0, A1, B, rw, wrow, lane16, lds, base, row_step);
+    GemmSteps<C, S, TAPS9, STEM, CTN, 0, T::N, NW>::run(acc, A0, A1, B, rw, wrow, lane16, lds, base, row_step);
 }
 
 // workgroup barrier that only orders LDS traffic: prefetched global loads stay in flight across it
@@ -350,12 +354,17 @@ __device__ __forceinline__ h4 to_h4(float a, float b, float c, float d) {
 
 // write relu(scale*acc + shift) (per channel) as fp16 rows; `chan_base` = first channel of co tile 0
 // per-channel parameters of this lane's 2 x 4 channels (issued early, consumed by store_act)
+template <int NW>
 __device__ __forceinline__ void load_chan_params(__amdgpu_buffer_rsrc_t rf, int float_off, int chan_base, int lane,
-                                                 f4 (&v)[2]) {
+                                                 f4 (&v)[NW]) {
     const int sub = (lane >> 4) * 4;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) v[j] = load_f4(rf, sub, float_off + chan_base + j * 16);
+    for (int j = 0; j < NW; ++j) v[j] = load_f4(rf, sub, float_off + chan_base + j * 16);
 }
+// byte offset of the lane's store for channel tile j of the wave, relative to tile 0: tiles 0 / 1 sit 4 chunk positions
+// (64 B) apart; tiles 2 / 3 (4 tiles per wave: chan_base is then a multiple of 64) are the interleaved K block, one
+// position (16 B) further (chunk_pos)
+__host__ __device__ constexpr int store_off(int j) { return (j & 1) * 64 + (j >> 1) * 16; }
 
 // The store address of the lane's cell in tile i is derived from base[i] (the read address of its left
 // neighbour + the lane's K chunk): row(cell) = base[i] + STRIDE - 32*(lane>>4); the lane writes channels
@@ -368,17 +377,17 @@ __device__ __forceinline__ int store_delta(int chan_base, int lane) {
     return K::STRIDE - 32 * q + (chunk_pos(chan_base >> 3) << 4) + 32 * (q >> 1) + 8 * (q & 1);
 }
 
-template <int C, int S, bool HAS_SCALE>
-__device__ __forceinline__ void store_act(const Acc& acc, unsigned char* lds, const int (&base)[9], int chan_base,
-                                          const f4 (&sc)[2], const f4 (&sh)[2], int lane) {
+template <int C, int S, bool HAS_SCALE, int NW>
+__device__ __forceinline__ void store_act(const AccT<NW>& acc, unsigned char* lds, const int (&base)[9], int chan_base,
+                                          const f4 (&sc)[NW], const f4 (&sh)[NW], int lane) {
     const int delta = store_delta<C, S>(chan_base, lane);
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < NW; ++j) {
             f4 v = acc[i][j];
             if (HAS_SCALE) v = fma4(v, sc[j], sh[j]); else v = v + sh[j];
-            *reinterpret_cast<h4*>(lds + base[i] + delta + j * 64) = relu_h4(v);
+            *reinterpret_cast<h4*>(lds + base[i] + delta + store_off(j)) = relu_h4(v);
         }
     }
 }
@@ -439,33 +448,35 @@ __device__ __forceinline__ f4 fc_tile(__amdgpu_buffer_rsrc_t rw, int half_off, i
 }
 
 // write one head map (64 channels wide) from a wave's 2 output tiles: channel = (tile_in_map*16) + ...
-template <int C, int S>
-__device__ __forceinline__ void store_head(const Acc& acc, unsigned char* lds, const int (&base)[9], int map_tile0,
+template <int C, int S, int NW>
+__device__ __forceinline__ void store_head(const AccT<NW>& acc, unsigned char* lds, const int (&base)[9], int map_tile0,
                                            __amdgpu_buffer_rsrc_t rf, int bias_off, int lane) {
     const int sub = (lane >> 4) * 4;
     const int delta = store_delta<C, S>(map_tile0 * 16, lane);
-    f4 b[2];
+    f4 b[NW];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) b[j] = load_f4(rf, sub, bias_off + (map_tile0 + j) * 16);
+    for (int j = 0; j < NW; ++j) b[j] = load_f4(rf, sub, bias_off + (map_tile0 + j) * 16);
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < NW; ++j) {
             const f4 v = acc[i][j] + b[j];
-            *reinterpret_cast<h4*>(lds + base[i] + delta + j * 64) = relu_h4(v);
+            *reinterpret_cast<h4*>(lds + base[i] + delta + store_off(j)) = relu_h4(v);
         }
     }
 }
 
 template <int C, int S, int W>
-__global__ __launch_bounds__(W * 64, 2) void net_forward_kernel(NetParams P, const float* __restrict__ planes,
+__global__ __launch_bounds__(W * 64, (C == 128 && W == 4) ? 1 : 2) void net_forward_kernel(NetParams P, const float* __restrict__ planes,
                                                             const uint64_t* __restrict__ packed,
                                                             int64_t N, float* __restrict__ lp1,
                                                             float* __restrict__ lp2, float* __restrict__ lpm,
                                                             float* __restrict__ vlogits, float* __restrict__ value) {
     using K = Cfg<C, S, W>;
     if (P.n_dev != nullptr) { const long long nd = *P.n_dev; N = nd < N ? nd : N; }   // count produced on the device
-    static_assert(K::CT == K::CG * K::CTW, "each wave owns 2 output-channel tiles");
+    static_assert(K::CT == K::CG * K::CTW && (K::CTW == 2 || K::CTW == 4), "each wave owns 2 or 4 output-channel tiles");
+    constexpr int NW = K::CTW;
+    using Acc = AccT<NW>;
     static_assert(K::NT % 9 == 0 && K::PG * K::CG == K::WAVES, "waves = cell groups x channel groups");
     static_assert(S * 32 <= K::THREADS, "global pooling uses 2 lanes per (sample, 4-channel group)");
     constexpr int NTHR = K::THREADS;
@@ -558,15 +569,15 @@ __global__ __launch_bounds__(W * 64, 2) void net_forward_kernel(NetParams P, con
 #pragma unroll
         for (int i = 0; i < 9; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) x[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
-        h8 Af[2];                                              // first weight fragments of the upcoming conv
-        f4 pa[2], pb[2];                                       // per-channel parameters of the upcoming store
+            for (int j = 0; j < NW; ++j) x[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
+        h8 Af[NW];                                              // first weight fragments of the upcoming conv
+        f4 pa[NW], pb[NW];                                       // per-channel parameters of the upcoming store
         // ---- stem: x = relu(conv(planes) + bias) ----
-        load_first_frags<C, S, true, true, K::CT>(rw, P.layer_off[0], ct0, lane, Af);
-        load_chan_params(rf, P.stem_bias, chan0, lane, pb);
-        conv_gemm<C, S, true, true, K::CT>(x, rw, P.layer_off[0], ct0, lds, base, lane, Af, mirror, row_step);
+        load_first_frags<C, S, true, true, K::CT, NW>(rw, P.layer_off[0], ct0, lane, Af);
+        load_chan_params<NW>(rf, P.stem_bias, chan0, lane, pb);
+        conv_gemm<C, S, true, true, K::CT, NW>(x, rw, P.layer_off[0], ct0, lds, base, lane, Af, mirror, row_step);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < NW; ++j) {
 #pragma unroll
             for (int i = 0; i < 9; ++i) {
                 f4 v = x[i][j] + pb[j];
@@ -583,31 +594,31 @@ __global__ __launch_bounds__(W * 64, 2) void net_forward_kernel(NetParams P, con
 #endif
         for (int blk = 0; blk < P.blocks; ++blk) {
             const int bp = P.blk0 + blk * 3 * C;               // float offsets: a1 | b1 | bias1
-            load_chan_params(rf, bp, chan0, lane, pa);
-            load_chan_params(rf, bp + C, chan0, lane, pb);
-            load_first_frags<C, S, true, false, K::CT>(rw, P.layer_off[1 + 2 * blk], ct0, lane, Af);
+            load_chan_params<NW>(rf, bp, chan0, lane, pa);
+            load_chan_params<NW>(rf, bp + C, chan0, lane, pb);
+            load_first_frags<C, S, true, false, K::CT, NW>(rw, P.layer_off[1 + 2 * blk], ct0, lane, Af);
             LZ_STAMP(0)
             lds_barrier();                                     // everyone finished reading the act buffer
             LZ_STAMP(1)
-            store_act<C, S, true>(x, lds, base, chan0, pa, pb, lane);                 // t = relu(a1*x + b1)
-            load_chan_params(rf, bp + 2 * C, chan0, lane, pb);                          // bias1, used after conv1
+            store_act<C, S, true, NW>(x, lds, base, chan0, pa, pb, lane);                 // t = relu(a1*x + b1)
+            load_chan_params<NW>(rf, bp + 2 * C, chan0, lane, pb);                          // bias1, used after conv1
             LZ_STAMP(2)
             lds_barrier();
             LZ_STAMP(3)
 #pragma unroll
             for (int i = 0; i < 9; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
-            conv_gemm<C, S, true, false, K::CT>(acc, rw, P.layer_off[1 + 2 * blk], ct0, lds, base, lane, Af, mirror, row_step);
-            load_first_frags<C, S, true, false, K::CT>(rw, P.layer_off[2 + 2 * blk], ct0, lane, Af);
+                for (int j = 0; j < NW; ++j) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
+            conv_gemm<C, S, true, false, K::CT, NW>(acc, rw, P.layer_off[1 + 2 * blk], ct0, lds, base, lane, Af, mirror, row_step);
+            load_first_frags<C, S, true, false, K::CT, NW>(rw, P.layer_off[2 + 2 * blk], ct0, lane, Af);
             LZ_STAMP(4)
             lds_barrier();
             LZ_STAMP(5)
-            store_act<C, S, false>(acc, lds, base, chan0, pb, pb, lane);               // u = relu(conv1 + bias1)
+            store_act<C, S, false, NW>(acc, lds, base, chan0, pb, pb, lane);               // u = relu(conv1 + bias1)
             LZ_STAMP(6)
             lds_barrier();
             LZ_STAMP(7)
-            conv_gemm<C, S, true, false, K::CT>(x, rw, P.layer_off[2 + 2 * blk], ct0, lds, base, lane, Af, mirror, row_step);  // x += conv2(u)
+            conv_gemm<C, S, true, false, K::CT, NW>(x, rw, P.layer_off[2 + 2 * blk], ct0, lds, base, lane, Af, mirror, row_step);  // x += conv2(u)
             LZ_STAMP(8)
         }
 #ifdef LZ_EXP_STAMPS
@@ -622,27 +633,27 @@ __global__ __launch_bounds__(W * 64, 2) void net_forward_kernel(NetParams P, con
         const int wh = P.layer_off[1 + 2 * P.blocks];
         const int ht0 = cg * K::CTW;                               // head tile of acc   (0..7)
         const int ht1 = K::CG * K::CTW + cg * K::CTW;              // head tile of x     (HP == 2 only)
-        load_chan_params(rf, P.trunk_a, chan0, lane, pa);
-        load_chan_params(rf, P.trunk_b, chan0, lane, pb);
-        load_first_frags<C, S, false, false, 8>(rw, wh, ht0, lane, Af);
+        load_chan_params<NW>(rf, P.trunk_a, chan0, lane, pa);
+        load_chan_params<NW>(rf, P.trunk_b, chan0, lane, pb);
+        load_first_frags<C, S, false, false, 8, NW>(rw, wh, ht0, lane, Af);
         lds_barrier();
-        store_act<C, S, true>(x, lds, base, chan0, pa, pb, lane);
+        store_act<C, S, true, NW>(x, lds, base, chan0, pa, pb, lane);
         lds_barrier();
 #pragma unroll
         for (int i = 0; i < 9; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) { acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f}; x[i][j] = (f4){0.f, 0.f, 0.f, 0.f}; }
+            for (int j = 0; j < NW; ++j) { acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f}; x[i][j] = (f4){0.f, 0.f, 0.f, 0.f}; }
         // pass 0 -> acc, pass 1 (only when 4 waves' worth of tiles cover half of the 8 head tiles) -> x
-        conv_gemm<C, S, false, false, 8>(acc, rw, wh, ht0, lds, base, lane, Af, mirror, row_step);
+        conv_gemm<C, S, false, false, 8, NW>(acc, rw, wh, ht0, lds, base, lane, Af, mirror, row_step);
         if (K::HP == 2) {
-            load_first_frags<C, S, false, false, 8>(rw, wh, ht1, lane, Af);
-            conv_gemm<C, S, false, false, 8>(x, rw, wh, ht1, lds, base, lane, Af, mirror, row_step);
+            load_first_frags<C, S, false, false, 8, NW>(rw, wh, ht1, lane, Af);
+            conv_gemm<C, S, false, false, 8, NW>(x, rw, wh, ht1, lds, base, lane, Af, mirror, row_step);
         }
         __syncthreads();
         if (P.debug_stop == 4) { if (lane == 0 && (acc[0][0][0] + x[0][0][0]) == 123.f) lp1[0] = 1.f; continue; }   // after head convs
         // ---- policy head (skipped when the caller only wants values: lp1 == nullptr) ----
         if (lp1 != nullptr) {
-        if (ht0 < 4) store_head<C, S>(acc, lds, base, ht0, rf, P.head_bias, lane);
+        if (ht0 < 4) store_head<C, S, NW>(acc, lds, base, ht0, rf, P.head_bias, lane);
         __syncthreads();
         gpool64<C, S>(lds, tid_h);
         __syncthreads();
@@ -701,8 +712,8 @@ __global__ __launch_bounds__(W * 64, 2) void net_forward_kernel(NetParams P, con
         }
         if (P.debug_stop == 5) { if (lane_h == 0 && x[0][0][0] == 123.f) lp1[0] = 1.f; continue; }   // after the policy head
         // ---- value head ----
-        if (K::HP == 2) store_head<C, S>(x, lds, base, ht1 - 4, rf, P.head_bias + kHead, lane);
-        else if (ht0 >= 4) store_head<C, S>(acc, lds, base, ht0 - 4, rf, P.head_bias + kHead, lane);
+        if (K::HP == 2) store_head<C, S, NW>(x, lds, base, ht1 - 4, rf, P.head_bias + kHead, lane);
+        else if (ht0 >= 4) store_head<C, S, NW>(acc, lds, base, ht0 - 4, rf, P.head_bias + kHead, lane);
         __syncthreads();
         gpool64<C, S>(lds, tid_h);
         __syncthreads();
@@ -834,8 +845,9 @@ int lz_prof_net_busy(double* busy_ms) {
 }
 
 int lz_net_configure(void) {
-    const int a = configure_net<64, 16, 8>(), b = configure_net<128, 8, 8>(), c = configure_net<64, 8, 4>();
-    return a != LZ_OK ? a : (b != LZ_OK ? b : c);
+    const int a = configure_net<64, 16, 8>(), b = configure_net<128, 8, 8>(), c = configure_net<64, 8, 4>(),
+              e = configure_net<128, 8, 4>();
+    return a != LZ_OK ? a : (b != LZ_OK ? b : (c != LZ_OK ? c : e));
 }
 
 static int net_forward_impl(const LzNetDesc* d, const float* planes, const uint64_t* packed, int64_t N, float* lp1,
@@ -875,11 +887,15 @@ static int net_forward_impl(const LzNetDesc* d, const float* planes, const uint6
     if (prof) (void)hipEventRecord(g_prof.ev[2 * g_prof.used], st);
     // Two 4-wave workgroups of 8 samples per CU (<64,8,4>) were measured, also staggered by half a layer: 9 % fewer
     // shader cycles per pass, but the chip then holds 1.87 GHz instead of 2.05 GHz -- the same wall time.
+    // flags bit 1 (128 channels): 4-wave workgroups, one wave per SIMD with 512 registers and 4 channel tiles per wave
+    // (half the LDS operand reads of the 8-wave shape)
+    const bool wide = d->channels == 128 && (d->flags & 2);
     const int rc = d->channels == 64
                        ? (half_wg
                               ? launch_net<64, 8, 4>(P, planes, packed, N, lp1, lp2, lpmc, value_logits, value, max_blocks, st)
                               : launch_net<64, 16, 8>(P, planes, packed, N, lp1, lp2, lpmc, value_logits, value, max_blocks, st))
-                       : launch_net<128, 8, 8>(P, planes, packed, N, lp1, lp2, lpmc, value_logits, value, max_blocks, st);
+                       : (wide ? launch_net<128, 8, 4>(P, planes, packed, N, lp1, lp2, lpmc, value_logits, value, max_blocks, st)
+                               : launch_net<128, 8, 8>(P, planes, packed, N, lp1, lp2, lpmc, value_logits, value, max_blocks, st));
     if (prof) { (void)hipEventRecord(g_prof.ev[2 * g_prof.used + 1], st); g_prof.used += 1; g_prof.evals += N; }
     return rc;
 }

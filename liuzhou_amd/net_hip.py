@@ -9,6 +9,7 @@ reference gives to its TorchScript/CUDA-graph InferenceEngine (v0/src/net/infere
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -31,8 +32,11 @@ _configured = False
 
 
 class FusedNet:
-    def __init__(self, model, device=None, max_blocks: int = 0, half_workgroups: bool = False) -> None:
-        """`half_workgroups` (64 channels): 4-wave workgroups of 8 samples, two per CU (LzNetDesc.flags bit 0)."""
+    def __init__(self, model, device=None, max_blocks: int = 0, half_workgroups: bool = False,
+                 wide_tiles: Optional[bool] = None) -> None:
+        """`half_workgroups` (64 channels): 4-wave workgroups of 8 samples, two per CU (LzNetDesc.flags bit 0).
+        `wide_tiles` (128 channels): 4-wave workgroups, one wave per SIMD with 4 channel tiles per wave -- half the LDS
+        operand reads of the 8-wave shape (flags bit 1); None: env LZ_NET_WIDE (default off)."""
         global _configured
         dev = torch.device(device) if device is not None else next(model.parameters()).device
         if dev.type != "cuda":
@@ -45,7 +49,10 @@ class FusedNet:
         d.channels, d.blocks = self.pack.channels, self.pack.blocks
         d.num_layers = len(self.pack.layer_offsets)
         d.max_blocks = int(max_blocks)
-        d.flags = 1 if (half_workgroups and self.pack.channels == 64) else 0
+        if wide_tiles is None:
+            wide_tiles = os.environ.get("LZ_NET_WIDE", "0").strip().lower() in ("1", "on", "true")
+        d.flags = (1 if (half_workgroups and self.pack.channels == 64) else 0) | \
+                  (2 if (wide_tiles and self.pack.channels == 128) else 0)
         d.wfrag, d.fparams = self.pack.wfrag.data_ptr(), self.pack.fparams.data_ptr()
         d.wfrag_bytes = int(self.pack.wfrag.numel()) * 2
         d.fparams_bytes = int(self.pack.fparams.numel()) * 4
@@ -69,13 +76,15 @@ class FusedNet:
     def eval(self):
         return self
 
-    def variant(self, half_workgroups: bool) -> "FusedNet":
+    def variant(self, half_workgroups: bool = False, wide_tiles: Optional[bool] = None) -> "FusedNet":
         """Same packed weights, other kernel configuration (a second descriptor over the same buffers)."""
         import copy
         other = copy.copy(self)
         d = LzNetDesc()
         C.memmove(C.byref(d), C.byref(self.desc), C.sizeof(LzNetDesc))
-        d.flags = 1 if (half_workgroups and self.pack.channels == 64) else 0
+        wide = bool(self.desc.flags & 2) if wide_tiles is None else bool(wide_tiles)
+        d.flags = (1 if (half_workgroups and self.pack.channels == 64) else 0) | \
+                  (2 if (wide and self.pack.channels == 128) else 0)
         other.desc = d
         other.last_value = None
         return other

@@ -33,6 +33,15 @@ def rate(f, seconds=2.5):
     return n * N / dt, dt / n * 1e6
 
 
+mode = sys.argv[3] if len(sys.argv) > 3 else "cus"
+if mode == "wide":          # 8-wave shape (2 channel tiles per wave) vs 4-wave shape (4 channel tiles per wave), alternating
+    for rep in range(3):
+        for wide in (False, True):
+            f = FusedNet(model, wide_tiles=wide)
+            r, us = rate(f, 3.0)
+            print(f"{name} N={N} wide_tiles={wide}: {r / 1e6:.3f} M evals/s, {us:.1f} us/launch, "
+                  f"{r * f.flops_per_eval / 1e12:.0f} TFLOP/s", flush=True)
+    sys.exit(0)
 for same in ("0", "1"):
     os.environ["LZ_EXP_SAME_LAYER"] = same
     for blocks in (256, 248, 240, 224, 192, 128):

@@ -23,9 +23,12 @@ def _planes(n, seed=0):
 
 @pytest.mark.parametrize("name,n,half", [("b6c64", 16, False), ("b6c64", 1000, False), ("b6c64", 4099, False),
                                          ("b10c128", 8, False), ("b10c128", 777, False),
-                                         ("b6c64", 5, True), ("b6c64", 2049, True)])
+                                         ("b6c64", 5, True), ("b6c64", 2049, True),
+                                         ("b10c128", 9, "wide"), ("b10c128", 2050, "wide")])
 def test_fused_net_matches_fp32_model(name, n, half):
-    """`half`: the 4-wave / 8-sample workgroup configuration used by the dual-stream search."""
+    """`half`: the 4-wave / 8-sample workgroup configuration used by the dual-stream search; "wide": the 4-wave shape
+    of the 128-channel net with 4 channel tiles per wave (must also equal the 8-wave shape bit for bit: same MFMAs in
+    the same order per output element)."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     from liuzhou_amd.net import ChessNet, MODEL_CONFIGS, bucket_logits_to_scalar
@@ -41,9 +44,14 @@ def test_fused_net_matches_fp32_model(name, n, half):
             mod.bias.data.copy_(torch.randn(mod.bias.shape, generator=g) * 0.1)
     m = m.to(DEV)
     x = _planes(n, seed=n)
-    fused = FusedNet(m, half_workgroups=half)
+    fused = FusedNet(m, half_workgroups=half is True, wide_tiles=half == "wide")
     lp1, lp2, lpm, vl = fused(x)
     val = fused.last_value
+    if half == "wide":
+        ref8 = FusedNet(m, wide_tiles=False)
+        for a, b in zip(ref8(x), (lp1, lp2, lpm, vl)):
+            assert torch.equal(a, b)
+        assert torch.equal(ref8.last_value, val)
     with torch.inference_mode():
         r1, r2, rm, rv = m(x)
         rval = bucket_logits_to_scalar(rv)
