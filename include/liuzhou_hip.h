@@ -113,6 +113,29 @@ LZ_API int lz_root_pack_rows(const uint8_t* legal_mask, const float* probs, cons
                              int32_t* counts, int32_t* legal_index, float* priors, int32_t* codes,
                              void* stream);
 
+/* v0_core.root_pack_sparse_actions (module.cpp:247-363, :1357-1362) through the C ABI.  Its output shapes [R, Amax]
+ * depend on the data, so it is a two-call protocol with ONE host read in between (the reference reads R and Amax back
+ * too, module.cpp:295,310):
+ *   1. lz_root_pack_rows (above) -> fixed-capacity rows, then
+ *      lz_root_pack_plan(counts, B, rank int32[B], child_off int64[B], sizes int64[3]) -- all device memory:
+ *        rank[b] = index of row b among the non-terminal rows (-1: no legal action), child_off[b] = number of legal
+ *        actions in the rows before b, sizes = {R = non-terminal rows, Amax = largest count, N = sum of counts};
+ *   2. the caller reads `sizes`, allocates the ten outputs and calls
+ *      lz_root_pack_fill(...): terminal_mask uint8[B], valid_root_indices int64[R], counts int64[R],
+ *        valid_mask uint8[R,Amax], legal_index_mat int64[R,Amax] (0 pad), priors_mat float32[R,Amax] (0 pad),
+ *        action_code_mat int32[R,Amax,4] (0 pad), pack_flat_idx int64[N] (row-major positions of the valid entries),
+ *        action_codes_all int32[N,4], parent_indices_all int64[N] (row b of every entry) -- the reference's 10-tuple.
+ * Pointers of empty outputs (R = 0 / N = 0) may be NULL.  The int32x4 code arrays must be 16-byte aligned. */
+LZ_API int lz_root_pack_plan(const int32_t* counts, int64_t batch, int32_t* rank, int64_t* child_off, int64_t* sizes,
+                             void* stream);
+LZ_API int lz_root_pack_fill(const int32_t* counts, const int32_t* legal_index, const float* priors,
+                             const int32_t* codes, const int32_t* rank, const int64_t* child_off, int64_t batch,
+                             int64_t cap, int64_t R, int64_t Amax, int64_t N, uint8_t* terminal_mask,
+                             int64_t* valid_root_indices, int64_t* counts_out, uint8_t* valid_mask,
+                             int64_t* legal_index_mat, float* priors_mat, int32_t* action_code_mat,
+                             int64_t* pack_flat_idx, int32_t* action_codes_all, int64_t* parent_indices_all,
+                             void* stream);
+
 /* v0_core.root_puct_allocate_visits  (module.cpp:1349-1356; root_puct_fused.cu:12-117)
  * fp32 bandit: `num_simulations` serial pulls per root, lowest index wins ties.  A <= 256. */
 LZ_API int lz_root_puct_allocate_visits(const float* priors, const float* leaf_values,

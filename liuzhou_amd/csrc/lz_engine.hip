@@ -870,6 +870,10 @@ __global__ __launch_bounds__(kBlock) void tree_advance_kernel(Tree t, const int*
     }
     const int nn = t.n_nodes[g], n_e = t.n_edges[g];
     int kept_nodes = 0, kept_edges = 0;
+    if (c > 0 && ((nn + 63) >> 6) > kMarkWords) {              // more nodes than the LDS mark words cover: fresh root
+        c = -1;                                                 // (lz_tree_advance refuses such arenas; belt and braces)
+        if (lane == 0 && dropped != nullptr) atomicAdd(dropped, 1);
+    }
     if (c > 0) {
         // ---- pass 1: marks + per-word prefix counts ----
         const int words = (nn + 63) >> 6;
@@ -1404,7 +1408,7 @@ int lz_tree_advance(const LzTreeDesc* d, const int32_t* played_action, const uin
                     int32_t* dropped, void* stream) {
     if (!tree_ok(d) || next_sims < 0) return LZ_ERR_ARG;
     if (d->num_games == 0) return LZ_OK;
-    if (d->node_cap > 65535) return LZ_ERR_ARG;              // edge records carry 16-bit owner ids
+    if (d->node_cap > kMarkWords * kWave) return LZ_ERR_UNSUPPORTED;   // LDS mark words / 16-bit owner ids: <= 16384 nodes
     const int64_t rn = next_sims + 1, re = (next_sims + 1) * kMaxChildren;
     if (rn > d->node_cap || re > d->edge_cap) return LZ_ERR_ARG;
     hipLaunchKernelGGL(tree_advance_kernel, dim3(gw(d->num_games)), dim3(kBlock), 0, as_stream(stream), make_tree(d),

@@ -433,6 +433,93 @@ __global__ __launch_bounds__(kBlock) void root_pack_kernel(const uint8_t* __rest
     if (lane == 0) counts[row] = base;
 }
 
+// root_pack_sparse_actions, second half (module.cpp:285-363): the reference's data-dependent [R, Amax] outputs from the
+// fixed-capacity rows.  Plan: one workgroup scans the counts -- rank of every non-terminal row among the valid roots,
+// exclusive sum of the counts (offset of the row's children in the flat lists), R / Amax / N.  Fill: one wave per row.
+constexpr int kPlanBlock = 1024;
+__global__ __launch_bounds__(kPlanBlock) void root_pack_plan_kernel(const int32_t* __restrict__ counts, int64_t B,
+                                                                    int32_t* __restrict__ rank,
+                                                                    int64_t* __restrict__ child_off,
+                                                                    int64_t* __restrict__ sizes) {
+    __shared__ int s_roots[kPlanBlock / kWave];
+    __shared__ long long s_kids[kPlanBlock / kWave];
+    __shared__ int s_max[kPlanBlock / kWave];
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), w = tid / kWave;
+    const int64_t per = (B + kPlanBlock - 1) / kPlanBlock;
+    const int64_t lo = tid * per, hi = (lo + per < B) ? lo + per : B;
+    int roots = 0, mx = 0;
+    long long kids = 0;
+    for (int64_t j = lo; j < hi; ++j) {
+        const int c = counts[j];
+        roots += c > 0 ? 1 : 0;
+        kids += c > 0 ? c : 0;
+        mx = c > mx ? c : mx;
+    }
+    int ri = roots;
+    long long ki = kids;
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+        const int rv = __shfl_up(ri, d, kWave);
+        const long long kv = __shfl_up(ki, d, kWave);
+        if (lane >= d) { ri += rv; ki += kv; }
+    }
+    int wmx = mx;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const int v = __shfl_xor(wmx, o); wmx = v > wmx ? v : wmx; }
+    if (lane == kWave - 1) { s_roots[w] = ri; s_kids[w] = ki; }
+    if (lane == 0) s_max[w] = wmx;
+    __syncthreads();
+    int rb = 0, rt = 0, amax = 0;
+    long long kb = 0, kt = 0;
+    for (int i = 0; i < kPlanBlock / kWave; ++i) {
+        if (i < w) { rb += s_roots[i]; kb += s_kids[i]; }
+        rt += s_roots[i]; kt += s_kids[i];
+        amax = s_max[i] > amax ? s_max[i] : amax;
+    }
+    int r = rb + ri - roots;
+    long long k = kb + ki - kids;
+    for (int64_t j = lo; j < hi; ++j) {
+        const int c = counts[j];
+        rank[j] = c > 0 ? r : -1;
+        child_off[j] = k;
+        if (c > 0) { ++r; k += c; }
+    }
+    if (tid == 0) { sizes[0] = rt; sizes[1] = amax; sizes[2] = kt; }
+}
+
+__global__ __launch_bounds__(kBlock) void root_pack_fill_kernel(
+    const int32_t* __restrict__ counts, const int32_t* __restrict__ legal_index, const float* __restrict__ priors,
+    const int4* __restrict__ codes, const int32_t* __restrict__ rank, const int64_t* __restrict__ child_off, int64_t B,
+    int cap, int M, uint8_t* __restrict__ terminal_mask, int64_t* __restrict__ valid_root_indices,
+    int64_t* __restrict__ counts_out, uint8_t* __restrict__ valid_mask, int64_t* __restrict__ legal_index_mat,
+    float* __restrict__ priors_mat, int4* __restrict__ action_code_mat, int64_t* __restrict__ pack_flat_idx,
+    int4* __restrict__ action_codes_all, int64_t* __restrict__ parent_indices_all) {
+    const int lane = lane_id();
+    const int64_t b = wave_item();
+    if (b >= B) return;
+    const int c = counts[b];
+    const int r = rank[b];
+    if (lane == 0) terminal_mask[b] = c == 0 ? 1 : 0;
+    if (r < 0) return;
+    if (lane == 0) { valid_root_indices[r] = b; counts_out[r] = c; }
+    const int64_t off = child_off[b];
+    for (int k = lane; k < M; k += kWave) {
+        const bool ok = k < c && k < cap;
+        const int64_t o = (int64_t)r * M + k;
+        valid_mask[o] = ok ? 1 : 0;
+        const int li = ok ? legal_index[b * cap + k] : 0;
+        legal_index_mat[o] = li < 0 ? 0 : li;                       // module.cpp:327: clamp_min(0) on the padding
+        priors_mat[o] = ok ? priors[b * cap + k] : 0.f;
+        const int4 code = ok ? codes[b * cap + k] : make_int4(0, 0, 0, 0);
+        action_code_mat[o] = code;
+        if (ok) {
+            pack_flat_idx[off + k] = o;
+            action_codes_all[off + k] = code;
+            parent_indices_all[off + k] = b;
+        }
+    }
+}
+
 // =================================================================================================
 // root_puct_allocate_visits: one wave per root, statistics in registers for all simulations.
 // SLOTS actions per lane (A <= 64*SLOTS).  Each pull is a single 64-bit wave max over
@@ -1017,6 +1104,38 @@ int lz_root_pack_rows(const uint8_t* mask, const float* probs, const int32_t* me
     hipLaunchKernelGGL(root_pack_kernel, dim3(grid_waves(B)), dim3(kBlock), 0, as_stream(stream), mask, probs,
                        reinterpret_cast<const int4*>(meta), B, (int)T, (int)cap, counts, legal_index, priors,
                        reinterpret_cast<int4*>(codes));
+    return launch_status();
+}
+
+int lz_root_pack_plan(const int32_t* counts, int64_t B, int32_t* rank, int64_t* child_off, int64_t* sizes,
+                      void* stream) {
+    if (B < 0) return LZ_ERR_ARG;
+    if (!sizes) return LZ_ERR_ARG;
+    if (B > 0 && (!counts || !rank || !child_off)) return LZ_ERR_ARG;
+    hipLaunchKernelGGL(root_pack_plan_kernel, dim3(1), dim3(kPlanBlock), 0, as_stream(stream), counts, B, rank, child_off,
+                       sizes);
+    return launch_status();
+}
+
+int lz_root_pack_fill(const int32_t* counts, const int32_t* legal_index, const float* priors, const int32_t* codes,
+                      const int32_t* rank, const int64_t* child_off, int64_t B, int64_t cap, int64_t R, int64_t M,
+                      int64_t N, uint8_t* terminal_mask, int64_t* valid_root_indices, int64_t* counts_out,
+                      uint8_t* valid_mask, int64_t* legal_index_mat, float* priors_mat, int32_t* action_code_mat,
+                      int64_t* pack_flat_idx, int32_t* action_codes_all, int64_t* parent_indices_all, void* stream) {
+    if (B < 0 || cap < 1 || R < 0 || M < 0 || N < 0 || R > B || M > cap) return LZ_ERR_ARG;
+    if (B == 0) return LZ_OK;
+    if (!counts || !legal_index || !priors || !codes || !rank || !child_off || !terminal_mask) return LZ_ERR_ARG;
+    if (R > 0 && (!valid_root_indices || !counts_out)) return LZ_ERR_ARG;
+    if (R * M > 0 && (!valid_mask || !legal_index_mat || !priors_mat || !action_code_mat)) return LZ_ERR_ARG;
+    if (N > 0 && (!pack_flat_idx || !action_codes_all || !parent_indices_all)) return LZ_ERR_ARG;
+    if ((reinterpret_cast<uintptr_t>(codes) | reinterpret_cast<uintptr_t>(action_code_mat) |
+         reinterpret_cast<uintptr_t>(action_codes_all)) & 15)
+        return LZ_ERR_ALIGN;
+    hipLaunchKernelGGL(root_pack_fill_kernel, dim3(grid_waves(B)), dim3(kBlock), 0, as_stream(stream), counts, legal_index,
+                       priors, reinterpret_cast<const int4*>(codes), rank, child_off, B, (int)cap, (int)M, terminal_mask,
+                       valid_root_indices, counts_out, valid_mask, legal_index_mat, priors_mat,
+                       reinterpret_cast<int4*>(action_code_mat), pack_flat_idx, reinterpret_cast<int4*>(action_codes_all),
+                       parent_indices_all);
     return launch_status();
 }
 

@@ -76,6 +76,17 @@ class FusedNet:
     def eval(self):
         return self
 
+    def refresh(self, model) -> "FusedNet":
+        """Re-pack `model`'s current weights INTO the existing device buffers (same architecture): descriptors, kernel
+        arguments frozen in captured graphs and every `variant()` keep pointing at valid, now updated, memory.  The
+        checkpoint hand-off of a training iteration (v1/train.py:978 writes `model_state_cpu.pt` for the workers)."""
+        p = pack_model(model)
+        if (p.channels, p.blocks) != (self.pack.channels, self.pack.blocks) or p.wfrag.numel() != self.pack.wfrag.numel():
+            raise ValueError("refresh() needs the architecture this FusedNet was built for")
+        self.pack.wfrag.copy_(p.wfrag.to(self.device))
+        self.pack.fparams.copy_(p.fparams.to(self.device))
+        return self
+
     def variant(self, half_workgroups: bool = False, wide_tiles: Optional[bool] = None) -> "FusedNet":
         """Same packed weights, other kernel configuration (a second descriptor over the same buffers)."""
         import copy

@@ -70,8 +70,10 @@ class NetPack:
 
 
 def pack_model(model) -> NetPack:
-    sd_dev = next(model.parameters()).device
-    m = model.to("cpu").eval()
+    """BN folding + MFMA fragment order, on a detached host copy: the caller's module keeps its device, its train /
+    eval mode and its parameter storages (optimizer state, DDP buckets and captured graphs keep pointing at them)."""
+    import copy
+    m = copy.deepcopy(model).to("cpu").eval()
     C = int(m.stem_conv.weight.shape[0])
     NB = len(m.blocks)
     if C % 32 != 0:
@@ -142,7 +144,6 @@ def pack_model(model) -> NetPack:
     frags = frags + head_frags
     wfrag = torch.cat([f.reshape(-1) for f in frags]).contiguous()
     fparams = torch.cat(fl).to(torch.float32).contiguous()
-    model.to(sd_dev)
     return NetPack(C, NB, wfrag, fparams, offsets, foff, head_offsets)
 
 

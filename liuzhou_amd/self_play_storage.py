@@ -51,13 +51,22 @@ def plan_sample_ranges(*, total_samples: int, num_shards: int, target_samples_pe
     return out
 
 
+def _own_storage(t: torch.Tensor) -> torch.Tensor:
+    """Host tensor that owns exactly its bytes.  `torch.save` serialises a tensor's WHOLE underlying storage, so a
+    slice of a host batch would write (and every loader of the shard would pin) the full batch per chunk."""
+    t = t.detach().to("cpu")
+    if not t.is_contiguous() or t.untyped_storage().nbytes() > t.numel() * t.element_size():
+        t = t.contiguous().clone()
+    return t
+
+
 def slice_batch_cpu(samples: TensorSelfPlayBatch, *, start: int, end: int) -> TensorSelfPlayBatch:
-    return TensorSelfPlayBatch(*(getattr(samples, f)[int(start):int(end)].to("cpu") for f in _FIELDS))
+    return TensorSelfPlayBatch(*(_own_storage(getattr(samples, f)[int(start):int(end)]) for f in _FIELDS))
 
 
 def save_self_play_payload(*, path: str, samples: TensorSelfPlayBatch, stats_payload: Dict[str, Any],
                            metadata: Dict[str, Any]) -> None:
-    payload = {f: getattr(samples, f).detach().cpu() for f in _FIELDS}
+    payload = {f: _own_storage(getattr(samples, f)) for f in _FIELDS}
     payload["stats"] = dict(stats_payload)
     payload["metadata"] = dict(metadata)
     os.makedirs(os.path.dirname(path) or ".", exist_ok=True)

@@ -193,30 +193,36 @@ def root_pack_rows(legal_mask, probs, metadata, cap: int = PACK_CAP):
 
 def root_pack_sparse_actions(legal_mask, probs, metadata):
     """module.cpp:1357-1362 -> the reference's 10-tuple with data-dependent [R, Amax] shapes.
-    The compaction itself runs in one HIP kernel; the final row/column slicing needs the same two
-    host reads (R and Amax) the reference performs (module.cpp:295,310)."""
+    Entirely behind the C ABI (include/liuzhou_hip.h: lz_root_pack_rows -> lz_root_pack_plan -> read {R, Amax, N} ->
+    lz_root_pack_fill): three kernels and ONE host read of the sizes (the reference reads R and Amax separately,
+    module.cpp:295,310); this wrapper only allocates the outputs."""
     if legal_mask.dim() != 2 or probs.dim() != 2 or metadata.dim() != 3 or metadata.shape[2] != 4:
         raise RuntimeError("legal_mask [B,A], probs [B,A], metadata [B,A,4] expected")
     counts, lidx, pri, codes = root_pack_rows(legal_mask, probs, metadata)
     dev = legal_mask.device
-    terminal_mask = counts.eq(0)
-    valid_root_indices = torch.nonzero(~terminal_mask).view(-1)
-    counts_v = counts.index_select(0, valid_root_indices).to(torch.int64)
-    if int(valid_root_indices.numel()) == 0:
-        e = lambda shape, dt: torch.empty(shape, dtype=dt, device=dev)
-        return (terminal_mask, valid_root_indices, counts_v, e((0, 0), torch.bool), e((0, 0), torch.int64),
-                e((0, 0), torch.float32), e((0, 0, 4), torch.int32), e((0,), torch.int64),
-                e((0, 4), torch.int32), e((0,), torch.int64))
-    M = int(counts_v.max().item())
-    R = int(valid_root_indices.numel())
-    valid_mask = torch.arange(M, device=dev).view(1, M) < counts_v.view(R, 1)
-    legal_index_mat = lidx.index_select(0, valid_root_indices)[:, :M].to(torch.int64).clamp_min_(0)
-    priors_mat = pri.index_select(0, valid_root_indices)[:, :M].contiguous()
-    action_code_mat = codes.index_select(0, valid_root_indices)[:, :M].contiguous()
-    pack_flat_idx = torch.nonzero(valid_mask.reshape(-1)).view(-1)
-    action_codes_all = action_code_mat.reshape(-1, 4).index_select(0, pack_flat_idx)
-    parent_local = torch.div(pack_flat_idx, M, rounding_mode="floor")
-    parent_indices_all = valid_root_indices.index_select(0, parent_local)
+    B = int(counts.shape[0])
+    rank = torch.empty((B,), dtype=torch.int32, device=dev)
+    child_off = torch.empty((B,), dtype=torch.int64, device=dev)
+    sizes = torch.zeros((3,), dtype=torch.int64, device=dev)
+    with torch.cuda.device(dev):
+        L.check(L.lib().lz_root_pack_plan(L.ptr(counts), L.i64(B), L.ptr(rank), L.ptr(child_off), L.ptr(sizes),
+                                          L.stream_ptr(dev)), "root_pack_sparse_actions")
+    R, M, N = (int(v) for v in sizes.tolist())                     # the one host synchronisation
+    e = lambda shape, dt: torch.empty(shape, dtype=dt, device=dev)
+    terminal_mask = e((B,), torch.bool)
+    valid_root_indices, counts_v = e((R,), torch.int64), e((R,), torch.int64)
+    if R == 0:
+        M = 0
+    valid_mask, legal_index_mat = e((R, M), torch.bool), e((R, M), torch.int64)
+    priors_mat, action_code_mat = e((R, M), torch.float32), e((R, M, 4), torch.int32)
+    pack_flat_idx, action_codes_all, parent_indices_all = e((N,), torch.int64), e((N, 4), torch.int32), e((N,), torch.int64)
+    with torch.cuda.device(dev):
+        L.check(L.lib().lz_root_pack_fill(
+            L.ptr(counts), L.ptr(lidx), L.ptr(pri), L.ptr(codes), L.ptr(rank), L.ptr(child_off), L.i64(B),
+            L.i64(int(lidx.shape[1])), L.i64(R), L.i64(M), L.i64(N), L.ptr(terminal_mask), L.ptr(valid_root_indices),
+            L.ptr(counts_v), L.ptr(valid_mask), L.ptr(legal_index_mat), L.ptr(priors_mat), L.ptr(action_code_mat),
+            L.ptr(pack_flat_idx), L.ptr(action_codes_all), L.ptr(parent_indices_all), L.stream_ptr(dev)),
+            "root_pack_sparse_actions")
     return (terminal_mask, valid_root_indices, counts_v, valid_mask, legal_index_mat, priors_mat,
             action_code_mat, pack_flat_idx, action_codes_all, parent_indices_all)
 

@@ -1,5 +1,6 @@
 #!/bin/bash
 # kernel-stats of a short default bench run: prints the top kernels (avg us)
+GRAFT_REPO_ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}   # default: the repo this script lives in
 OUT=$PWD/gpurun_out/prof_quick
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp

@@ -1,6 +1,8 @@
 #!/bin/bash
-# rocprofv3 kernel stats of a short bench run in another mode, summarised into profiles/<tag>_kernel_stats.md
+# rocprofv3 kernel stats of a short bench run in another mode, summarised into gpurun_out/<tag>_kernel_stats.md (scratch:
+# copy the summary you want judged into profiles/)
 #   bash scripts/prof_mode.sh r01_bench_root --search root --steps 30 --warmup 5
+GRAFT_REPO_ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}   # default: the repo this script lives in
 TAG=$1; shift
 OUT=$PWD/gpurun_out/prof_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"

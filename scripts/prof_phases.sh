@@ -1,5 +1,6 @@
 #!/bin/bash
 # kernel-only durations (rocprofv3) of the network kernel truncated after each phase (LZ_NET_DEBUG_STOP)
+GRAFT_REPO_ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}   # default: the repo this script lives in
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 for stop in 1 2 3 4 5 0; do
   rm -rf gpurun_out/ph_$stop

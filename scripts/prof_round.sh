@@ -3,6 +3,7 @@
 #   1. kernel trace + stats of the default bench workload (tree search, C2)
 #   2. PMC passes (one counter per pass, kernel-trace only) of the network kernel at the bench batch
 # Summaries are post-processed into profiles/ by scripts/summarize_profiles.py.
+GRAFT_REPO_ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}   # default: the repo this script lives in
 set -e
 TAG=${1:-r01}
 OUT=$PWD/gpurun_out/prof_$TAG

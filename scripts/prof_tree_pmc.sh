@@ -1,5 +1,6 @@
 #!/bin/bash
 # instruction-mix counters of the fused tree kernel (one PMC pass, kernel-trace only)
+GRAFT_REPO_ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}   # default: the repo this script lives in
 OUT=$PWD/gpurun_out/prof_tree_pmc
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp

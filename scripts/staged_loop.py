@@ -58,7 +58,10 @@ def main() -> int:
     stable_resnet_init(model, 20260314)                               # MODEL_INIT_SEED (big_train_v1.sh:24)
     model.to(dev).eval()
     log = []
+    fused = FusedNet(model, dev) if plays else None
     for it in range(1, args.iterations + 1):
+        if fused is not None and it > 1:
+            fused.refresh(model)                                       # new checkpoint into the same device buffers
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
@@ -66,7 +69,7 @@ def main() -> int:
         if plays:
             torch.manual_seed(worker_seed(it, rank))                   # v1/train.py:998
             play = self_play_tree_gpu if args.search == "tree" else self_play_v1_gpu
-            batch, stats = play(FusedNet(model, dev), num_games=args.games_per_gpu, mcts_simulations=args.sims,
+            batch, stats = play(fused, num_games=args.games_per_gpu, mcts_simulations=args.sims,
                                 temperature_init=1.0, temperature_final=0.1, temperature_threshold=10,
                                 exploration_weight=1.0, device=str(dev), max_game_plies=args.max_game_plies,
                                 concurrent_games=args.games_per_gpu)

@@ -52,6 +52,27 @@ def test_storage_planning_and_payload(tmp_path):
     assert set(got) == {"state_tensors", "legal_masks", "policy_targets", "value_targets", "soft_value_targets", "stats", "metadata"}
 
 
+def test_chunk_files_hold_only_their_own_rows(tmp_path):
+    """A chunk sliced out of a host batch must not drag the whole batch's storage into its file (torch.save writes a
+    tensor's entire underlying storage): file size ~ rows x 2692 B, and the loaded tensors own just their bytes."""
+    from liuzhou_amd.self_play_storage import save_self_play_payload, slice_batch_cpu
+    from liuzhou_amd.trajectory_buffer import TensorSelfPlayBatch
+    n = 2000
+    b = TensorSelfPlayBatch(torch.rand(n, 11, 6, 6), torch.rand(n, 220) < 0.1, torch.rand(n, 220), torch.rand(n), torch.rand(n))
+    part = slice_batch_cpu(b, start=100, end=300)
+    assert part.state_tensors.untyped_storage().nbytes() == 200 * 11 * 36 * 4
+    p = tmp_path / "chunk.pt"
+    save_self_play_payload(path=str(p), samples=part, stats_payload={}, metadata={})
+    assert 200 * 2692 <= os.path.getsize(p) < 200 * 2692 + 16384
+    q = tmp_path / "view.pt"                                      # views handed straight to the writer are materialised too
+    view = TensorSelfPlayBatch(*(getattr(b, f)[100:300] for f in ("state_tensors", "legal_masks", "policy_targets",
+                                                                   "value_targets", "soft_value_targets")))
+    save_self_play_payload(path=str(q), samples=view, stats_payload={}, metadata={})
+    assert os.path.getsize(q) < 200 * 2692 + 16384
+    got = torch.load(q)
+    assert torch.equal(got["policy_targets"], b.policy_targets[100:300])
+
+
 def test_target_summary_and_stats_merge():
     from liuzhou_amd.self_play_worker import merge_self_play_stats, merge_target_summaries, summarize_scalar_targets
     from liuzhou_amd.self_play_types import SelfPlayV1Stats
