@@ -245,7 +245,15 @@ typedef struct LzNetDesc {
             off_head_bias, off_p_gwT, off_p_a2, off_p_b2, off_p_out, off_v_w1T, off_v_b1, off_v_w2T, off_v_b2;
     int32_t flags;               /* bit 0 (64 channels): 4-wave workgroups of 8 samples, two per CU (default grid 512):
                                     a half-size batch then still covers every CU -- for two half-batches evaluated
-                                    concurrently on two streams */
+                                    concurrently on two streams;
+                                    bit 1 (128 channels): 4-wave workgroups with 4 channel tiles per wave (one wave per
+                                    SIMD, half the LDS operand reads; measured 2 % slower, off by default);
+                                    bit 2: fp32 OPERANDS (parity mode, csrc/lz_net_f32.hip: v_mfma_f32_16x16x4_f32 on
+                                    `wfrag_f32`): the reference's fp32 forward within 1e-5, at a fraction of the speed;
+                                    every lz_net_forward_* entry point and the search loops honour it */
+    const float* wfrag_f32;      /* device, fp32 conv fragments [layer][tap][K/4][Cout/16][64 lanes] at the same element
+                                    offsets as `wfrag` (layer_offsets); NULL unless flags bit 2 is used */
+    int64_t wfrag_f32_bytes;
 } LzNetDesc;
 
 /* ChessNet.forward (src/neural_network.py:213-259) + bucket_logits_to_scalar (:201-210), fused:

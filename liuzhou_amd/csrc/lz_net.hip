@@ -850,6 +850,11 @@ int lz_net_configure(void) {
     return a != LZ_OK ? a : (b != LZ_OK ? b : (c != LZ_OK ? c : e));
 }
 
+// fp32-operand parity mode (lz_net_f32.hip)
+int lz_net_forward_f32_dispatch(const LzNetDesc* d, const float* planes, const uint64_t* packed, int64_t N, float* lp1,
+                                float* lp2, float* lpmc, float* value_logits, float* value, const int64_t* n_dev,
+                                void* stream);
+
 static int net_forward_impl(const LzNetDesc* d, const float* planes, const uint64_t* packed, int64_t N, float* lp1,
                             float* lp2, float* lpmc, float* value_logits, float* value, void* stream,
                             const int64_t* n_dev = nullptr) {
@@ -860,6 +865,8 @@ static int net_forward_impl(const LzNetDesc* d, const float* planes, const uint6
     if (!heads && (lp1 || lp2 || lpmc || !value)) return LZ_ERR_ARG;     // all three policy outputs, or values only
     if (d->blocks < 0 || d->blocks > 15 || d->num_layers != 2 + 2 * d->blocks) return LZ_ERR_ARG;
     if ((reinterpret_cast<uintptr_t>(d->wfrag) & 15) || (reinterpret_cast<uintptr_t>(d->fparams) & 15)) return LZ_ERR_ALIGN;
+    if (d->flags & 4)
+        return lz_net_forward_f32_dispatch(d, planes, packed, N, lp1, lp2, lpmc, value_logits, value, n_dev, stream);
     NetParams P;
     P.wfrag = reinterpret_cast<const _Float16*>(d->wfrag);
     P.fp = d->fparams;

@@ -25,7 +25,8 @@ class LzNetDesc(C.Structure):
                 ("head_frag_offsets", C.c_int32 * 4)] + \
                [(n, C.c_int32) for n in ("off_stem_bias", "off_block0", "off_trunk_a", "off_trunk_b", "off_head_bias",
                                          "off_p_gwT", "off_p_a2", "off_p_b2", "off_p_out", "off_v_w1T", "off_v_b1",
-                                         "off_v_w2T", "off_v_b2", "flags")]
+                                         "off_v_w2T", "off_v_b2", "flags")] + \
+               [("wfrag_f32", C.c_void_p), ("wfrag_f32_bytes", C.c_int64)]
 
 
 _configured = False
@@ -33,16 +34,22 @@ _configured = False
 
 class FusedNet:
     def __init__(self, model, device=None, max_blocks: int = 0, half_workgroups: bool = False,
-                 wide_tiles: Optional[bool] = None) -> None:
+                 wide_tiles: Optional[bool] = None, precision: str = "fp16") -> None:
         """`half_workgroups` (64 channels): 4-wave workgroups of 8 samples, two per CU (LzNetDesc.flags bit 0).
         `wide_tiles` (128 channels): 4-wave workgroups, one wave per SIMD with 4 channel tiles per wave -- half the LDS
-        operand reads of the 8-wave shape (flags bit 1); None: env LZ_NET_WIDE (default off)."""
+        operand reads of the 8-wave shape (flags bit 1); None: env LZ_NET_WIDE (default off).
+        `precision`: "fp16" = fp16 MFMA operands with fp32 accumulation (the reference's autocast inference mode);
+        "fp32" = fp32 operands (csrc/lz_net_f32.hip, flags bit 2): the reference's fp32 forward within 1e-5 -- the parity
+        mode, many times slower, honoured by every entry point including the captured search loops."""
         global _configured
         dev = torch.device(device) if device is not None else next(model.parameters()).device
         if dev.type != "cuda":
             raise RuntimeError("FusedNet needs a HIP device (no CPU path)")
         self.device = dev
-        self.pack: NetPack = pack_model(model).to(dev)
+        if precision not in ("fp16", "fp32"):
+            raise ValueError(f"precision must be fp16 or fp32, got {precision!r}")
+        self.precision = precision
+        self.pack: NetPack = pack_model(model, fp32_fragments=precision == "fp32").to(dev)
         if self.pack.channels not in (64, 128):
             raise RuntimeError(f"fused kernel is built for 64 / 128 trunk channels, got {self.pack.channels}")
         d = LzNetDesc()
@@ -53,6 +60,10 @@ class FusedNet:
             wide_tiles = os.environ.get("LZ_NET_WIDE", "0").strip().lower() in ("1", "on", "true")
         d.flags = (1 if (half_workgroups and self.pack.channels == 64) else 0) | \
                   (2 if (wide_tiles and self.pack.channels == 128) else 0)
+        if precision == "fp32":
+            d.flags |= 4
+            d.wfrag_f32 = self.pack.wfrag_f32.data_ptr()
+            d.wfrag_f32_bytes = int(self.pack.wfrag_f32.numel()) * 4
         d.wfrag, d.fparams = self.pack.wfrag.data_ptr(), self.pack.fparams.data_ptr()
         d.wfrag_bytes = int(self.pack.wfrag.numel()) * 2
         d.fparams_bytes = int(self.pack.fparams.numel()) * 4
@@ -80,11 +91,13 @@ class FusedNet:
         """Re-pack `model`'s current weights INTO the existing device buffers (same architecture): descriptors, kernel
         arguments frozen in captured graphs and every `variant()` keep pointing at valid, now updated, memory.  The
         checkpoint hand-off of a training iteration (v1/train.py:978 writes `model_state_cpu.pt` for the workers)."""
-        p = pack_model(model)
+        p = pack_model(model, fp32_fragments=self.precision == "fp32")
         if (p.channels, p.blocks) != (self.pack.channels, self.pack.blocks) or p.wfrag.numel() != self.pack.wfrag.numel():
             raise ValueError("refresh() needs the architecture this FusedNet was built for")
         self.pack.wfrag.copy_(p.wfrag.to(self.device))
         self.pack.fparams.copy_(p.fparams.to(self.device))
+        if p.wfrag_f32 is not None:
+            self.pack.wfrag_f32.copy_(p.wfrag_f32.to(self.device))
         return self
 
     def variant(self, half_workgroups: bool = False, wide_tiles: Optional[bool] = None) -> "FusedNet":
@@ -95,7 +108,7 @@ class FusedNet:
         C.memmove(C.byref(d), C.byref(self.desc), C.sizeof(LzNetDesc))
         wide = bool(self.desc.flags & 2) if wide_tiles is None else bool(wide_tiles)
         d.flags = (1 if (half_workgroups and self.pack.channels == 64) else 0) | \
-                  (2 if (wide and self.pack.channels == 128) else 0)
+                  (2 if (wide and self.pack.channels == 128) else 0) | (self.desc.flags & 4)
         other.desc = d
         other.last_value = None
         return other

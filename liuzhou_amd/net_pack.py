@@ -54,6 +54,23 @@ def _frag_conv(w: torch.Tensor, k_pad: int) -> torch.Tensor:
     return out.to(torch.float16)
 
 
+def _frag_conv_f32(w: torch.Tensor, k_pad: int) -> torch.Tensor:
+    """w [Co, Ci, kh, kw] (double) -> fp32 fragments [taps][k_pad/4][Co/16][64] in v_mfma_f32_16x16x4_f32 A-operand order:
+    lane l holds W[co = 16*ct + (l & 15)][ci = 4*kb + (l >> 4)] (csrc/lz_net_f32.hip).  Same element count per layer as
+    the fp16 fragments, so the fp16 layer offsets apply."""
+    co, ci, kh, kw = w.shape
+    wp = torch.zeros((co, k_pad, kh, kw), dtype=torch.float64)
+    wp[:, :ci] = w
+    lane = torch.arange(64)
+    out = torch.empty((kh * kw, k_pad // 4, co // 16, 64), dtype=torch.float64)
+    for t in range(kh * kw):
+        ky, kx = divmod(t, kw)
+        for kb in range(k_pad // 4):
+            for ct in range(co // 16):
+                out[t, kb, ct] = wp[16 * ct + (lane & 15), 4 * kb + (lane >> 4), ky, kx]
+    return out.to(torch.float32)
+
+
 @dataclass
 class NetPack:
     channels: int
@@ -63,14 +80,17 @@ class NetPack:
     layer_offsets: List[int]       # offsets (in halfs) of each conv layer in wfrag; last = heads
     foff: Dict[str, int]           # offsets (in floats) into fparams
     head_offsets: List[int] = None  # offsets (in halfs) of gpool_linear / fc1 / fc2 / out-conv fragments
+    wfrag_f32: torch.Tensor = None  # optional fp32 conv fragments (parity mode), same element offsets as wfrag
 
     def to(self, device) -> "NetPack":
         return NetPack(self.channels, self.blocks, self.wfrag.to(device), self.fparams.to(device),
-                       list(self.layer_offsets), dict(self.foff), list(self.head_offsets))
+                       list(self.layer_offsets), dict(self.foff), list(self.head_offsets),
+                       None if self.wfrag_f32 is None else self.wfrag_f32.to(device))
 
 
-def pack_model(model) -> NetPack:
-    """BN folding + MFMA fragment order, on a detached host copy: the caller's module keeps its device, its train /
+def pack_model(model, fp32_fragments: bool = False) -> NetPack:
+    """`fp32_fragments`: also lay the (BN-folded) conv weights out as fp32 MFMA fragments for the parity-mode kernel.
+    BN folding + MFMA fragment order, on a detached host copy: the caller's module keeps its device, its train /
     eval mode and its parameter storages (optimizer state, DDP buckets and captured graphs keep pointing at them)."""
     import copy
     m = copy.deepcopy(model).to("cpu").eval()
@@ -85,7 +105,13 @@ def pack_model(model) -> NetPack:
         raise ValueError("fused kernel needs value MLP 128 and 101 bins")
 
     frags: List[torch.Tensor] = []
+    frags32: List[torch.Tensor] = []
     fl: List[torch.Tensor] = []
+
+    def conv_layer(w: torch.Tensor, k_pad: int) -> None:
+        frags.append(_frag_conv(w, k_pad))
+        if fp32_fragments:
+            frags32.append(_frag_conv_f32(w, k_pad))
     foff: Dict[str, int] = {}
 
     def put(name: str, t: torch.Tensor) -> None:
@@ -93,21 +119,21 @@ def pack_model(model) -> NetPack:
         fl.append(t.detach().double().reshape(-1))
 
     a, b = _bn_affine(m.stem_bn)
-    frags.append(_frag_conv(m.stem_conv.weight.detach().double() * a.view(-1, 1, 1, 1), STEM_K))
+    conv_layer(m.stem_conv.weight.detach().double() * a.view(-1, 1, 1, 1), STEM_K)
     put("stem_bias", b)
     for i, blk in enumerate(m.blocks):
         a1, b1 = _bn_affine(blk.bn1)
         a2, b2 = _bn_affine(blk.bn2)
         put(f"b{i}_a1", a1); put(f"b{i}_b1", b1); put(f"b{i}_bias1", b2)
-        frags.append(_frag_conv(blk.conv1.weight.detach().double() * a2.view(-1, 1, 1, 1), C))
-        frags.append(_frag_conv(blk.conv2.weight.detach().double(), C))
+        conv_layer(blk.conv1.weight.detach().double() * a2.view(-1, 1, 1, 1), C)
+        conv_layer(blk.conv2.weight.detach().double(), C)
     at, bt = _bn_affine(m.trunk_bn)
     put("trunk_a", at); put("trunk_b", bt)
     pa, pb = _bn_affine(ph.bn1)
     va, vb = _bn_affine(vh.bn1)
     head_w = torch.cat([ph.conv1.weight.detach().double() * pa.view(-1, 1, 1, 1),
                         vh.conv1.weight.detach().double() * va.view(-1, 1, 1, 1)], dim=0)      # [128, C, 1, 1]
-    frags.append(_frag_conv(head_w, C))
+    conv_layer(head_w, C)
     put("head_bias", torch.cat([pb, vb]))
     p2a, p2b = _bn_affine(ph.bn2)
     put("p_gw", ph.gpool_linear.weight)                  # [64,192]
@@ -144,7 +170,8 @@ def pack_model(model) -> NetPack:
     frags = frags + head_frags
     wfrag = torch.cat([f.reshape(-1) for f in frags]).contiguous()
     fparams = torch.cat(fl).to(torch.float32).contiguous()
-    return NetPack(C, NB, wfrag, fparams, offsets, foff, head_offsets)
+    wf32 = torch.cat([f.reshape(-1) for f in frags32]).contiguous() if fp32_fragments else None
+    return NetPack(C, NB, wfrag, fparams, offsets, foff, head_offsets, wf32)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -78,3 +78,57 @@ def test_values_only_mode_equals_full_forward():
         f(x)
         full = f.last_value.clone()
         assert torch.equal(f.values_only(x), full)
+
+
+def _g9_model(name, seed):
+    from liuzhou_amd.net import ChessNet, MODEL_CONFIGS
+    torch.manual_seed(seed)
+    m = ChessNet(**MODEL_CONFIGS[name])
+    gen = torch.Generator().manual_seed(seed + 1)
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.running_mean.copy_(torch.randn(mod.running_mean.shape, generator=gen) * 0.1)
+            mod.running_var.copy_(torch.rand(mod.running_var.shape, generator=gen) * 0.5 + 0.75)
+            mod.weight.data.copy_(torch.rand(mod.weight.shape, generator=gen) * 0.5 + 0.75)
+            mod.bias.data.copy_(torch.randn(mod.bias.shape, generator=gen) * 0.1)
+    return m.eval()
+
+
+@pytest.mark.parametrize("name", ["b6c64", "b10c128"])
+def test_fp32_operand_kernel_meets_the_reference_tolerance(name):
+    """The hand-written kernel in its fp32-operand mode (csrc/lz_net_f32.hip, v_mfma_f32_16x16x4_f32) against the
+    REFERENCE's own outputs (tests/golden/g9_net.npz: src/neural_network.py ChessNet in fp32, weights regenerated from
+    the seed) and against the fp32 module on several hundred real positions: <= 1e-5 on the three log-prob heads, the
+    101 value logits and the scalar value -- north_star's tolerance for policy / value tensors."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from liuzhou_amd.net import bucket_logits_to_scalar
+    from liuzhou_amd.net_hip import FusedNet
+    z = load("g9_net.npz")
+    m = _g9_model(name, 20260314).to(DEV)
+    f32 = FusedNet(m, precision="fp32")
+    x = torch.from_numpy(z["inputs"].astype(np.float32)).to(DEV)
+    got = f32(x)
+    for g, k in zip(got, ("lp1", "lp2", "lpmc", "value_logits")):
+        np.testing.assert_allclose(g.cpu().numpy(), z[f"{name}_{k}"], atol=1e-5, rtol=0, err_msg=f"{name}/{k}")
+    for n in (1, 7, 333):
+        xs = _planes(n, seed=40 + n)
+        lp1, lp2, lpm, vl = f32(xs)
+        val = f32.last_value
+        with torch.inference_mode():
+            r1, r2, rm, rv = m(xs)
+        for a, b in ((lp1, r1), (lp2, r2), (lpm, rm), (vl, rv), (val, bucket_logits_to_scalar(rv))):
+            assert (a - b).abs().max().item() <= 1e-5, (name, n, (a - b).abs().max().item())
+    # packed-state entry point (the search loop's) == planes entry point, and the mode survives variant()
+    from liuzhou_amd.tree_engine import TreeEngine
+    from tests.tree_parity import to_gpu_batch
+    st = states(load("g1_rules.npz"), "s")
+    idx = np.arange(50)
+    batch = to_gpu_batch({k: np.ascontiguousarray(np.asarray(st[k])[idx]) for k in FIELDS}, DEV)
+    eng = TreeEngine(50, 2, DEV)
+    eng.set_roots(batch)
+    from liuzhou_amd.mcts_gpu import states_to_model_input
+    a = f32.variant()(states_to_model_input(batch))
+    b = f32.forward_packed(eng.buf["root_state"])
+    for u, v in zip(a[:3], b[:3]):
+        assert torch.equal(u, v)
