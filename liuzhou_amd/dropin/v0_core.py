@@ -2,3 +2,8 @@
 resolves to the MI355X operator surface instead of the reference's CUDA extension."""
 from liuzhou_amd.v0_core import *  # noqa: F401,F403
 from liuzhou_amd.v0_core import Phase, version  # noqa: F401
+
+
+def __getattr__(name):          # MCTSConfig / MCTSCore / InferenceEngine are resolved lazily by the package module
+    import liuzhou_amd.v0_core as _m
+    return getattr(_m, name)

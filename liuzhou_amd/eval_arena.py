@@ -29,6 +29,7 @@ class EvaluationStats:
     draws: int
     total_games: int
     color_breakdown: Dict[str, Dict[str, int]] = field(default_factory=dict)
+    move_log: Optional[torch.Tensor] = None      # int32[games, plies] 220-d action indices (-1 pad), if recorded
 
     def _rate(self, v: int) -> float:
         return 0.0 if self.total_games == 0 else v / self.total_games
@@ -65,6 +66,18 @@ def _uniform_legal_codes(state: GpuStateBatch):
     return codes, valid, ~valid
 
 
+def codes_to_indices(codes: torch.Tensor) -> torch.Tensor:
+    """Action codes int32[N,4] (kind, primary, secondary, extra) -> 220-d action indices (v0/python/move_encoder.py:46-51:
+    placement = cell, movement = 36 + 4*from + dir, selections = 180 + cell, process-removal = 216; invalid: -1)."""
+    kind, a, b = codes[:, 0].to(torch.int64), codes[:, 1].to(torch.int64), codes[:, 2].to(torch.int64)
+    idx = torch.full_like(kind, -1)
+    idx = torch.where(kind == 1, a, idx)
+    idx = torch.where(kind == 2, 36 + 4 * a + b, idx)
+    idx = torch.where((kind >= 3) & (kind <= 7), 180 + a, idx)
+    idx = torch.where(kind == 8, torch.full_like(kind, 216), idx)
+    return idx.to(torch.int32)
+
+
 class RandomAgent:
     """Uniform over the legal moves (the reference's vs-random opponent)."""
 
@@ -92,8 +105,9 @@ class RootSearchAgent:
 
 
 def play_matches(challenger, opponent, num_games: int, device, *, opening_random_moves: int = 0,
-                 max_game_plies: int = 512, seed: Optional[int] = None) -> EvaluationStats:
-    """All `num_games` games at once on `device`; returns the challenger's W/L/D."""
+                 max_game_plies: int = 512, seed: Optional[int] = None, record_moves: bool = False) -> EvaluationStats:
+    """All `num_games` games at once on `device`; returns the challenger's W/L/D (`record_moves`: plus every game's
+    sequence of 220-d action indices in `move_log`)."""
     dev = torch.device(device)
     if dev.type != "cuda":
         raise RuntimeError("eval arena needs a HIP device (no CPU path)")
@@ -107,6 +121,7 @@ def play_matches(challenger, opponent, num_games: int, device, *, opening_random
     challenger_black = torch.arange(n, device=dev) < (n / 2)          # eval_checkpoint.py:487-495
     result_black = torch.zeros((n,), dtype=torch.float32, device=dev)
     finished = torch.zeros((n,), dtype=torch.bool, device=dev)
+    log = []
     while True:
         active = torch.nonzero(~done).view(-1)
         if int(active.numel()) == 0:
@@ -131,6 +146,10 @@ def play_matches(challenger, opponent, num_games: int, device, *, opening_random
             codes.index_copy_(0, rows, c.to(torch.int32))
             valid.index_copy_(0, rows, v.to(torch.bool))
             term.index_copy_(0, rows, t.to(torch.bool))
+        if record_moves:
+            row = torch.full((n,), -1, dtype=torch.int32, device=dev)
+            row.index_copy_(0, active, torch.where(valid & ~term, codes_to_indices(codes), torch.full_like(codes[:, 0], -1)))
+            log.append(row)
         fin, res, _soft = v0_core.self_play_step_inplace(*states.tensors(), plies, done, active, codes, term, valid,
                                                          int(max_game_plies), 2.0)
         if int(fin.numel()) > 0:
@@ -143,7 +162,7 @@ def play_matches(challenger, opponent, num_games: int, device, *, opening_random
         cb[name] = {"wins": int((win & sel).sum()), "losses": int((loss & sel).sum()), "draws": int((draw & sel).sum()),
                     "games": int(sel.sum())}
     return EvaluationStats(wins=int(win.sum()), losses=int(loss.sum()), draws=int(draw.sum()), total_games=n,
-                           color_breakdown=cb)
+                           color_breakdown=cb, move_log=torch.stack(log, dim=1) if (record_moves and log) else None)
 
 
 def load_checkpoint_model(path: str):

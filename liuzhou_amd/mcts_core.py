@@ -1,0 +1,318 @@
+"""`MCTSConfig` / `MCTSCore` / `InferenceEngine`: the class surface of the reference's `v0_core` that `v0/python/mcts.py`
+(:138-470) and the web backend's model loader bind, as thin adapters over the device-resident tree engine (SURVEY.md
+section 8 row f4).
+
+  reference                                                    here
+  v0/src/bindings/module.cpp:1158-1173  MCTSConfig              `MCTSConfig` (same fields / defaults)
+  v0/src/bindings/module.cpp:1175-1284  MCTSCore                `MCTSCore`: one game on a `TreeEngine(1, ...)`
+  v0/src/bindings/module.cpp:1422-1438  InferenceEngine         `InferenceEngine`: the fused network kernel (or any module)
+  v0/src/mcts/mcts_core.cpp:181-230,703-760,815-829             root_value / get_policy / get_root_children_stats / advance_root
+
+Search semantics are the engine's variant P (one leaf per simulation, first maximum wins, sign flipped only when the mover
+changes) -- the reference's own C++ tree flips the sign on every level, which is wrong for this game's same-player atomic
+phases ("not an oracle"), and uses virtual-loss batches; `batch_size` / `virtual_loss` /
+`max_actions_per_batch` are accepted and ignored.  TorchScript is not loaded: `InferenceEngine` takes a module, a
+state-dict file or a TorchScript archive whose state_dict has ChessNet's keys, and rebuilds the network from it.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Callable, Dict, List, Optional, Tuple
+
+import torch
+
+from .mcts_gpu import GpuStateBatch
+from .net import ChessNet
+from .net_hip import FusedNet
+from .tree_engine import MAX_CHILDREN, OUT_CAP, TreeEngine
+
+
+@dataclass
+class MCTSConfig:
+    """v0/include/v0/mcts_core.hpp:18-32 (defaults as the PyBind class exposes them)."""
+    num_simulations: int = 800
+    exploration_weight: float = 1.0
+    temperature: float = 1.0
+    add_dirichlet_noise: bool = False
+    dirichlet_alpha: float = 0.3
+    dirichlet_epsilon: float = 0.25
+    batch_size: int = 16
+    max_actions_per_batch: int = 0
+    virtual_loss: float = 1.0
+    seed: int = 12345
+    device: str = "cuda"
+
+
+def _int(v) -> int:
+    return int(getattr(v, "value", v))
+
+
+def state_like_to_batch(state, device) -> GpuStateBatch:
+    """module.cpp:79-178 (GameStateFromPyLike / CoerceGameStateLike): any object with `board` (6x6 nested ints),
+    `phase`, `current_player` (ints or enums), optional `marked_black` / `marked_white` (iterables of (r, c)) and the
+    optional counters.  Like the reference's coercion, `moves_since_capture` is NOT read (it stays 0)."""
+    if state is None:
+        raise RuntimeError("state must not be None")
+    for name in ("board", "phase", "current_player"):
+        if not hasattr(state, name):
+            raise RuntimeError(f"Python GameState is missing attribute: {name}")
+    board = torch.tensor([[int(v) for v in row] for row in state.board], dtype=torch.int8)
+    if tuple(board.shape) != (6, 6):
+        raise RuntimeError(f"board must be 6x6, got {tuple(board.shape)}")
+    phase, player = _int(state.phase), _int(state.current_player)
+    if not 1 <= phase <= 7:
+        raise RuntimeError("phase enum value out of range")
+    if player not in (1, -1):
+        raise RuntimeError("current_player must be 1 or -1")
+
+    def marks(name):
+        m = torch.zeros((6, 6), dtype=torch.bool)
+        for rc in (getattr(state, name, None) or ()):
+            r, c = int(rc[0]), int(rc[1])
+            if not (0 <= r < 6 and 0 <= c < 6):
+                raise RuntimeError("mark coordinate outside the board")
+            m[r, c] = True
+        return m
+
+    opt = lambda name: int(getattr(state, name, 0) or 0)
+    one = lambda v: torch.tensor([int(v)], dtype=torch.int64)
+    b = GpuStateBatch(board.view(1, 6, 6), marks("marked_black").view(1, 6, 6), marks("marked_white").view(1, 6, 6),
+                      one(phase), one(player), one(opt("pending_marks_required")), one(opt("pending_marks_remaining")),
+                      one(opt("pending_captures_required")), one(opt("pending_captures_remaining")),
+                      one(opt("forced_removals_done")), one(opt("move_count")), one(0))
+    return b.to(device)
+
+
+class InferenceEngine:
+    """module.cpp:1422-1438: `InferenceEngine(path, device, dtype, batch_size, ...)` with `.forward(input, n_valid)`.
+    `path` may be a ChessNet module, a state-dict file, or a TorchScript archive (only its state_dict is used: the
+    reference's TorchScript / CUDA-graph replay, v0/src/net/inference_engine.cpp:58-202, is replaced by the fused network
+    kernel for 64- / 128-channel nets and by the eager module otherwise)."""
+
+    def __init__(self, path, device: str = "cuda", dtype: str = "float16", batch_size: int = 512,
+                 input_channels: int = 11, height: int = 6, width: int = 6, warmup_iters: int = 5,
+                 use_inference_mode: bool = True) -> None:
+        self._device = torch.device(device)
+        if self._device.type != "cuda":
+            raise RuntimeError("InferenceEngine needs a HIP device (no CPU path)")
+        self._dtype, self._batch = str(dtype), int(batch_size)
+        model = path if isinstance(path, torch.nn.Module) else self._load(path)
+        self.model = model.to(self._device).eval()
+        chans = int(self.model.stem_conv.out_channels)
+        self.fused: Optional[FusedNet] = None
+        if chans in (64, 128) and self._dtype in ("float16", "half", "fp16", "float32", "fp32"):
+            self.fused = FusedNet(self.model, self._device,
+                                  precision="fp32" if self._dtype in ("float32", "fp32") else "fp16")
+
+    @staticmethod
+    def _load(path) -> torch.nn.Module:
+        try:
+            sd = torch.jit.load(str(path), map_location="cpu").state_dict()
+        except Exception:
+            obj = torch.load(str(path), map_location="cpu", weights_only=False)
+            sd = obj.get("model_state_dict", obj.get("state_dict", obj)) if isinstance(obj, dict) else obj.state_dict()
+        c = int(sd["stem_conv.weight"].shape[0])
+        nb = len({k.split(".")[1] for k in sd if k.startswith("blocks.")})
+        model = ChessNet(trunk_channels=c, num_blocks=nb,
+                         policy_channels=int(sd["policy_head.conv1.weight"].shape[0]),
+                         value_channels=int(sd["value_head.conv1.weight"].shape[0]),
+                         value_mlp_channels=int(sd["value_head.fc1.weight"].shape[0]),
+                         value_bucket_bins=int(sd["value_head.fc2.weight"].shape[0]))
+        model.load_state_dict(sd, strict=True)
+        return model
+
+    def forward(self, input: torch.Tensor, n_valid: int = -1):
+        """-> (log_p1, log_p2, log_pmc, value output of the network) for the first n_valid rows (all: -1)."""
+        x = input.to(self._device, torch.float32)
+        if n_valid is not None and int(n_valid) >= 0:
+            x = x[: int(n_valid)]
+        if self.fused is not None:
+            return self.fused(x)
+        with torch.inference_mode():
+            return self.model(x)
+
+    device = property(lambda self: str(self._device))
+    dtype = property(lambda self: self._dtype)
+    batch_size = property(lambda self: self._batch)
+    graph_enabled = property(lambda self: self.fused is not None)
+
+
+class MCTSCore:
+    """One search tree on the device engine behind the reference's `MCTSCore` methods."""
+
+    def __init__(self, config: Optional[MCTSConfig] = None) -> None:
+        self.cfg = config or MCTSConfig()
+        self.device = torch.device(self.cfg.device)
+        if self.device.type != "cuda":
+            raise RuntimeError("MCTSCore needs a HIP device (no CPU path)")
+        self._callback: Optional[Callable] = None
+        self._fused: Optional[FusedNet] = None
+        self._engine: Optional[TreeEngine] = None
+        self._root: Optional[GpuStateBatch] = None
+        self._root_like = None
+        self._expanded = False
+        self._sims_in_tree = 0
+        self._eval_calls = self._eval_leaves = 0
+        from .game_rng import GameRng
+        self._rng = GameRng(1, self.device, seed=int(self.cfg.seed))
+        self._noise = torch.zeros((1, OUT_CAP), dtype=torch.float32, device=self.device)
+
+    # ---- evaluators (module.cpp:1177-1228) ----
+    def set_forward_callback(self, callback: Callable) -> None:
+        """callback(inputs f32[N,11,6,6]) -> (log_p1, log_p2, log_pmc, value f32[N])"""
+        self._callback, self._fused = callback, None
+
+    def set_inference_engine(self, engine: InferenceEngine) -> None:
+        if engine is None:
+            raise RuntimeError("InferenceEngine is null")
+        if engine.fused is not None:
+            self._fused, self._callback = engine.fused, None
+        else:
+            from .net import bucket_logits_to_scalar
+
+            def cb(x, _e=engine):
+                lp1, lp2, lpm, raw = _e.forward(x)
+                return lp1, lp2, lpm, bucket_logits_to_scalar(raw.float())
+            self._callback, self._fused = cb, None
+
+    def set_torchscript_runner(self, runner) -> None:
+        raise RuntimeError("TorchScript runners are not part of this build; use set_inference_engine / set_forward_callback")
+
+    set_eval_batcher = set_torchscript_runner
+
+    # ---- tree ----
+    def _capacity(self) -> int:
+        return max(1024, 4 * int(self.cfg.num_simulations))
+
+    def set_root_state(self, state) -> None:
+        self._root = state if isinstance(state, GpuStateBatch) else state_like_to_batch(state, self.device)
+        self._root_like = state
+        cap = self._capacity()
+        if self._engine is None or self._engine.max_sims < cap:
+            self._engine = TreeEngine(1, cap, self.device, float(self.cfg.exploration_weight),
+                                      reuse_factor=min(3.0, (16384 - cap - 2) / cap))
+        self._engine.set_roots(self._root)
+        self._engine.begin()
+        self._expanded, self._sims_in_tree = False, 0
+        self._rng.ply.zero_()
+
+    def reset(self) -> None:
+        self._root = self._root_like = None
+        self._expanded, self._sims_in_tree = False, 0
+
+    def _evaluate(self):
+        e = self._engine
+        if self._fused is not None:
+            lp1, lp2, lpm, _, val = self._fused.forward_packed(e.buf["leaf_state"])
+        else:
+            if self._callback is None:
+                raise RuntimeError("no forward callback / inference engine set")
+            lp1, lp2, lpm, val = self._callback(e.leaf_planes())
+            f = lambda t: t.float().reshape(1, -1).to(self.device).contiguous()
+            lp1, lp2, lpm, val = f(lp1), f(lp2), f(lpm), val.float().reshape(-1).to(self.device).contiguous()
+        self._eval_calls += 1
+        self._eval_leaves += 1
+        return lp1, lp2, lpm, val
+
+    def run_simulations(self, num_simulations: int) -> None:
+        if self._root is None:
+            raise RuntimeError("root state is not set")
+        e, n = self._engine, int(num_simulations)
+        if self._sims_in_tree + n > e.max_sims:
+            raise RuntimeError(f"search arena holds {e.max_sims} simulations per root; {self._sims_in_tree} used, {n} requested")
+        if not self._expanded:
+            kind = int(e.buf["leaf_kind"].item())
+            noise = None
+            if self.cfg.add_dirichlet_noise:
+                self._rng.gamma_into(self._noise, float(self.cfg.dirichlet_alpha), MAX_CHILDREN)
+                noise = self._noise
+            if kind in (1, 3):                                   # fresh root: evaluate; kept root: fresh noise only
+                lp1, lp2, lpm, val = self._evaluate() if kind == 1 else (e.lp1, e.lp2, e.lpm, e.values)
+                e.expand(is_root=True, values=val, heads=(lp1, lp2, lpm), noise=noise,
+                         epsilon=float(self.cfg.dirichlet_epsilon))
+            self._expanded = True
+        for _ in range(n):
+            e.select()
+            lp1, lp2, lpm, val = self._evaluate()
+            e.expand(is_root=False, values=val, heads=(lp1, lp2, lpm))
+        self._sims_in_tree += n
+
+    def _children(self) -> Tuple[List[int], List[float], List[float]]:
+        e = self._engine
+        t = torch.ones((1,), dtype=torch.float32, device=self.device)
+        e.finish(t, None)
+        k = int(e.child_count.item())
+        return (e.child_action[0, :k].tolist(), [float(v) for v in e.child_visits[0, :k].tolist()],
+                e.child_prior[0, :k].tolist())
+
+    def get_policy(self, temperature: float = 1.0) -> List[Tuple[int, float]]:
+        """mcts_core.cpp:703-760: visits^(1/T) normalised over the root's children (T <= 1e-6: one-hot argmax)."""
+        if self._root is None or not self._expanded:
+            return []
+        acts, visits, _ = self._children()
+        if not acts:
+            return []
+        temp = max(float(temperature), 1e-6)
+        if temp <= 1e-6:
+            best = max(range(len(visits)), key=lambda i: (visits[i], -i))
+            return [(a, 1.0 if i == best else 0.0) for i, a in enumerate(acts)]
+        scaled = [v ** (1.0 / temp) for v in visits]
+        s = sum(scaled)
+        scaled = [1.0 / len(scaled)] * len(scaled) if s <= 0 else [v / s for v in scaled]
+        return list(zip(acts, scaled))
+
+    def get_root_children_stats(self) -> List[Dict[str, float]]:
+        """mcts_core.cpp:200-217: per child of the root {action_index, prior, visit_count, value_sum}; `value_sum` is
+        given from the ROOT mover's side (value_sum / visit_count is the Q the selection rule uses)."""
+        if self._root is None or not self._expanded:
+            return []
+        root_white = int(self._root.current_player.item()) < 0
+        out = []
+        for rec in self._engine.root_edge_records(0):
+            w = rec["value_sum"] if rec["child_white"] == root_white else -rec["value_sum"]
+            out.append({"action_index": rec["action_index"], "prior": rec["prior"],
+                        "visit_count": float(rec["visit_count"]), "value_sum": w})
+        return out
+
+    def advance_root(self, action_index: int) -> None:
+        """mcts_core.cpp:815-829: keep the subtree of the played child (tree reuse); unknown child: reset."""
+        if self._root is None or not self._expanded:
+            return
+        from . import v0_core
+        acts, _, _ = self._children()
+        if int(action_index) not in acts:
+            self.reset()
+            return
+        mask, meta = v0_core.encode_actions_fast(*self._root.tensors()[:10], 36, 144, 36, 4)
+        code = meta[0, int(action_index)].view(1, 4).contiguous()
+        nxt = GpuStateBatch(*v0_core.batch_apply_moves(*self._root.tensors(), code,
+                                                       torch.zeros((1,), dtype=torch.int64, device=self.device)))
+        e = self._engine
+        e.set_roots(nxt)
+        e.advance(torch.tensor([int(action_index)], dtype=torch.int32, device=self.device), None,
+                  min(int(self.cfg.num_simulations), e.max_sims))
+        self._root, self._root_like = nxt, None
+        self._expanded = False
+        self._sims_in_tree = 0
+        self._rng.ply.add_(1)
+
+    def reset_eval_stats(self) -> None:
+        self._eval_calls = self._eval_leaves = 0
+
+    def get_eval_stats(self) -> Dict[str, object]:
+        return {"eval_calls": self._eval_calls, "eval_leaves": self._eval_leaves, "full512_calls": 0, "hist": []}
+
+    @property
+    def root_value(self) -> float:
+        if self._root is None or self._engine is None:
+            return 0.0
+        n = int(self._engine.buf["root_visits"].item())
+        return float(self._engine.buf["root_w"].item()) / n if n > 0 else 0.0
+
+    @property
+    def root_visit_count(self) -> float:
+        return 0.0 if self._root is None or self._engine is None else float(self._engine.buf["root_visits"].item())
+
+    @property
+    def root_state(self):
+        return self._root_like if self._root_like is not None else self._root

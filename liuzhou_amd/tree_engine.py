@@ -161,6 +161,21 @@ class TreeEngine:
         self.desc.trace_cap = n
         return self.trace
 
+    def root_edge_records(self, g: int):
+        """The root's edge records of game g, read from the arena (host copy: inspection / adapters, not the hot loop):
+        list of {action_index, prior, visit_count, value_sum (child mover's side), child_white, terminal}."""
+        import numpy as np
+        node = self.buf["nodes"].view(self.B, self.node_cap, 6)[g, 0].cpu().numpy()
+        e0, ne = int(node[4] & 0xFFFFFFFF), int(np.int32(node[4] >> 32))
+        if ne <= 0:
+            return []
+        dt = np.dtype([("W", "<f8"), ("P", "<f4"), ("n_info", "<u4"), ("child", "<i4"), ("cbegin", "<i4"),
+                       ("act", "u1"), ("cn", "u1"), ("owner", "<u2"), ("pad", "V4")])
+        recs = self.buf["edges"].view(self.B, self.edge_cap, 4)[g, e0:e0 + ne].contiguous().cpu().numpy().view(dt).reshape(ne)
+        return [{"action_index": int(r["act"]), "prior": float(r["P"]), "visit_count": int(r["n_info"] & 0xFFFFFF),
+                 "value_sum": float(r["W"]), "child_white": bool((r["n_info"] >> 24) & 1),
+                 "terminal": bool((r["n_info"] >> 24) & 2)} for r in recs]
+
     def hbm_bytes(self) -> int:
         return sum(t.numel() * t.element_size() for t in self.buf.values())
 

@@ -377,3 +377,12 @@ def finalize_trajectory_inplace(value_targets, soft_value_targets, player_signs,
     L.check(st, "finalize_trajectory_inplace")
     kidx = torch.nonzero(keep).view(-1)
     return sl.index_select(0, kidx), fcounts.index_select(0, kidx), counts_out
+
+
+def __getattr__(name: str):
+    """`MCTSConfig`, `MCTSCore`, `InferenceEngine` (module.cpp:1158-1284,1422-1438): adapters over the device tree engine,
+    resolved lazily (they sit above the modules that import this one)."""
+    if name in ("MCTSConfig", "MCTSCore", "InferenceEngine"):
+        from . import mcts_core
+        return getattr(mcts_core, name)
+    raise AttributeError(f"module 'v0_core' has no attribute {name!r}")

@@ -20,6 +20,7 @@ Fixture groups:
   g11_loss.npz      training-loss values and head gradients from the reference's own loss functions
   g10_tree_selfplay.npz  full-tree self-play traces of the reference portable runner (subtree reuse on every move)
   g9_net.npz        network outputs for seeded weights (tiny / 6x64 / 10x128)
+  g14_eval_arena.npz  the reference's evaluation arena (two tiny checkpoints, deterministic): outcome, moves, evaluations
   g13_legacy_waves.npz  root visit counts of src/mcts.py searches with batch_K = 16 / 4 (wave-batched leaves), incl. tree reuse
   g12_sparse_selfplay.npz  root-PUCT self-play traces of the reference v1 runner with sparse_ply = 2 and 3 (top-K lookahead)
 """
@@ -708,6 +709,93 @@ def gen_tree_selfplay():
 
 
 # --------------------------------------------------------------------------------------------
+# G14: the reference's evaluation arena (scripts/eval_checkpoint.py::_eval_worker_v1, backend v1) on CPU
+# --------------------------------------------------------------------------------------------
+def _fnv64(rows: np.ndarray) -> np.ndarray:
+    """FNV-1a over the bytes of each row (uint8[N, K]) -> uint64[N]: key of a packed input-plane row."""
+    h = np.full(rows.shape[0], 0xCBF29CE484222325, np.uint64)
+    for j in range(rows.shape[1]):
+        h = (h ^ rows[:, j].astype(np.uint64)) * np.uint64(0x100000001B3)
+    return h
+
+
+def gen_eval_arena():
+    """Two tiny checkpoints play `num_games` games against each other through the reference's own arena worker
+    (deterministic picks, no random openings): the outcome tuple, every game's move sequence, and every network
+    evaluation of both agents (so that a run on another host replays them instead of re-rounding the convolutions;
+    value for every evaluated position, the three head rows for the positions that were searched as roots)."""
+    import importlib
+    ec = importlib.import_module("scripts.eval_checkpoint")
+    from src.neural_network import bucket_logits_to_scalar
+    G, SIMS = 4, 16
+    models = {}
+    for tag, seed in (("chall", 7), ("opp", 8)):
+        torch.manual_seed(seed)
+        m = ChessNet(board_size=6, num_input_channels=NUM_INPUT_CHANNELS, trunk_channels=8, num_blocks=1,
+                     policy_channels=4, value_channels=4, value_mlp_channels=8).eval()
+        models[tag] = m
+    rec = {"chall": {}, "opp": {}}
+
+    class Recording(torch.nn.Module):
+        def __init__(self, tag):
+            super().__init__()
+            self.tag, self.inner = tag, models[tag]
+
+        def forward(self, x):
+            out = self.inner(x)
+            keys = _fnv64(np.packbits(x.detach().cpu().numpy().astype(bool).reshape(x.shape[0], -1), axis=1))
+            val = bucket_logits_to_scalar(out[3].float(), num_bins=int(out[3].shape[1])).detach().cpu().numpy()
+            heads = torch.cat([o.reshape(x.shape[0], -1) for o in out[:3]], dim=1).detach().cpu().numpy().astype(np.float32)
+            for i, k in enumerate(keys.tolist()):
+                v = (heads[i].copy(), np.float32(val[i]))
+                if k in rec[self.tag]:
+                    assert np.array_equal(rec[self.tag][k][0], v[0]) and rec[self.tag][k][1] == v[1], "not batch-invariant"
+                rec[self.tag][k] = v
+            return out
+
+    ec._load_model_from_checkpoint = lambda path, device: Recording("chall" if "chall" in str(path) else "opp").eval()
+    moves, roots, ids = {}, set(), {}
+    real_apply = ec.apply_move
+
+    def logging_apply(state, move, quiet=True):
+        g = ids.pop(id(state), None)
+        if g is None:
+            g = len(moves)
+            moves[g] = []
+        moves[g].append(int(action_to_index(move, 6)))
+        planes = state_to_tensor(state, state.current_player).numpy().astype(bool).reshape(1, -1)
+        roots.add(int(_fnv64(np.packbits(planes, axis=1))[0]))
+        nxt = real_apply(state, move, quiet=quiet)
+        ids[id(nxt)] = g
+        logging_apply.keep.append(nxt)                         # keep ids unique while the game is alive
+        return nxt
+    logging_apply.keep = []
+    ec.apply_move = logging_apply
+    torch.manual_seed(0); np.random.seed(0); random.seed(0)
+    try:
+        result = ec._eval_worker_v1(0, list(range(G)), G, "cpu", SIMS, 0.1, "chall.pt", "opp.pt", 0, G, 0, False, "v1",
+                                    "python", 1)
+    finally:
+        ec.apply_move = real_apply
+    L = max(len(v) for v in moves.values())
+    seq = np.full((G, L), -1, np.int32)
+    for g, v in moves.items():
+        seq[g, :len(v)] = v
+    out = {"result": np.asarray(result, np.int64), "moves": seq, "config": np.asarray([G, SIMS], np.int64)}
+    for tag in ("chall", "opp"):
+        keys = np.asarray(sorted(rec[tag]), np.uint64)
+        assert len(set(keys.tolist())) == len(keys)
+        out[f"{tag}_keys"] = keys
+        out[f"{tag}_values"] = np.asarray([rec[tag][int(k)][1] for k in keys], np.float32)
+        rk = np.asarray([k for k in keys.tolist() if k in roots], np.uint64)
+        out[f"{tag}_root_keys"] = rk
+        out[f"{tag}_root_heads"] = np.stack([rec[tag][int(k)][0] for k in rk]).astype(np.float32)
+    np.savez_compressed(os.path.join(OUT, "g14_eval_arena.npz"), **out)
+    print(f"[g14] result={result} game lengths={[len(v) for v in moves.values()]} "
+          f"evaluations chall/opp={len(rec['chall'])}/{len(rec['opp'])}")
+
+
+# --------------------------------------------------------------------------------------------
 # G11: training loss (values + autograd gradients of the reference's functions)
 # --------------------------------------------------------------------------------------------
 def gen_loss():
@@ -814,6 +902,8 @@ def main():
         gen_net(chosen)
     if not which or "g10" in which:
         gen_tree_selfplay()
+    if not which or "g14" in which:
+        gen_eval_arena()
     if not which or "g13" in which:
         gen_legacy_waves()
     if not which or "g12" in which:
