@@ -36,8 +36,17 @@ typedef enum LzStatus {
     LZ_ERR_ARG = -1,          /* null pointer / negative size / inconsistent dims */
     LZ_ERR_UNSUPPORTED = -2,  /* dims outside what the kernels are built for */
     LZ_ERR_LAUNCH = -3,       /* hipGetLastError() != hipSuccess after launch */
-    LZ_ERR_ALIGN = -4         /* pointer not aligned as documented */
+    LZ_ERR_ALIGN = -4,        /* pointer not aligned as documented */
+    LZ_ERR_ILLEGAL = -5       /* host library only: an action is illegal for its state (the reference's CPU path raises
+                                 there, fast_apply_moves.cpp:264-470; the device path is a silent no-op) */
 } LzStatus;
+
+/* Two builds export this ABI:
+ *   libliuzhou_hip.so  (hipcc, gfx950): everything below, pointers are DEVICE memory, launches on `stream`;
+ *   libliuzhou_host.so (g++, csrc/lz_host.cpp): the v0_core OPERATOR subset (lz_encode_actions_fast .. lz_finalize_
+ *     trajectory_inplace incl. lz_root_pack_*), pointers are HOST memory, `stream` is ignored -- what the Python
+ *     `v0_core` module dispatches CPU tensors to, as the reference extension does (fast_legal_mask.cpp:453).
+ * The search engines, the network kernels, the RNG and the trainer / codec kernels exist in the device build only. */
 
 /* 12-tensor state batch.  board int8[B,36] in {-1,0,1}; marks bool(uint8)[B,36]; the rest int64[B].
  * board / marks rows must be 4-byte aligned (they are for any contiguous torch tensor). */

@@ -101,9 +101,52 @@ def lib() -> C.CDLL:
     return _lib
 
 
+_host: Optional[C.CDLL] = None
+HOST_SYMBOLS = ("lz_version", "lz_status_string", "lz_encode_actions_fast", "lz_batch_apply_moves",
+                "lz_batch_apply_moves_inplace", "lz_states_to_model_input", "lz_project_policy_logits_fast",
+                "lz_root_pack_rows", "lz_root_pack_plan", "lz_root_pack_fill", "lz_root_puct_allocate_visits",
+                "lz_root_finalize_from_visits", "lz_self_play_step_inplace", "lz_finalize_trajectory_inplace")
+_STATUS = {0: "ok", -1: "invalid argument", -2: "unsupported dimensions", -3: "kernel launch failed",
+           -4: "misaligned pointer", -5: "illegal action for the state"}
+
+
+def host_lib() -> C.CDLL:
+    """libliuzhou_host.so: the operator subset of the same C ABI over HOST memory (csrc/lz_host.cpp, g++).  Only the
+    `v0_core` operators dispatch here, for CPU tensors, like the reference extension (fast_legal_mask.cpp:453)."""
+    global _host
+    if _host is None:
+        from .build import HOST_LIB, build_host
+        path = HOST_LIB if os.path.exists(HOST_LIB) else build_host()
+        H = C.CDLL(path)
+        for name in HOST_SYMBOLS:
+            fn = getattr(H, name)
+            fn.restype, fn.argtypes = DECLS[name]
+        _host = H
+    return _host
+
+
+def lib_for(t: torch.Tensor) -> C.CDLL:
+    """Device dispatch of a v0_core operator: HIP tensors -> the gfx950 kernels, CPU tensors -> the host build.  There is
+    no fallback in either direction: a missing library is an error."""
+    return lib() if t.is_cuda else host_lib()
+
+
+class device_ctx:
+    """`torch.cuda.device(dev)` for HIP tensors, nothing for CPU tensors."""
+
+    def __init__(self, device) -> None:
+        self._cm = torch.cuda.device(device) if torch.device(device).type == "cuda" else None
+
+    def __enter__(self):
+        return self._cm.__enter__() if self._cm is not None else None
+
+    def __exit__(self, *exc):
+        return self._cm.__exit__(*exc) if self._cm is not None else False
+
+
 def check(status: int, op: str) -> None:
     if status != 0:
-        raise RuntimeError(f"liuzhou_amd.{op} failed: {lib().lz_status_string(int(status)).decode()} ({status})")
+        raise RuntimeError(f"liuzhou_amd.{op} failed: {_STATUS.get(int(status), 'unknown status')} ({status})")
 
 
 def require_hip(t: torch.Tensor, op: str) -> None:
@@ -114,6 +157,8 @@ def require_hip(t: torch.Tensor, op: str) -> None:
 
 
 def stream_ptr(device: torch.device) -> C.c_void_p:
+    if torch.device(device).type != "cuda":
+        return C.c_void_p(None)                            # host build: no stream
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 

@@ -19,6 +19,27 @@ def hipcc_path() -> str:
     raise RuntimeError("hipcc not found (expected /opt/rocm/bin/hipcc)")
 
 
+HOST_LIB = os.path.join(PKG, "libliuzhou_host.so")
+HOST_SOURCE = os.path.join(CSRC, "lz_host.cpp")
+
+
+def build_host(force: bool = False, verbose: bool = False) -> str:
+    """g++ -> liuzhou_amd/libliuzhou_host.so: the operator subset of the C ABI for CPU tensors (csrc/lz_host.cpp)."""
+    deps = [HOST_SOURCE] + [os.path.join(CSRC, h) for h in HEADERS]
+    if not force and os.path.exists(HOST_LIB) and all(
+            (not os.path.exists(d)) or os.path.getmtime(d) <= os.path.getmtime(HOST_LIB) for d in deps):
+        return HOST_LIB
+    cxx = os.environ.get("CXX") or shutil.which("g++") or shutil.which("c++")
+    if not cxx:
+        raise RuntimeError("no host C++ compiler (g++) found for libliuzhou_host.so")
+    cmd = [cxx, "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-fvisibility=hidden", "-o", HOST_LIB,
+           HOST_SOURCE]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return HOST_LIB
+
+
 def needs_build() -> bool:
     if not os.path.exists(LIB):
         return True
@@ -43,3 +64,4 @@ def build_hip(force: bool = False, verbose: bool = False) -> str:
 
 if __name__ == "__main__":
     print(build_hip(force=True, verbose=True))
+    print(build_host(force=True, verbose=True))

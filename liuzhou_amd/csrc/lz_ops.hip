@@ -1028,6 +1028,7 @@ const char* lz_status_string(int status) {
         case LZ_ERR_UNSUPPORTED: return "unsupported dimensions";
         case LZ_ERR_LAUNCH: return "kernel launch failed";
         case LZ_ERR_ALIGN: return "misaligned pointer";
+        case LZ_ERR_ILLEGAL: return "illegal action";
         default: return "unknown status";
     }
 }

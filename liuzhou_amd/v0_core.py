@@ -3,7 +3,10 @@
 Python-side mirror of the reference's PyBind11 module (v0/src/bindings/module.cpp:874-1482): same
 operator names, argument names/order, dtypes, shapes and return tuples, for the operators the v1
 self-play path uses.  Every operator launches hand-written gfx950 kernels through the C ABI of
-libliuzhou_hip.so on the *current* torch stream; tensors must be on a HIP device (no CPU path).
+libliuzhou_hip.so on the *current* torch stream.  Like the reference extension, which dispatches on
+`board.device().is_cuda()` (v0/src/game/fast_legal_mask.cpp:453), CPU tensors go to the host build of the same ABI
+(libliuzhou_host.so, csrc/lz_host.cpp: plain loops over the same bitboard rules) with the reference's CPU error
+convention (an illegal action raises); the search engines and the network kernel are HIP-only.
 
 Drop-in use: put `liuzhou_amd/dropin` on PYTHONPATH, then `import v0_core` resolves to this module.
 """
@@ -55,7 +58,6 @@ def encode_actions_fast(board, marks_black, marks_white, phase, current_player, 
                         forced_removals_done, placement_dim: int, movement_dim: int, selection_dim: int,
                         auxiliary_dim: int) -> Tuple[torch.Tensor, torch.Tensor]:
     """module.cpp:1294-1310 -> (mask bool[B,T], metadata int32[B,T,4])"""
-    L.require_hip(board, "encode_actions_fast")
     ts = _state12(board, marks_black, marks_white, phase, current_player, pending_marks_required,
                   pending_marks_remaining, pending_captures_required, pending_captures_remaining,
                   forced_removals_done)
@@ -64,8 +66,8 @@ def encode_actions_fast(board, marks_black, marks_white, phase, current_player, 
     mask = torch.empty((B, T), dtype=torch.bool, device=board.device)
     meta = torch.empty((B, T, 4), dtype=torch.int32, device=board.device)
     s = L.soa(ts)
-    with torch.cuda.device(board.device):
-        st = L.lib().lz_encode_actions_fast(C.byref(s), L.i64(B), L.i64(placement_dim), L.i64(movement_dim),
+    with L.device_ctx(board.device):
+        st = L.lib_for(board).lz_encode_actions_fast(C.byref(s), L.i64(B), L.i64(placement_dim), L.i64(movement_dim),
                                             L.i64(selection_dim), L.i64(auxiliary_dim), L.ptr(mask), L.ptr(meta),
                                             L.stream_ptr(board.device))
     L.check(st, "encode_actions_fast")
@@ -84,7 +86,6 @@ def batch_apply_moves(board, marks_black, marks_white, phase, current_player, pe
                       pending_marks_remaining, pending_captures_required, pending_captures_remaining,
                       forced_removals_done, move_count, moves_since_capture, action_codes, parent_indices):
     """module.cpp:1311-1327 -> 12-tuple of child tensors [N,...] (GPU semantics: illegal == no-op)."""
-    L.require_hip(board, "batch_apply_moves")
     ts = _state12(board, marks_black, marks_white, phase, current_player, pending_marks_required,
                   pending_marks_remaining, pending_captures_required, pending_captures_remaining,
                   forced_removals_done, move_count, moves_since_capture)
@@ -97,8 +98,8 @@ def batch_apply_moves(board, marks_black, marks_white, phase, current_player, pe
         raise RuntimeError("parent_indices must align with action_codes.")
     out = _alloc_states(N, board.device)
     si, so = L.soa(ts), L.soa(out)
-    with torch.cuda.device(board.device):
-        st = L.lib().lz_batch_apply_moves(C.byref(si), L.i64(ts[0].shape[0]), L.ptr(codes), L.ptr(parents),
+    with L.device_ctx(board.device):
+        st = L.lib_for(board).lz_batch_apply_moves(C.byref(si), L.i64(ts[0].shape[0]), L.ptr(codes), L.ptr(parents),
                                           L.i64(N), C.byref(so), L.stream_ptr(board.device))
     L.check(st, "batch_apply_moves")
     return tuple(out)
@@ -108,7 +109,6 @@ def batch_apply_moves_inplace(board, marks_black, marks_white, phase, current_pl
                               pending_marks_remaining, pending_captures_required, pending_captures_remaining,
                               forced_removals_done, move_count, moves_since_capture, action_codes, slot_indices):
     """fast_apply_moves_cuda.cu:746-917 (state tensors must be contiguous; they are mutated)."""
-    L.require_hip(board, "batch_apply_moves_inplace")
     ts = [board, marks_black, marks_white, phase, current_player, pending_marks_required, pending_marks_remaining,
           pending_captures_required, pending_captures_remaining, forced_removals_done, move_count,
           moves_since_capture]
@@ -118,22 +118,21 @@ def batch_apply_moves_inplace(board, marks_black, marks_white, phase, current_pl
     codes = _c(action_codes.to(board.device), torch.int32)
     slots = _c(slot_indices.to(board.device), torch.int64).view(-1)
     s = L.soa(ts)
-    with torch.cuda.device(board.device):
-        st = L.lib().lz_batch_apply_moves_inplace(C.byref(s), L.i64(board.shape[0]), L.ptr(codes), L.ptr(slots),
+    with L.device_ctx(board.device):
+        st = L.lib_for(board).lz_batch_apply_moves_inplace(C.byref(s), L.i64(board.shape[0]), L.ptr(codes), L.ptr(slots),
                                                   L.i64(slots.numel()), L.stream_ptr(board.device))
     L.check(st, "batch_apply_moves_inplace")
 
 
 def states_to_model_input(board, marks_black, marks_white, phase, current_player) -> torch.Tensor:
     """module.cpp:1286-1293 -> float32[B,11,6,6]"""
-    L.require_hip(board, "states_to_model_input")
     b = _c(board, torch.int8)
     mb, mw = _c(marks_black, torch.bool), _c(marks_white, torch.bool)
     ph, cp = _c(phase, torch.int64), _c(current_player, torch.int64)
     B = int(b.shape[0])
     out = torch.empty((B, 11, 6, 6), dtype=torch.float32, device=board.device)
-    with torch.cuda.device(board.device):
-        st = L.lib().lz_states_to_model_input(L.ptr(b), L.ptr(mb), L.ptr(mw), L.ptr(ph), L.ptr(cp), L.i64(B),
+    with L.device_ctx(board.device):
+        st = L.lib_for(board).lz_states_to_model_input(L.ptr(b), L.ptr(mb), L.ptr(mw), L.ptr(ph), L.ptr(cp), L.i64(B),
                                               L.ptr(out), L.stream_ptr(board.device))
     L.check(st, "states_to_model_input")
     return out
@@ -142,7 +141,6 @@ def states_to_model_input(board, marks_black, marks_white, phase, current_player
 def project_policy_logits_fast(log_p1, log_p2, log_pmc, legal_mask, placement_dim: int, movement_dim: int,
                                selection_dim: int, auxiliary_dim: int):
     """module.cpp:1328-1338 -> (probs, masked_logits) in the heads' dtype (computed in fp32)."""
-    L.require_hip(log_p1, "project_policy_logits_fast")
     if legal_mask.dtype != torch.bool:
         raise RuntimeError("legal_mask must be of dtype bool.")
     if not (log_p1.dtype == log_p2.dtype == log_pmc.dtype):
@@ -158,8 +156,8 @@ def project_policy_logits_fast(log_p1, log_p2, log_pmc, legal_mask, placement_di
     mk = _c(legal_mask, torch.bool)
     probs = torch.empty((B, T), dtype=torch.float32, device=log_p1.device)
     ml = torch.empty((B, T), dtype=torch.float32, device=log_p1.device)
-    with torch.cuda.device(log_p1.device):
-        st = L.lib().lz_project_policy_logits_fast(L.ptr(p1), L.ptr(p2), L.ptr(pm), L.ptr(mk), L.i64(B),
+    with L.device_ctx(log_p1.device):
+        st = L.lib_for(log_p1).lz_project_policy_logits_fast(L.ptr(p1), L.ptr(p2), L.ptr(pm), L.ptr(mk), L.i64(B),
                                                    L.i64(placement_dim), L.i64(movement_dim), L.i64(selection_dim),
                                                    L.i64(auxiliary_dim), L.ptr(probs), L.ptr(ml),
                                                    L.stream_ptr(log_p1.device))
@@ -174,7 +172,6 @@ PACK_CAP = 80   # >= max legal actions of any state (placement 36, movement <= 7
 
 def root_pack_rows(legal_mask, probs, metadata, cap: int = PACK_CAP):
     """Sync-free fixed-capacity form: (counts i32[B], legal_index i32[B,cap], priors f32[B,cap], codes i32[B,cap,4])."""
-    L.require_hip(legal_mask, "root_pack_sparse_actions")
     mk = _c(legal_mask, torch.bool)
     pr = _c(probs, torch.float32)
     md = _c(metadata, torch.int32)
@@ -184,8 +181,8 @@ def root_pack_rows(legal_mask, probs, metadata, cap: int = PACK_CAP):
     lidx = torch.empty((B, cap), dtype=torch.int32, device=dev)
     pri = torch.empty((B, cap), dtype=torch.float32, device=dev)
     codes = torch.empty((B, cap, 4), dtype=torch.int32, device=dev)
-    with torch.cuda.device(dev):
-        st = L.lib().lz_root_pack_rows(L.ptr(mk), L.ptr(pr), L.ptr(md), L.i64(B), L.i64(T), L.i64(cap),
+    with L.device_ctx(dev):
+        st = L.lib_for(mk).lz_root_pack_rows(L.ptr(mk), L.ptr(pr), L.ptr(md), L.i64(B), L.i64(T), L.i64(cap),
                                        L.ptr(counts), L.ptr(lidx), L.ptr(pri), L.ptr(codes), L.stream_ptr(dev))
     L.check(st, "root_pack_sparse_actions")
     return counts, lidx, pri, codes
@@ -204,8 +201,8 @@ def root_pack_sparse_actions(legal_mask, probs, metadata):
     rank = torch.empty((B,), dtype=torch.int32, device=dev)
     child_off = torch.empty((B,), dtype=torch.int64, device=dev)
     sizes = torch.zeros((3,), dtype=torch.int64, device=dev)
-    with torch.cuda.device(dev):
-        L.check(L.lib().lz_root_pack_plan(L.ptr(counts), L.i64(B), L.ptr(rank), L.ptr(child_off), L.ptr(sizes),
+    with L.device_ctx(dev):
+        L.check(L.lib_for(counts).lz_root_pack_plan(L.ptr(counts), L.i64(B), L.ptr(rank), L.ptr(child_off), L.ptr(sizes),
                                           L.stream_ptr(dev)), "root_pack_sparse_actions")
     R, M, N = (int(v) for v in sizes.tolist())                     # the one host synchronisation
     e = lambda shape, dt: torch.empty(shape, dtype=dt, device=dev)
@@ -216,8 +213,8 @@ def root_pack_sparse_actions(legal_mask, probs, metadata):
     valid_mask, legal_index_mat = e((R, M), torch.bool), e((R, M), torch.int64)
     priors_mat, action_code_mat = e((R, M), torch.float32), e((R, M, 4), torch.int32)
     pack_flat_idx, action_codes_all, parent_indices_all = e((N,), torch.int64), e((N, 4), torch.int32), e((N,), torch.int64)
-    with torch.cuda.device(dev):
-        L.check(L.lib().lz_root_pack_fill(
+    with L.device_ctx(dev):
+        L.check(L.lib_for(counts).lz_root_pack_fill(
             L.ptr(counts), L.ptr(lidx), L.ptr(pri), L.ptr(codes), L.ptr(rank), L.ptr(child_off), L.i64(B),
             L.i64(int(lidx.shape[1])), L.i64(R), L.i64(M), L.i64(N), L.ptr(terminal_mask), L.ptr(valid_root_indices),
             L.ptr(counts_v), L.ptr(valid_mask), L.ptr(legal_index_mat), L.ptr(priors_mat), L.ptr(action_code_mat),
@@ -235,7 +232,6 @@ def root_puct_allocate_visits(priors, leaf_values, valid_mask, num_simulations: 
         raise RuntimeError("priors, leaf_values and valid_mask shape mismatch")
     if int(num_simulations) <= 0:
         raise RuntimeError("num_simulations must be positive")
-    L.require_hip(priors, "root_puct_allocate_visits")
     p = _c(priors, torch.float32)
     lv = _c(leaf_values, torch.float32)
     vm = _c(valid_mask, torch.bool)
@@ -246,8 +242,8 @@ def root_puct_allocate_visits(priors, leaf_values, valid_mask, num_simulations: 
     rv = torch.zeros((R,), dtype=torch.float32, device=dev)
     if R == 0 or A == 0:
         return visits, vs, rv
-    with torch.cuda.device(dev):
-        st = L.lib().lz_root_puct_allocate_visits(L.ptr(p), L.ptr(lv), L.ptr(vm), L.i64(R), L.i64(A),
+    with L.device_ctx(dev):
+        st = L.lib_for(p).lz_root_puct_allocate_visits(L.ptr(p), L.ptr(lv), L.ptr(vm), L.i64(R), L.i64(A),
                                                   L.i64(num_simulations), C.c_float(float(exploration_weight)),
                                                   L.ptr(visits), L.ptr(vs), L.ptr(rv), L.stream_ptr(dev))
     L.check(st, "root_puct_allocate_visits")
@@ -261,7 +257,6 @@ def root_finalize_from_visits(legal_index_mat, action_code_mat, valid_mask, visi
     i32[B,4], chosen_valid_mask bool[B], root_value f32[R]).  sample_moves draws one Philox uniform per
     root on the device (or uses the injected `uniforms` for parity runs) and samples by inverse CDF from
     the log-space policy of mcts_gpu.py:853-898."""
-    L.require_hip(visits, "root_finalize_from_visits")
     dev = visits.device
     li = _c(legal_index_mat, torch.int64)
     ac = _c(action_code_mat, torch.int32)
@@ -281,8 +276,8 @@ def root_finalize_from_visits(legal_index_mat, action_code_mat, valid_mask, visi
     u = None
     if sample_moves and M > 1:
         u = _c(uniforms, torch.float32) if uniforms is not None else torch.rand((R,), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
-        st = L.lib().lz_root_finalize_from_visits(L.ptr(li), L.ptr(ac), L.ptr(vm), L.ptr(vi), L.ptr(vs),
+    with L.device_ctx(dev):
+        st = L.lib_for(vi).lz_root_finalize_from_visits(L.ptr(li), L.ptr(ac), L.ptr(vm), L.ptr(vi), L.ptr(vs),
                                                   L.ptr(roots), L.i64(R), L.i64(M), L.i64(B), L.i64(T), L.ptr(temps),
                                                   L.ptr(u), L.ptr(policy), L.ptr(cidx), L.ptr(ccodes), L.ptr(cvalid),
                                                   L.ptr(rv), L.stream_ptr(dev))
@@ -311,8 +306,8 @@ def self_play_step_raw(state12, plies, done, active_idx, chosen_action_codes, te
     res = torch.empty((A,), dtype=torch.float32, device=dev)
     soft = torch.empty((A,), dtype=torch.float32, device=dev)
     s = L.soa(state12)
-    with torch.cuda.device(dev):
-        st = L.lib().lz_self_play_step_inplace(C.byref(s), L.i64(board.shape[0]), L.ptr(plies), L.ptr(done),
+    with L.device_ctx(dev):
+        st = L.lib_for(board).lz_self_play_step_inplace(C.byref(s), L.i64(board.shape[0]), L.ptr(plies), L.ptr(done),
                                                L.ptr(act), L.i64(A), L.ptr(codes), L.ptr(term), L.ptr(cval),
                                                L.i64(max_game_plies), C.c_float(float(soft_value_k)), L.ptr(kind),
                                                L.ptr(res), L.ptr(soft), L.stream_ptr(dev))
@@ -330,7 +325,6 @@ def self_play_step_inplace(board, marks_black, marks_white, phase, current_playe
     each in active order (module.cpp:724-741, :838-856)."""
     if int(max_game_plies) <= 0:
         raise RuntimeError("max_game_plies must be positive")
-    L.require_hip(board, "self_play_step_inplace")
     if done.dtype != torch.bool or plies.dtype != torch.int64:
         raise RuntimeError("plies must be int64 and done must be bool")
     st12 = [board, marks_black, marks_white, phase, current_player, pending_marks_required,
@@ -348,7 +342,6 @@ def self_play_step_inplace(board, marks_black, marks_white, phase, current_playe
 def finalize_trajectory_inplace(value_targets, soft_value_targets, player_signs, step_index_matrix, step_counts,
                                 slots, result_from_black, soft_value_from_black):
     """module.cpp:1410-1420 -> (final_slots, final_counts, counts_out i64[3]); mutates the two targets."""
-    L.require_hip(value_targets, "finalize_trajectory_inplace")
     dev = value_targets.device
     if not (value_targets.is_contiguous() and soft_value_targets.is_contiguous()):
         raise RuntimeError("target buffers must be contiguous")
@@ -369,8 +362,8 @@ def finalize_trajectory_inplace(value_targets, soft_value_targets, player_signs,
     sc = _c(step_counts, torch.int64)
     keep = torch.empty((F,), dtype=torch.bool, device=dev)
     fcounts = torch.empty((F,), dtype=torch.int64, device=dev)
-    with torch.cuda.device(dev):
-        st = L.lib().lz_finalize_trajectory_inplace(L.ptr(value_targets), L.ptr(soft_value_targets), L.ptr(signs),
+    with L.device_ctx(dev):
+        st = L.lib_for(value_targets).lz_finalize_trajectory_inplace(L.ptr(value_targets), L.ptr(soft_value_targets), L.ptr(signs),
                                                     L.ptr(sim), L.ptr(sc), L.i64(sim.shape[0]), L.i64(sim.shape[1]),
                                                     L.ptr(sl), L.ptr(res), L.ptr(sft), L.i64(F), L.ptr(keep),
                                                     L.ptr(fcounts), L.ptr(counts_out), L.stream_ptr(dev))

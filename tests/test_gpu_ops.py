@@ -275,10 +275,17 @@ def test_finalize_trajectory_inplace(v0):
     assert np.array_equal(co.cpu().numpy(), z["traj_counts_out"])
 
 
-def test_cpu_tensors_fail_loudly(v0):
-    t = [torch.from_numpy(np.asarray(v)) for v in O.initial_states(2).values()]
-    with pytest.raises(RuntimeError, match="CUDA kernels were not built"):
-        v0.encode_actions_fast(*t[:10], 36, 144, 36, 4)
+def test_cpu_and_hip_tensors_dispatch_to_their_own_build(v0):
+    """Device dispatch like the reference extension (fast_legal_mask.cpp:453): the same call on CPU tensors runs the host
+    build and returns CPU tensors with the same contents as the HIP kernels."""
+    z = load("g1_rules.npz")
+    st = states(z, "s")
+    t_dev = to_dev(st)
+    t_cpu = [t.cpu() for t in t_dev]
+    m1, d1 = v0.encode_actions_fast(*t_dev[:10], 36, 144, 36, 4)
+    m2, d2 = v0.encode_actions_fast(*t_cpu[:10], 36, 144, 36, 4)
+    assert m1.is_cuda and not m2.is_cuda
+    assert torch.equal(m1.cpu(), m2) and torch.equal(d1.cpu(), d2)
 
 
 def test_model_fp32_matches_reference_outputs(v0):

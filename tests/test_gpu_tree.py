@@ -342,7 +342,7 @@ def test_tree_engine_degenerate_sizes():
     assert L.lib().lz_tree_begin(C.byref(d), None) == -1
     d.nodes = eng.desc.nodes
     d.node_cap = 70000
-    assert L.lib().lz_tree_advance(C.byref(d), None, None, L.i64(4), None, None) == -1      # 16-bit owner ids
+    assert L.lib().lz_tree_advance(C.byref(d), None, None, L.i64(4), None, None) == -2      # > 16384 nodes: unsupported
 
 
 def test_auto_reuse_factor_is_bounded_by_memory_and_node_limit():

@@ -24,15 +24,15 @@ def test_c_abi_exports_every_declared_symbol():
     assert b"gfx950" in lib.lz_version()
 
 
-def test_ops_fail_loudly_without_gpu():
-    from liuzhou_amd import v0_core
-    from liuzhou_amd.mcts_gpu import GpuStateBatch
-    st = GpuStateBatch.initial("cpu", 2)
-    with pytest.raises(RuntimeError, match="HIP device"):
-        v0_core.encode_actions_fast(*st.tensors()[:10], 36, 144, 36, 4)
+def test_engines_fail_loudly_without_gpu():
+    """The v0_core OPERATORS dispatch CPU tensors to the host build (tests/test_host_ops.py); the search engines and the
+    network kernel are HIP-only and say so."""
     from liuzhou_amd.tree_engine import TreeEngine
     with pytest.raises(RuntimeError, match="HIP device"):
         TreeEngine(4, 8, "cpu")
+    from liuzhou_amd.game_rng import GameRng
+    with pytest.raises(RuntimeError, match="HIP device"):
+        GameRng(4, "cpu")
 
 
 def test_storage_planning_and_payload(tmp_path):
