@@ -55,11 +55,11 @@ WAVE_PATH_CAP = 64             # entries per leaf path of a wave (the kernel fol
 REUSE_EDGES_PER_NODE = 40      # arena sizing for kept subtrees (average fan-out is ~25; overflow drops the subtree)
 
 
-def auto_reuse_factor(num_games: int, sims: int, device, memory_fraction: float = 0.72, cap: float = 16.0) -> float:
+def auto_reuse_factor(num_games: int, sims: int, device, memory_fraction: float = 0.80, cap: float = 16.0) -> float:
     """Room for kept subtrees, as a multiple of `sims` nodes per game: as much as fits in `memory_fraction` of the
     device's free memory (a kept subtree that would leave no room for the next search is dropped, so more room = fewer
     deviations from the reference's unbounded tree; measured on C2: 2 425 / 224 / 12 / 0 drops per 1.2 M moves at
-    factor 3 / 6 / 10 / 16; C3 at factor 4: 278 per 0.5 M moves), at most `cap` and at most what 16 384 nodes per game
+    factor 3 / 6 / 10 / 16; C3: 278 per 0.5 M moves at factor 4, 0-3 at 10.75), at most `cap` and at most what 16 384 nodes per game
     allow.  The arenas are the one large consumer of the 288 GB: nothing else on the path needs more than a few GB."""
     free, _total = torch.cuda.mem_get_info(torch.device(device))
     per_game = free * float(memory_fraction) / max(1, int(num_games))
