@@ -94,3 +94,24 @@ def test_gather_with_empty_rank_world2_gloo():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert dict((k, v) for k, v in items if k != "digest").get("gather") is True
+
+
+def test_bench_spawns_its_own_ranks_and_relays_rank0_line():
+    """`bench.py --gpus 2` started as a plain process (what the driver's N > 1 fallback does) must start the two ranks
+    itself, run the barrier / max-over-ranks protocol and print rank 0's single JSON line.  `--dry-run` replaces the GPU
+    work by a gloo group and no-op steps, so the spawning path runs on a CPU box."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    env["LZ_BENCH_PORT"] = str(_free_port())
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "1",
+                        "--dry-run"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 5 and out["dry_run"] is True
+    assert out["ms_per_step"] >= 2.0                      # rank 1 sleeps 2 ms per step: the MAX over ranks was taken
