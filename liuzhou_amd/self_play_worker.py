@@ -140,6 +140,10 @@ def write_worker_chunks(run_once, *, worker_idx: int, device: str, games: int, g
     while remaining > 0:
         n = min(int(games_per_chunk), remaining)
         batch, st = run_once(n)
+        if int((st.mcts_counters or {}).get("graph_retry_off", 0)):
+            # a hipGraph capture failed in this chunk and the engine went on with direct launches (the reference records
+            # the same about its finalize graph, v1/python/self_play_worker.py:434-442,475)
+            meta_common["graph_retry_off"] = True
         cpu = batch.to("cpu")
         stats_chunks.append(st)
         val_s.append(summarize_scalar_targets(cpu.value_targets))
@@ -217,14 +221,17 @@ def run_self_play_worker(*, worker_idx: int, shard_device: str, shard_games: int
         if int(model.stem_conv.weight.shape[0]) in (64, 128):
             from .net_hip import FusedNet
             evaluator = FusedNet(model, dev)
-        elif backend in ("portable", "tree"):
-            raise RuntimeError("the tree engine needs the fused network kernel (64 / 128 trunk channels)")
+        # other widths: the module itself is the (external fp32) evaluator of the tree engine / the root search
         chunk_dir, prefix = str(chunk_output_dir or "").strip(), str(chunk_file_prefix or "").strip()
         if not chunk_dir or not prefix:
             raise ValueError("run_self_play_worker requires chunk_output_dir and chunk_file_prefix to emit worker "
                              "manifest output.")
 
+        chunk_no = [0]
+
         def run_once(n: int):
+            chunk_no[0] += 1                  # every chunk plays NEW games: its own RNG key (game ids restart per chunk)
+            rng_seed = (int(seed) * 1000003 + chunk_no[0]) & 0x7FFFFFFFFFFFFFFF
             common = dict(num_games=n, mcts_simulations=int(mcts_simulations), temperature_init=float(temperature_init),
                           temperature_final=float(temperature_final), temperature_threshold=int(temperature_threshold),
                           exploration_weight=float(exploration_weight), device=str(dev), add_dirichlet_noise=True,
@@ -236,7 +243,7 @@ def run_self_play_worker(*, worker_idx: int, shard_device: str, shard_games: int
                 return self_play_tree_gpu(evaluator, opening_random_moves=int(opening_random_moves),
                                           policy_target_temperature=policy_target_temperature,
                                           policy_target_prior_pseudocount=float(policy_target_prior_pseudocount),
-                                          **common)
+                                          seed=rng_seed, collect_timing=True, **common)
             from .self_play_gpu_runner import self_play_v1_gpu
             return self_play_v1_gpu(evaluator, opening_random_moves=int(opening_random_moves), sparse_ply=int(sparse_ply),
                                     sparse_top_k=int(sparse_top_k), **common)
