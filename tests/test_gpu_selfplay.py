@@ -376,3 +376,39 @@ def test_tree_runner_with_a_module_as_external_evaluator():
     assert np.array_equal(batch.state_tensors[0].cpu().numpy(), want[0])      # the opening position
     assert torch.allclose(batch.policy_targets.sum(1), torch.ones(batch.num_samples, device="cuda:0"), atol=1e-5)
     assert bool((batch.policy_targets[~batch.legal_masks] == 0).all())
+
+
+def test_fused_root_search_rng_is_independent_of_the_batch_split():
+    """Root noise and sampled picks of the fused root search come from the per-game counter RNG: one search over all
+    games == two half-size searches on two streams (DualStreamRootSearch), noise and sampling on, over several plies;
+    another seed plays other moves."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from liuzhou_amd import v0_core
+    from liuzhou_amd.net import ChessNet, MODEL_CONFIGS
+    from liuzhou_amd.net_hip import FusedNet
+    from liuzhou_amd.mcts_gpu import GpuStateBatch
+    from liuzhou_amd.root_search_fused import DualStreamRootSearch, FusedRootSearch
+    dev = "cuda:0"
+    torch.manual_seed(20260314)
+    net = FusedNet(ChessNet(**MODEL_CONFIGS["b6c64"]).eval().to(dev))
+    B = 70
+    kw = dict(add_dirichlet_noise=True, sample_moves=True, seed=99)
+    one, two = FusedRootSearch(net, B, 32, dev, **kw), DualStreamRootSearch(net, B, 32, dev, **kw)
+    other = FusedRootSearch(net, B, 32, dev, **{**kw, "seed": 100})
+    s1, s2 = GpuStateBatch.initial(dev, B), GpuStateBatch.initial(dev, B)
+    temps = torch.ones(B, device=dev)
+    differs = False
+    for ply in range(6):
+        plies = torch.full((B,), ply, dtype=torch.int64, device=dev)
+        o1 = one.search_batch(s1, temperatures=temps, rng_plies=plies)
+        o2 = two.search_batch(s2, temperatures=temps, rng_plies=plies)
+        o3 = other.search_batch(s1, temperatures=temps, rng_plies=plies)
+        assert torch.equal(o1.chosen_action_indices, o2.chosen_action_indices), ply
+        assert torch.equal(o1.policy_dense, o2.policy_dense), ply
+        differs = differs or not torch.equal(o1.chosen_action_indices, o3.chosen_action_indices)
+        for s, o in ((s1, o1), (s2, o2)):
+            p = torch.zeros(B, dtype=torch.int64, device=dev); d = torch.zeros(B, dtype=torch.bool, device=dev)
+            v0_core.self_play_step_inplace(*s.tensors(), p, d, torch.arange(B, device=dev), o.chosen_action_codes.clone(),
+                                           o.terminal_mask.clone(), o.chosen_valid_mask.clone(), 512, 2.0)
+    assert differs
