@@ -111,3 +111,31 @@ def test_compact_gather_with_an_empty_rank():
 def test_unrepresentable_row_makes_every_rank_raise():
     items = _run("bad", 2)
     assert sorted(r for r, _, _ in items) == [0, 1] and all(v is True for _, _, v in items)
+
+
+def test_bench_two_ranks_with_gather_in_the_timed_region():
+    """`bench.py --gpus 2 --include-gather` (C4's code path: games sharded over the ranks, barrier + max-over-ranks timing,
+    the compact gather of the timed steps' rows inside the timed region) started as a plain process: it spawns its two
+    ranks itself.  Both ranks share cuda:0 here (gloo group; RCCL refuses two ranks per device), small workload."""
+    import json
+    import subprocess
+    import sys
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    env.update(LZ_BENCH_BACKEND="gloo", LZ_BENCH_SHARE_GPU="1", LZ_BENCH_PORT=str(_free_port()))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
+                        "--games", "256", "--sims", "16", "--model", "b6c64", "--soak-seconds", "0", "--include-gather",
+                        "--reuse-factor", "2", "--no-probe"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 4 and out["scaling"] == "weak"
+    assert abs(out["value"] - 2 * 256 * 4 / (out["ms_per_step"] * 4e-3)) < 1e-6 * out["value"] + 1.0
+    g = out["gather"]
+    assert g["rows_on_rank0"] == 2 * 256 * 4 and g["record_bytes"] == 360 and g["bytes_received"] == 256 * 4 * 360
+    assert "gathered to rank 0" in out["config"]["workload"]
