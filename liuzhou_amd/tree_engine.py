@@ -751,7 +751,10 @@ class SteadyStateTreeSelfPlay:
             self.mcts = DualStreamTreeMCTS(self.net, num_games, sims, dev, exploration_weight=exploration_weight,
                                            reuse_tree=reuse_tree, reuse_factor=reuse_factor, batch_k=batch_k, seed=seed)
         else:
-            self.mcts = PortableTreeMCTS(self.net, num_games, sims, dev, exploration_weight, reuse_tree=reuse_tree,
+            one = self.net
+            if os.environ.get("LZ_SINGLE_STREAM_HALF_WG", "0") == "1":      # experiment: 4-wave workgroups, two per CU, one stream
+                one = self.net.variant(half_workgroups=True)
+            self.mcts = PortableTreeMCTS(one, num_games, sims, dev, exploration_weight, reuse_tree=reuse_tree,
                                          reuse_factor=reuse_factor, batch_k=batch_k, seed=seed)
         self._reseated = torch.zeros((self.B,), dtype=torch.uint8, device=dev)
         self.positions = 0

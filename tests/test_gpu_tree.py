@@ -531,3 +531,17 @@ def test_device_rng_equals_oracle_and_is_independent_of_the_batch_split():
     b = PortableTreeMCTS(net, 96, 40, DEV, **kw).search_batch(batch, temperatures=temps).chosen_action_indices.clone()
     c = PortableTreeMCTS(net, 96, 40, DEV, **{**kw, "seed": 4243}).search_batch(batch, temperatures=temps).chosen_action_indices
     assert torch.equal(a, b) and not torch.equal(a, c)      # same seed: same games; another seed: other games
+
+
+def test_production_search_path_on_edge_states():
+    """The reference tests' representative / terminal states (g2: finished games, a MARK_SELECTION state without a legal
+    move, forced-removal states ...) through the production launch path, two moves: terminal roots stay inactive, no-legal
+    leaves back up -1, everything else is replayed bit for bit."""
+    _need_gpu()
+    from tests.tree_parity import run_production_parity
+    z = load("g2_edges.npz")
+    st = states(z, "s")
+    for dual in (False, True):
+        mcts, tot = run_production_parity(DEV, "b6c64", sims=40, moves=2, dual=dual, seed=31,
+                                          states={f: np.ascontiguousarray(np.asarray(st[f])) for f in FIELDS})
+        assert tot["evals"] > 0

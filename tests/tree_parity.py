@@ -401,8 +401,8 @@ def replay_part_in_oracle(part, trees, move, c_eps, check_net=None, float_tol=1e
             stats["max_prior_err"] = max(stats["max_prior_err"], float(err))
             assert err <= float_tol, f"move {move} step {s}: in-kernel head -> prior softmax off by {err}"
             assert not pri[s, need][~mask].any(), "prior mass on an illegal action"
-            if check_net is not None:
-                check_net(s, need, tr["trace_leaf"][s, need], heads[s, need], val[s, need])
+            if check_net is not None and has.any():       # (a leaf without a legal move is backed up as -1: its rows are not read)
+                check_net(s, need[has], tr["trace_leaf"][s, need[has]], heads[s, need[has]], val[s, need[has]])
             stats["evals"] += int(need.size)
         for i in need:
             trees[i].complete(pri[s, i], float(val[s, i]), noise[i] if (s == 0 and c_eps is not None) else None,
@@ -430,7 +430,7 @@ def replay_part_in_oracle(part, trees, move, c_eps, check_net=None, float_tol=1e
 
 
 def run_production_parity(device, model_name="b6c64", num_games=128, sims=200, moves=3, dual=False, seed=0, use_graph=True,
-                          noise=True, temperature=1.0, reuse_factor=4.0, rng_seed=777):
+                          noise=True, temperature=1.0, reuse_factor=4.0, rng_seed=777, states=None):
     """bench.py's search (PortableTreeMCTS / DualStreamTreeMCTS with the fused network, hipGraph, subtree reuse, Philox
     noise and sampled moves) over `moves` consecutive moves from a mixed-phase batch, replayed in the oracle."""
     from liuzhou_amd.net import ChessNet, MODEL_CONFIGS
@@ -440,12 +440,13 @@ def run_production_parity(device, model_name="b6c64", num_games=128, sims=200, m
     dev = torch.device(device)
     torch.manual_seed(20260314)
     net = FusedNet(ChessNet(**MODEL_CONFIGS[model_name]).eval().to(dev))
-    z = load("g1_rules.npz")
-    st_all = gstates(z, "s")
-    rng = np.random.default_rng(seed)
-    idx0 = rng.integers(0, st_all["board"].shape[0], num_games)
-    states = {f: np.ascontiguousarray(np.asarray(st_all[f])[idx0]) for f in FIELDS}
-    B = num_games
+    if states is None:
+        z = load("g1_rules.npz")
+        st_all = gstates(z, "s")
+        rng = np.random.default_rng(seed)
+        idx0 = rng.integers(0, st_all["board"].shape[0], num_games)
+        states = {f: np.ascontiguousarray(np.asarray(st_all[f])[idx0]) for f in FIELDS}
+    B = num_games = int(np.asarray(states["board"]).shape[0])
     kw = dict(exploration_weight=1.0, add_dirichlet_noise=noise, dirichlet_alpha=0.3, dirichlet_epsilon=0.25,
               sample_moves=True, use_graph=use_graph, reuse_tree=True, reuse_factor=reuse_factor, trace=True, seed=rng_seed)
     mcts = (DualStreamTreeMCTS if dual else PortableTreeMCTS)(net, B, sims, dev, **kw)
@@ -495,6 +496,9 @@ def run_production_parity(device, model_name="b6c64", num_games=128, sims=200, m
                     (mv, i, "pick is not the inverse-CDF sample of the policy")
         for i in range(B):
             if trees[i].root_terminal():
+                # no move was played: the engine finds no child to keep and starts this game's next search from a fresh
+                # root (a runner would have ended the game here) -- so does the replay
+                trees[i] = O.OracleTree(cur[i], 1.0)
                 continue
             pick = int(chosen[i])
             cur[i] = O.apply_index(cur[i], pick)
