@@ -231,6 +231,8 @@ class MCTSCore:
                 e.expand(is_root=True, values=val, heads=(lp1, lp2, lpm), noise=noise,
                          epsilon=float(self.cfg.dirichlet_epsilon))
             self._expanded = True
+        if int(e.buf["root_terminal"].item()):                   # finished game / no legal move: nothing to search
+            return
         for _ in range(n):
             e.select()
             lp1, lp2, lpm, val = self._evaluate()
@@ -289,8 +291,8 @@ class MCTSCore:
                                                        torch.zeros((1,), dtype=torch.int64, device=self.device)))
         e = self._engine
         e.set_roots(nxt)
-        e.advance(torch.tensor([int(action_index)], dtype=torch.int32, device=self.device), None,
-                  min(int(self.cfg.num_simulations), e.max_sims))
+        # room for a full arena of new simulations is kept free (a subtree too large for that is dropped: fresh root)
+        e.advance(torch.tensor([int(action_index)], dtype=torch.int32, device=self.device), None, e.max_sims)
         self._root, self._root_like = nxt, None
         self._expanded = False
         self._sims_in_tree = 0
