@@ -132,3 +132,32 @@ def test_fp32_operand_kernel_meets_the_reference_tolerance(name):
     b = f32.forward_packed(eng.buf["root_state"])
     for u, v in zip(a[:3], b[:3]):
         assert torch.equal(u, v)
+
+
+def test_refresh_repacks_into_the_same_buffers_and_leaves_the_module_alone():
+    """FusedNet.refresh (checkpoint hand-off of a training iteration): new weights land in the existing device buffers
+    (same pointers: captured graphs and variants stay valid) and give the outputs of a freshly packed net; packing never
+    moves the caller's module or changes its mode."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from liuzhou_amd.net import ChessNet, MODEL_CONFIGS
+    from liuzhou_amd.net_hip import FusedNet
+    torch.manual_seed(1)
+    m = ChessNet(**MODEL_CONFIGS["b6c64"]).to(DEV).train()
+    f = FusedNet(m)
+    assert m.training and next(m.parameters()).is_cuda                     # untouched by packing
+    half = f.variant(half_workgroups=True)
+    ptrs = (f.pack.wfrag.data_ptr(), f.pack.fparams.data_ptr())
+    x = _planes(64, seed=2)
+    before = [t.clone() for t in f(x)]
+    with torch.no_grad():
+        for p in m.parameters():
+            p.add_(torch.randn_like(p) * 0.02)
+    f.refresh(m)
+    assert (f.pack.wfrag.data_ptr(), f.pack.fparams.data_ptr()) == ptrs
+    after = f(x)
+    fresh = FusedNet(m)(x)
+    for a, b, c in zip(after, fresh, before):
+        assert torch.equal(a, b) and not torch.equal(a, c)
+    for a, b in zip(half(x), fresh):                                         # the variant shares the refreshed buffers
+        assert torch.allclose(a, b, atol=1e-6)
