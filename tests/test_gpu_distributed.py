@@ -135,7 +135,7 @@ def test_bench_two_ranks_with_gather_in_the_timed_region():
     assert len(lines) == 1, r.stdout[-2000:]
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 4 and out["scaling"] == "weak"
-    assert abs(out["value"] - 2 * 256 * 4 / (out["ms_per_step"] * 4e-3)) < 1e-6 * out["value"] + 1.0
+    assert abs(out["value"] - 2 * 256 * 4 / (out["ms_per_step"] * 4e-3)) < 2e-3 * out["value"]      # ms_per_step is rounded
     g = out["gather"]
     assert g["rows_on_rank0"] == 2 * 256 * 4 and g["record_bytes"] == 360 and g["bytes_received"] == 256 * 4 * 360
     assert "gathered to rank 0" in out["config"]["workload"]
