@@ -550,6 +550,7 @@ __global__ __launch_bounds__(kBlock) void tree_expand_kernel(Tree t, const float
 
 // expand + backup of simulation s fused with the selection of simulation s+1 (same wave, same game: the edge
 // records it just touched are still in L1/L2) -- one launch per simulation besides the network kernel.
+// (forcing 8 waves / SIMD -- <= 96 SGPRs, 126 scalar spills -- was measured: no gain at 16 384 games, 1 % slower at C2)
 template <bool IS_ROOT>
 __global__ __launch_bounds__(kBlock) void tree_expand_select_kernel(Tree t, const float* __restrict__ lp1,
                                                                     const float* __restrict__ lp2,
