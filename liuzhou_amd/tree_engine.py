@@ -746,7 +746,10 @@ class SteadyStateTreeSelfPlay:
                                            temperature_init=temperature_init, temperature_final=temperature_final,
                                            temperature_threshold=temperature_threshold, max_game_plies=max_game_plies,
                                            fused_search=False, arena_rows=arena_rows)
-        self.dual_stream = bool(dual_stream and self.net.pack.channels == 64 and int(num_games) >= 2)
+        # two streams pay for 64 channels (two 4-wave workgroups share a CU); the 128-channel kernel fills a CU's registers
+        # with one workgroup, so its launches cannot overlap -- LZ_DUAL_128=1 tries it anyway (experiment)
+        allow = self.net.pack.channels == 64 or os.environ.get("LZ_DUAL_128", "0") == "1"
+        self.dual_stream = bool(dual_stream and allow and int(num_games) >= 2)
         if self.dual_stream:
             self.mcts = DualStreamTreeMCTS(self.net, num_games, sims, dev, exploration_weight=exploration_weight,
                                            reuse_tree=reuse_tree, reuse_factor=reuse_factor, batch_k=batch_k, seed=seed)
