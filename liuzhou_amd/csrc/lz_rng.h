@@ -14,7 +14,7 @@
 #include <stdint.h>
 #include <math.h>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define LZ_RNG_HD __host__ __device__ __forceinline__
 #else
 #define LZ_RNG_HD inline

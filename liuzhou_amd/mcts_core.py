@@ -181,6 +181,8 @@ class MCTSCore:
     set_eval_batcher = set_torchscript_runner
 
     # ---- tree ----
+    NODE_LIMIT = 16384          # tree_advance_kernel: LDS mark words / 16-bit owner ids (csrc/lz_engine.hip)
+
     def _capacity(self) -> int:
         return max(1024, 4 * int(self.cfg.num_simulations))
 
@@ -188,13 +190,22 @@ class MCTSCore:
         self._root = state if isinstance(state, GpuStateBatch) else state_like_to_batch(state, self.device)
         self._root_like = state
         cap = self._capacity()
+        if cap + 2 > self.NODE_LIMIT:
+            # the reference's tree is unbounded; ours is an arena of at most 16 384 nodes per game
+            raise ValueError(f"MCTSCore: num_simulations={self.cfg.num_simulations} needs an arena of {cap} nodes, above the "
+                             f"{self.NODE_LIMIT}-node limit of a device tree (use num_simulations <= {(self.NODE_LIMIT - 2) // 4})")
         if self._engine is None or self._engine.max_sims < cap:
-            self._engine = TreeEngine(1, cap, self.device, float(self.cfg.exploration_weight),
-                                      reuse_factor=min(3.0, (16384 - cap - 2) / cap))
+            # room for kept subtrees: up to 3 arenas' worth, never more than the node limit allows, never negative
+            # (a negative factor would mean "size from free memory" to TreeEngine)
+            factor = max(0.0, min(3.0, (self.NODE_LIMIT - cap - 2) / cap))
+            self._engine = TreeEngine(1, cap, self.device, float(self.cfg.exploration_weight), reuse_factor=factor)
         self._engine.set_roots(self._root)
         self._engine.begin()
         self._expanded, self._sims_in_tree = False, 0
-        self._rng.ply.zero_()
+        # Noise key: the reference's generator is stateful (mcts_core.cpp:132,316), so every root expansion -- each
+        # set_root_state, each advance_root -- draws fresh noise.  The key here is (seed, game 0, expansion counter): the
+        # counter only ever grows, so two roots never share their Gamma draws.
+        self._rng.ply.add_(1)
 
     def reset(self) -> None:
         self._root = self._root_like = None

@@ -643,6 +643,10 @@ class DualStreamTreeMCTS:
         self.parts = []
         base = model if isinstance(model, FusedNet) else FusedNet(model, dev)
         kw.pop("game_offset", None); kw.pop("game_stride", None)
+        # one arena factor for the whole batch: sized per part, the first part would take its share of the free memory
+        # and the next one a share of what is left -- unequal arenas, unequal subtree-drop rates
+        if kw.get("reuse_tree", False) and float(kw.get("reuse_factor", -1.0)) < 0:
+            kw["reuse_factor"] = auto_reuse_factor(self.B, int(num_simulations), dev)
         for (a, _b), n in zip(self.bounds, sizes):
             # waves of batch_k leaves are large launches: full 8-wave workgroups (they fill the chip on their own)
             half = int(kw.get("batch_k", 1)) <= 1

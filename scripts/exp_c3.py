@@ -1,7 +1,8 @@
 """Experiments on the 10x128 network kernel at the C3 launch shape (16 384 evaluations per launch):
   * evaluations/s against the number of persistent workgroups (= CUs used): under the package power limit fewer CUs
     may cost less than their share (the clock rises), which decides whether CUs can be set aside for the tree kernel;
-  * the same with every trunk layer reading one block's weights (LZ_EXP_SAME_LAYER=1, wrong results): the weight set
+  * the same with every trunk layer reading one block's weights (a library built with -DLZ_EXP_SAME_LAYER, wrong
+    results, never the shipped build -- `LZ_EXP_SAME_LAYER=1` in the environment only labels the run): the weight set
     then fits the 4 MB XCD L2, which bounds what the L2 misses on the real 5.9 MB set cost."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -42,11 +43,10 @@ if mode == "wide":          # 8-wave shape (2 channel tiles per wave) vs 4-wave 
             print(f"{name} N={N} wide_tiles={wide}: {r / 1e6:.3f} M evals/s, {us:.1f} us/launch, "
                   f"{r * f.flops_per_eval / 1e12:.0f} TFLOP/s", flush=True)
     sys.exit(0)
-for same in ("0", "1"):
-    os.environ["LZ_EXP_SAME_LAYER"] = same
+same = os.environ.get("LZ_EXP_SAME_LAYER", "0")      # label only: the behaviour is a compile-time flag of the library
+for _ in (0,):
     for blocks in (256, 248, 240, 224, 192, 128):
         f = FusedNet(model, max_blocks=blocks)
         r, us = rate(f)
         print(f"{name} N={N} same_layer={same} workgroups={blocks}: {r / 1e6:.3f} M evals/s, {us:.1f} us/launch, "
               f"{r * f.flops_per_eval / 1e12:.0f} TFLOP/s", flush=True)
-os.environ["LZ_EXP_SAME_LAYER"] = "0"

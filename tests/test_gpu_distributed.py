@@ -114,7 +114,7 @@ def test_unrepresentable_row_makes_every_rank_raise():
 
 
 def test_bench_two_ranks_with_gather_in_the_timed_region():
-    """`bench.py --gpus 2 --include-gather` (C4's code path: games sharded over the ranks, barrier + max-over-ranks timing,
+    """`bench.py --gpus 2` -- with more than one rank the gather is part of the measured config by default (C4's code path: games sharded over the ranks, barrier + max-over-ranks timing,
     the compact gather of the timed steps' rows inside the timed region) started as a plain process: it spawns its two
     ranks itself.  Both ranks share cuda:0 here (gloo group; RCCL refuses two ranks per device), small workload."""
     import json
@@ -128,7 +128,7 @@ def test_bench_two_ranks_with_gather_in_the_timed_region():
         env.pop(k, None)
     env.update(LZ_BENCH_BACKEND="gloo", LZ_BENCH_SHARE_GPU="1", LZ_BENCH_PORT=str(_free_port()))
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
-                        "--games", "256", "--sims", "16", "--model", "b6c64", "--soak-seconds", "0", "--include-gather",
+                        "--games", "256", "--sims", "16", "--model", "b6c64", "--soak-seconds", "0",
                         "--reuse-factor", "2", "--no-probe"], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -138,4 +138,4 @@ def test_bench_two_ranks_with_gather_in_the_timed_region():
     assert abs(out["value"] - 2 * 256 * 4 / (out["ms_per_step"] * 4e-3)) < 2e-3 * out["value"]      # ms_per_step is rounded
     g = out["gather"]
     assert g["rows_on_rank0"] == 2 * 256 * 4 and g["record_bytes"] == 360 and g["bytes_received"] == 256 * 4 * 360
-    assert "gathered to rank 0" in out["config"]["workload"]
+    assert "gathered to rank 0" in out["config"]["workload"] and out["config"]["workload"].startswith("C4")
