@@ -465,6 +465,24 @@ LZ_API int lz_tree_search_continue(const LzTreeDesc* tree, const LzNetDesc* net,
                                    float* log_p1, float* log_p2, float* log_pmc, float* values, const float* noise,
                                    int64_t noise_stride, float epsilon, void* stream);
 
+/* The same search (fresh: continue_trees = 0, or on the trees prepared by lz_tree_advance: 1) as ONE kernel launch in
+ * which a workgroup owns 8 games for the whole move: per simulation one network pass on its 8 pending leaves, then the
+ * expand / backup / select step of those games, with only a workgroup barrier in between -- no kernel boundary and no
+ * device-wide barrier per simulation (replaces the host loop of v1/cpp/portable_mcts.cpp:483-590,832-939 /
+ * v1/python/portable_cpp_mcts.py:270-282 like lz_tree_search does; identical results: the same device code runs the
+ * network pass and the tree steps).  Two such workgroups share a CU, so one's tree step overlaps the other's network
+ * pass.  64-channel networks in fp16 mode only: anything else returns LZ_ERR_UNSUPPORTED and the caller uses
+ * lz_tree_search.
+ *   cu_slots:    int32[4096] scratch (zeroed by the call) or NULL; with stagger_us > 0 the second workgroup to arrive
+ *                on a CU starts stagger_us microseconds late, so that the pair alternates its phases;
+ *   phase_ticks: optional int64[grid][2] = 100 MHz ticks each workgroup spent in network passes / tree steps
+ *                (grid = lz_tree_search_persistent_grid(num_games)); NULL in production. */
+LZ_API int lz_tree_search_persistent(const LzTreeDesc* tree, const LzNetDesc* net, int64_t sims, float* log_p1,
+                                     float* log_p2, float* log_pmc, float* values, const float* noise,
+                                     int64_t noise_stride, float epsilon, int continue_trees, int32_t* cu_slots,
+                                     int64_t stagger_us, int64_t* phase_ticks, void* stream);
+LZ_API int lz_tree_search_persistent_grid(int64_t num_games);
+
 /* ---- training loss (the step right after the path) --------------------- */
 
 /* Fused forward + backward of the reference's training loss (v1/python/train_bridge.py:330-375):

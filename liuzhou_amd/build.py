@@ -8,8 +8,8 @@ import subprocess
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libliuzhou_hip.so")
-SOURCES = ("lz_ops.hip", "lz_engine.hip", "lz_net.hip", "lz_net_f32.hip", "lz_train.hip")
-HEADERS = ("lz_rules.h", "lz_soa.h", "lz_wave.h", "lz_rng.h", "lz_net_dev.h", os.path.join("..", "..", "include", "liuzhou_hip.h"))
+SOURCES = ("lz_ops.hip", "lz_engine.hip", "lz_net.hip", "lz_net_f32.hip", "lz_train.hip", "lz_search.hip")
+HEADERS = ("lz_rules.h", "lz_soa.h", "lz_wave.h", "lz_rng.h", "lz_net_dev.h", "lz_tree_dev.h", os.path.join("..", "..", "include", "liuzhou_hip.h"))
 
 
 def hipcc_path() -> str:

@@ -21,93 +21,9 @@
 #include <stdint.h>
 
 #include "lz_rng.h"
-#include "lz_soa.h"
-#include "lz_wave.h"
-
-using namespace lz;
+#include "lz_tree_dev.h"
 
 namespace {
-
-constexpr int kWave = 64;
-constexpr int kBlock = 256;
-constexpr int kWavesPerBlock = 4;
-constexpr int kMaxChildren = 72;
-
-// kLeafReusedRoot: the root survived an advance (a21) -- no evaluation needed, only the fresh noise mix
-enum LeafKind : int { kLeafInactive = 0, kLeafExpand = 1, kLeafTerminal = 2, kLeafReusedRoot = 3 };
-// edge info bits
-constexpr uint8_t kInfoWhite = 1;       // child mover is white
-constexpr uint8_t kInfoTerminal = 2;    // child is terminal (game over, or found to have no legal move)
-// bits 2..3: terminal value + 1  (0 => -1, 1 => 0, 2 => +1), from the child's mover's perspective
-
-// 32-byte edge record: one load brings everything the descent needs for a child, including where the child's
-// own edges live -- select never touches node records until it has found the leaf's parent.
-struct Edge {
-    double W;            // value sum, child mover's perspective
-    float P;             // prior
-    uint32_t n_info;     // visit count (low 24 bits) | info (high 8 bits)
-    int32_t child;       // node index or -1
-    int32_t cbegin;      // child's first edge (valid when child >= 0)
-    uint8_t act;         // 220-d action index
-    uint8_t cn;          // child's edge count (valid when child >= 0)
-    uint16_t owner;      // node that owns this edge run (subtree compaction, lz_tree_advance)
-    uint8_t pad[4];
-};
-static_assert(sizeof(Edge) == 32, "edge record is 32 bytes");
-// 48-byte node record
-struct Node {
-    Packed state;
-    int32_t edge_begin, nedges;      // nedges = -1: not expanded
-    int32_t parent;                  // parent node (-1 for the root)
-    int32_t pad;
-};
-static_assert(sizeof(Node) == 48, "node record is 48 bytes");
-__device__ __forceinline__ int edge_n(uint32_t ni) { return (int)(ni & 0xFFFFFFu); }
-__device__ __forceinline__ uint8_t edge_info(uint32_t ni) { return (uint8_t)(ni >> 24); }
-
-struct Tree {
-    int B, node_cap, edge_cap, path_cap;
-    const Packed* root_state;
-    Node* nodes; Edge* edges;
-    int* n_nodes; int* n_edges; int* root_visits; double* root_W; float* root_init_value;
-    int* path; int* path_len; int* leaf_kind; Packed* leaf_state; float* leaf_value;
-    uint8_t* root_terminal; const uint8_t* active;
-    int* leaf_edge; int* leaf_parent;      // edge / node the pending leaf hangs from (written by select)
-    double c_puct;
-    // optional trace of what every expand step consumed (LzTreeDesc.trace_*; nullptr in production)
-    int* trace_kind; Packed* trace_leaf; float* trace_heads; float* trace_priors; float* trace_value;
-    int trace_cap;
-};
-
-// Edge / node records are read with plain (L1 + L2 cached, normal retention) 16-byte loads.  This is safe next to the
-// device-scope atomics of the backup because a launch never loads an edge line before its own atomics on it have
-// completed: expand touches no edge record with a load, and a workgroup fence (= wait for the atomics' and stores'
-// L2 acknowledgement) separates it from the selection that follows.  Streaming (`nt`) loads measured 10 % slower:
-// they evict the upper tree levels from L2, which every simulation re-reads.
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ Edge load_edge(const Edge* p) {
-    const u32x4* q = reinterpret_cast<const u32x4*>(p);
-    union U { u32x4 v[2]; Edge e; __device__ U() {} } u;
-    u.v[0] = q[0]; u.v[1] = q[1];
-    return u.e;
-}
-__device__ __forceinline__ Packed load_state(const Packed* p) {
-    const u32x4* q = reinterpret_cast<const u32x4*>(p);
-    union U { u32x4 v[2]; Packed s; __device__ U() {} } u;
-    u.v[0] = q[0]; u.v[1] = q[1];
-    return u.s;
-}
-constexpr uint32_t kPathFlip = 0x80000000u;    // path entry: edge index | flip bit (mover changes parent -> child)
-
-__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
-__device__ __forceinline__ int wave_game() {
-    return blockIdx.x * kWavesPerBlock + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-}
-__device__ __forceinline__ double terminal_value_for_mover(const State& s) {   // portable_mcts.py:141-147
-    const int st = game_status(s);
-    if (st == 1 || st == -1) return st == s.player ? 1.0 : -1.0;
-    return 0.0;
-}
 
 // ---- SoA <-> packed -------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void pack_states_kernel(LzStateSoA s, int64_t B, Packed* __restrict__ out) {
@@ -148,134 +64,12 @@ __global__ __launch_bounds__(kBlock) void packed_planes_kernel(const Packed* __r
     }
 }
 
-// ---- begin a search: fresh tree per game -----------------------------------------------------------------
-__device__ __forceinline__ void begin_game(const Tree& t, int g) {
-    const Packed rs = t.root_state[g];
-    Node& root = t.nodes[(size_t)g * t.node_cap];
-    root.state = rs;
-    root.edge_begin = 0;
-    root.nedges = -1;                                      // unexpanded
-    root.parent = -1;
-    t.n_nodes[g] = 1;
-    t.n_edges[g] = 0;
-    t.root_visits[g] = 0;
-    t.root_W[g] = 0.0;
-    t.root_init_value[g] = 0.f;
-    t.path_len[g] = 0;
-    const State s = unpack(rs);
-    const bool act = t.active == nullptr || t.active[g] != 0;
-    const bool term = game_status(s) != 0;                // portable_mcts.py:601-603
-    t.root_terminal[g] = (term || !act) ? 1 : 0;
-    t.leaf_kind[g] = (term || !act) ? kLeafInactive : kLeafExpand;
-    t.leaf_state[g] = rs;                                  // the root is the first pending evaluation
-    t.leaf_value[g] = 0.f;
-}
 __global__ __launch_bounds__(kBlock) void tree_begin_kernel(Tree t) {
     const int g = blockIdx.x * kBlock + threadIdx.x;
     if (g >= t.B) return;
     begin_game(t, g);
 }
 
-// ---- select: one wave per game ---------------------------------------------------------------------------
-// Per level the only dependent load is the current node's edge run (32 B per lane, coalesced); the reduction is
-// DPP-based and the chosen edge is broadcast with v_readlane.  The chosen child's state record is fetched
-// speculatively next to the next level's edge run, so reaching the leaf costs no extra round trip.
-struct RootInfo { int ne, e0, visits, player; Packed state; };
-__device__ __forceinline__ RootInfo load_root_info(const Tree& t, int g) {
-    RootInfo r;
-    const Node* root = t.nodes + (size_t)g * t.node_cap;
-    r.state = load_state(&root->state);
-    r.ne = root->nedges; r.e0 = root->edge_begin;
-    r.visits = t.root_visits[g];
-    r.player = ((r.state.w0 >> 53) & 1) ? -1 : 1;
-    return r;
-}
-
-__device__ __forceinline__ void tree_select(const Tree& t, int g, int lane, const RootInfo& root) {
-    if (t.root_terminal[g]) { if (lane == 0) t.leaf_kind[g] = kLeafInactive; return; }
-    const Node* nodes = t.nodes + (size_t)g * t.node_cap;
-    const Edge* edges = t.edges + (size_t)g * t.edge_cap;
-    int* path = t.path + (size_t)g * t.path_cap;
-    int node = 0, depth = 0;
-    int parent_n = root.visits;
-    int node_player = root.player;
-    int ne = root.ne, e0 = root.e0;
-    Packed node_state = root.state;
-    int kind = kLeafInactive;
-    float term_value = 0.f;
-    int leaf_action = 0, leaf_edge = -1;
-    while (ne > 0) {
-        const double sq = sqrt((double)(parent_n > 1 ? parent_n : 1));
-        double best = -INFINITY;
-        int best_k = -1;
-        Edge mine[2];
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {                          // up to 2 children per lane, ascending edge index
-            const int k = r * kWave + lane;
-            if (k < ne) {
-                mine[r] = load_edge(&edges[e0 + k]);
-                const int n = edge_n(mine[r].n_info);
-                double q = 0.0;
-                if (n > 0) {
-                    const double mv = mine[r].W / (double)n;
-                    const int child_player = (edge_info(mine[r].n_info) & kInfoWhite) ? -1 : 1;
-                    q = child_player == node_player ? mv : -mv;
-                }
-                const double u = t.c_puct * (double)mine[r].P * sq / (1.0 + (double)n);
-                const double sc = q + u;
-                if (sc > best) { best = sc; best_k = k; }
-            }
-        }
-        const double mx = lzw::wave_max(best);
-        const uint64_t lo = __ballot(best_k >= 0 && best_k < kWave && best == mx);   // lowest index among the maxima
-        int chosen;
-        if (lo) chosen = __ffsll((unsigned long long)lo) - 1;
-        else {
-            const uint64_t hi = __ballot(best_k >= kWave && best == mx);
-            if (!hi) break;                                    // every score NaN (portable: best_child is None)
-            chosen = kWave + __ffsll((unsigned long long)hi) - 1;
-        }
-        chosen = __builtin_amdgcn_readfirstlane(chosen);
-        const int src = chosen & 63;
-        const bool up = chosen >= kWave;
-        const uint32_t c_ni = (uint32_t)lzw::lane_bcast((int)(up ? mine[1].n_info : mine[0].n_info), src);
-        const int c_child = lzw::lane_bcast(up ? mine[1].child : mine[0].child, src);
-        const int c_begin = lzw::lane_bcast(up ? mine[1].cbegin : mine[0].cbegin, src);
-        const int c_meta = lzw::lane_bcast((int)(up ? mine[1].act : mine[0].act) | ((int)(up ? mine[1].cn : mine[0].cn) << 8), src);
-        const uint8_t info = edge_info(c_ni);
-        const int child_player = (info & kInfoWhite) ? -1 : 1;
-        leaf_edge = e0 + chosen;
-        if (lane == 0) path[depth] = leaf_edge | (child_player != node_player ? (int)kPathFlip : 0);
-        ++depth;
-        if (info & kInfoTerminal) {
-            kind = kLeafTerminal;
-            term_value = (float)((int)((info >> 2) & 3) - 1);
-            break;
-        }
-        if (c_child < 0) { kind = kLeafExpand; leaf_action = c_meta & 0xFF; break; }
-        node_state = load_state(&nodes[c_child].state);     // in flight together with the next level's edges
-        parent_n = edge_n(c_ni);
-        node_player = child_player;
-        node = c_child;
-        e0 = c_begin;
-        ne = c_meta >> 8;
-        if (depth >= t.path_cap - 1) break;
-    }
-    if (lane == 0) {
-        t.path_len[g] = depth;
-        t.leaf_kind[g] = kind;
-        t.leaf_value[g] = term_value;
-        t.leaf_edge[g] = leaf_edge;
-        t.leaf_parent[g] = node;
-        if (kind == kLeafExpand) {
-            State leaf = unpack(node_state);
-            int kd, p, q2, ex;
-            index_to_code(leaf.phase, leaf_action, kd, p, q2, ex);
-            apply(leaf, kd, p, q2);
-            t.leaf_state[g] = pack(leaf);
-        }
-    }
-}
 
 __global__ __launch_bounds__(kBlock) void tree_select_kernel(Tree t) {
     const int g = wave_game();
@@ -283,257 +77,6 @@ __global__ __launch_bounds__(kBlock) void tree_select_kernel(Tree t) {
     tree_select(t, g, lane_id(), load_root_info(t, g));
 }
 
-// ---- expand (+ backup): one wave per game -----------------------------------------------------------------
-// priors come either from the three 36-wide log-prob heads (production) or from a dense 220-d prior row
-// (injected evaluator, parity runs).  IS_ROOT: no backup, optional noise mix.
-// Every load that does not depend on another load is issued up front (leaf record, evaluator outputs, allocation
-// counters, the path, the root's statistics); the backup is fire-and-forget device atomics (N += 1 on the count
-// field, W += v in double -- one addition per edge and simulation, so bit-identical to a read-modify-write), the
-// signs come from the flip bits select left in the path entries.  Dependent round trips: 1 (was 5).
-template <bool IS_ROOT>
-__device__ __forceinline__ void tree_expand(const Tree& t, int g, int lane, const float* __restrict__ lp1,
-                                            const float* __restrict__ lp2, const float* __restrict__ lpm,
-                                            const float* __restrict__ priors220, const float* __restrict__ values,
-                                            const float* __restrict__ noise, int noise_stride, float epsilon,
-                                            RootInfo* root_after = nullptr, int step = -1) {
-    const int kind = t.leaf_kind[g];
-    Node* nodes = t.nodes + (size_t)g * t.node_cap;
-    Edge* edges = t.edges + (size_t)g * t.edge_cap;
-    const int* path = t.path + (size_t)g * t.path_cap;
-    // ---- independent loads, all in flight together ----
-    RootInfo root{};
-    int plen_ld = 0, leaf_edge = -1, leaf_parent = 0, nn_ld = 0, ne_ld = 0, path_entry = 0;
-    double root_w = 0.0;
-    float leaf_value_ld = 0.f, value_ld = 0.f;
-    Packed leaf_packed = t.leaf_state[g];
-    if (!IS_ROOT) {
-        root = load_root_info(t, g);
-        plen_ld = t.path_len[g];
-        leaf_edge = t.leaf_edge[g];
-        leaf_parent = t.leaf_parent[g];
-        path_entry = lane < t.path_cap ? path[lane] : 0;       // first 64 entries
-        root_w = t.root_W[g];
-        leaf_value_ld = t.leaf_value[g];
-    }
-    nn_ld = t.n_nodes[g];
-    ne_ld = t.n_edges[g];
-    value_ld = values[g];
-    if (root_after != nullptr) *root_after = root;
-    // trace slot of this step (parity tests only; wave-uniform)
-    const bool tracing = t.trace_kind != nullptr && step >= 0 && step < t.trace_cap;
-    const size_t tslot = tracing ? (size_t)step * (size_t)t.B + (size_t)g : 0;
-    if (tracing) {
-        if (lane == 0) { t.trace_kind[tslot] = kind; t.trace_leaf[tslot] = leaf_packed; t.trace_value[tslot] = value_ld; }
-        for (int a = lane; a < 220; a += kWave) t.trace_priors[tslot * 220 + a] = 0.f;
-    }
-    if (kind == kLeafInactive) return;
-    if (kind == kLeafReusedRoot) {
-        // portable_mcts.py:302-317 / :617-621: a root kept by advance_root gets a fresh noise mix on its
-        // existing priors, renormalised by max(sum, 1e-8); nothing else happens before the first selection.
-        if (IS_ROOT && noise != nullptr) {
-            const int ne = nodes[0].nedges, e0 = nodes[0].edge_begin;
-            if (ne > 1) {
-                const float keep = (float)(1.0 - (double)epsilon);
-                float pr[2]; bool ok[2];
-#pragma unroll
-                for (int r = 0; r < 2; ++r) {
-                    const int k = r * kWave + lane;
-                    ok[r] = k < ne;
-                    pr[r] = ok[r] ? keep * edges[e0 + k].P + epsilon * noise[(size_t)g * noise_stride + k] : 0.f;
-                }
-                float psum = 0.f;
-#pragma unroll
-                for (int r = 0; r < 2; ++r) {
-                    uint64_t m = __ballot(ok[r]);
-                    while (m) {
-                        const int l = __builtin_amdgcn_readfirstlane(__ffsll((unsigned long long)m) - 1);
-                        psum += lzw::lane_bcast(pr[r], l);
-                        m &= m - 1;
-                    }
-                }
-                const float denom = psum < 1e-8f ? 1e-8f : psum;
-#pragma unroll
-                for (int r = 0; r < 2; ++r)
-                    if (ok[r]) edges[e0 + r * kWave + lane].P = pr[r] / denom;
-            }
-        }
-        return;
-    }
-    const int plen = IS_ROOT ? 0 : plen_ld;
-    double backup_value = 0.0;
-
-    if (kind == kLeafTerminal) {
-        backup_value = (double)leaf_value_ld;
-    } else {
-        const State s = unpack(leaf_packed);
-        const Legal L = legal_actions(s, /*fallback_forced=*/0);     // python semantics (move_generator.py:24-70)
-        const int n = legal_count(L);
-        if (n == 0) {
-            // portable_mcts.py:433-441: no legal move on a non-finished state => terminal, value -1
-            backup_value = -1.0;
-            if (lane == 0) {
-                if (IS_ROOT) { nodes[0].nedges = 0; t.root_terminal[g] = 1; t.root_init_value[g] = -1.f; }
-                else atomicOr(&edges[leaf_edge].n_info, (uint32_t)kInfoTerminal << 24);   // value bits stay 0 (= -1)
-            }
-        } else {
-            // gather per-lane logits / priors of the legal actions in ascending index order
-            float h1 = 0.f, h2 = 0.f, hm = 0.f;
-            const bool heads = priors220 == nullptr;
-            if (heads && lane < kCells) {
-                h1 = lp1[(size_t)g * 36 + lane]; h2 = lp2[(size_t)g * 36 + lane]; hm = lpm[(size_t)g * 36 + lane];
-                if (tracing) {
-                    float* th = t.trace_heads + tslot * 108;
-                    th[lane] = h1; th[36 + lane] = h2; th[72 + lane] = hm;
-                }
-            }
-            // Phase A, per 64 action indices (skipped when none of them is legal): legality, compact slot, logit.
-            // The legal actions are then compacted through LDS so that Phase B (child state, terminal test, edge
-            // record -- the expensive per-action work) runs once over min(n, 64) lanes instead of four times.
-            __shared__ float s_val[kWavesPerBlock][80];
-            __shared__ int s_act[kWavesPerBlock][80];
-            const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-            float val[4]; int slot[4]; bool lg[4];
-            int base = 0;
-            float mx = -INFINITY;
-#pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                const int a = it * kWave + lane;
-                lg[it] = a < 217 && legal_bit(L, a);
-                val[it] = 0.f; slot[it] = 0;
-                const uint64_t bal = __ballot(lg[it]);
-                if (bal == 0) continue;                         // wave-uniform
-                slot[it] = base + __popcll(bal & ((1ull << lane) - 1ull));
-                base += __popcll(bal);
-                int from = 0, dest = 0, cell = 0;
-                if (a >= 36 && a < 180) { from = (a - 36) >> 2; dest = move_dest(from, (a - 36) & 3); dest = dest < 0 ? 0 : (dest > 35 ? 35 : dest); }
-                else if (a >= 180 && a < 216) cell = a - 180;
-                else if (a < 36) cell = a;
-                float x;
-                if (heads) {
-                    const float p1d = __shfl(h1, dest), p2f = __shfl(h2, from), p1c = __shfl(h1, cell), pmc = __shfl(hm, cell);
-                    x = a < 36 ? p1c : a < 180 ? (p2f + p1d) : a < 216 ? pmc : 0.f;
-                } else {
-                    x = lg[it] ? priors220[(size_t)g * 220 + a] : 0.f;
-                }
-                val[it] = x;
-                if (heads && lg[it]) mx = fmaxf(mx, x);
-            }
-            if (heads) {
-                // softmax over the legal set (portable_mcts.py:381-386), fp32
-                mx = lzw::wave_max(mx);
-                float sum = 0.f;
-#pragma unroll
-                for (int it = 0; it < 4; ++it) { val[it] = lg[it] ? expf(val[it] - mx) : 0.f; sum += val[it]; }
-                sum = lzw::wave_sum(sum);
-#pragma unroll
-                for (int it = 0; it < 4; ++it) val[it] = val[it] / sum;
-            }
-            if (tracing) {
-#pragma unroll
-                for (int it = 0; it < 4; ++it)
-                    if (lg[it]) t.trace_priors[tslot * 220 + it * kWave + lane] = val[it];
-            }
-            // root noise mix (portable_mcts.py:451-459)
-            if (IS_ROOT && noise != nullptr && n > 1) {
-                const float keep = (float)(1.0 - (double)epsilon);
-#pragma unroll
-                for (int it = 0; it < 4; ++it)
-                    if (lg[it]) val[it] = keep * val[it] + epsilon * noise[(size_t)g * noise_stride + slot[it]];
-            }
-            // compaction: lane k (and k + 64) takes over the k-th legal action in ascending index order
-#pragma unroll
-            for (int it = 0; it < 4; ++it)
-                if (lg[it]) { s_val[wv][slot[it]] = val[it]; s_act[wv][slot[it]] = it * kWave + lane; }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            float cval[2]; int cact[2];
-#pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                const int k = r * kWave + lane;
-                cval[r] = k < n ? s_val[wv][k] : 0.f;
-                cact[r] = k < n ? s_act[wv][k] : 0;
-            }
-            // renormalise with a sequential fp32 sum in ascending action order (== the oracle's order): scalar loop
-            // of v_readlane + add, no further LDS round trip
-            float psum = 0.f;
-            for (int k = 0; k < n; ++k) psum += lzw::lane_bcast(k < kWave ? cval[0] : cval[1], k & 63);
-            const bool bad = !(psum > 0.f) || !isfinite(psum);
-            // node + edge allocation (per-game bump counters, worst-case sized regions)
-            int node_id = 0, e0 = 0;
-            if (lane == 0) {
-                if (IS_ROOT) { node_id = 0; e0 = ne_ld; t.n_edges[g] = e0 + n; }
-                else {
-                    node_id = nn_ld; t.n_nodes[g] = node_id + 1;
-                    e0 = ne_ld; t.n_edges[g] = e0 + n;
-                    Edge& in = edges[leaf_edge];
-                    in.child = node_id; in.cbegin = e0; in.cn = (uint8_t)n;
-                    nodes[node_id].state = leaf_packed;
-                    nodes[node_id].parent = leaf_parent;
-                }
-                nodes[node_id].edge_begin = e0;
-                nodes[node_id].nedges = n;
-                if (IS_ROOT) t.root_init_value[g] = value_ld;
-            }
-            e0 = __builtin_amdgcn_readfirstlane(e0);
-            node_id = __builtin_amdgcn_readfirstlane(node_id);
-            // Phase B: one pass (two only when a movement position has more than 64 legal moves)
-            for (int r = 0; r < (n > kWave ? 2 : 1); ++r) {
-                const int k = r * kWave + lane;
-                if (k >= n) continue;
-                const int a = r == 0 ? cact[0] : cact[1];
-                State c = s;
-                int kd, p, q2, ex;
-                index_to_code(s.phase, a, kd, p, q2, ex);
-                apply(c, kd, p, q2);
-                uint8_t info = c.player < 0 ? kInfoWhite : 0;
-                if (game_status(c) != 0) {
-                    const int tv = (int)terminal_value_for_mover(c);
-                    info |= kInfoTerminal | (uint8_t)((tv + 1) << 2);
-                }
-                Edge rec;
-                rec.W = 0.0;
-                rec.P = bad ? (1.0f / (float)n) : ((r == 0 ? cval[0] : cval[1]) / psum);
-                rec.n_info = (uint32_t)info << 24;
-                rec.child = -1;
-                rec.cbegin = 0;
-                rec.act = (uint8_t)a;
-                rec.cn = 0;
-                rec.owner = (uint16_t)node_id;
-                rec.pad[0] = rec.pad[1] = rec.pad[2] = rec.pad[3] = 0;
-                edges[e0 + k] = rec;
-            }
-            backup_value = (double)value_ld;
-        }
-    }
-    if (IS_ROOT) return;
-    // ---- backup along the path (portable_mcts.py:123-138), one lane per path entry ----
-    // value added at offset j = v0 * (-1)^(#mover changes at offsets > j); the root gets the fully flipped value.
-    if (plen > 0) {
-        int flips_above = 0;                                    // mover changes at offsets above the current chunk
-        for (int hi = plen; hi > 0; hi -= kWave) {
-            const int lo = hi > kWave ? hi - kWave : 0;
-            const int j = lo + lane;
-            const bool in = j < hi;
-            const uint32_t pe = !in ? 0u : (lo == 0 ? (uint32_t)path_entry : (uint32_t)path[j]);
-            const uint64_t F = __ballot(in && (pe & kPathFlip) != 0u);
-            const int above = in ? __popcll(F >> (lane + 1)) : 0;   // flips at offsets > j inside the chunk
-            if (in) {
-                Edge* e = &edges[pe & ~kPathFlip];
-                const double v = ((above + flips_above) & 1) ? -backup_value : backup_value;
-                atomicAdd(&e->n_info, 1u);
-                unsafeAtomicAdd(&e->W, v);
-            }
-            flips_above += __popcll(F);
-        }
-        root.visits += 1;
-        if (lane == 0) {
-            t.root_visits[g] = root.visits;
-            t.root_W[g] = root_w + ((flips_above & 1) ? -backup_value : backup_value);
-        }
-        if (root_after != nullptr) root_after->visits = root.visits;
-    }
-}
 
 template <bool IS_ROOT>
 __global__ __launch_bounds__(kBlock) void tree_expand_kernel(Tree t, const float* __restrict__ lp1,
@@ -543,9 +86,10 @@ __global__ __launch_bounds__(kBlock) void tree_expand_kernel(Tree t, const float
                                                              const float* __restrict__ values,
                                                              const float* __restrict__ noise, int noise_stride,
                                                              float epsilon, int step) {
+    LZ_EXPAND_SCRATCH(sc);
     const int g = wave_game();
     if (g >= t.B) return;
-    tree_expand<IS_ROOT>(t, g, lane_id(), lp1, lp2, lpm, priors220, values, noise, noise_stride, epsilon, nullptr, step);
+    tree_expand<IS_ROOT>(t, g, lane_id(), lp1, lp2, lpm, priors220, values, noise, noise_stride, epsilon, sc, nullptr, step);
 }
 
 // expand + backup of simulation s fused with the selection of simulation s+1 (same wave, same game: the edge
@@ -564,11 +108,12 @@ __global__ __launch_bounds__(kBlock) void tree_expand_select_kernel(Tree t, cons
     // lets the short bursts between two loads go first.
     __builtin_amdgcn_s_setprio(3);
 #endif
+    LZ_EXPAND_SCRATCH(sc);
     const int g = wave_game();
     if (g >= t.B) return;
     const int lane = lane_id();
     RootInfo root;
-    tree_expand<IS_ROOT>(t, g, lane, lp1, lp2, lpm, nullptr, values, noise, noise_stride, epsilon, &root, step);
+    tree_expand<IS_ROOT>(t, g, lane, lp1, lp2, lpm, nullptr, values, noise, noise_stride, epsilon, sc, &root, step);
     __threadfence_block();
     if (IS_ROOT) root = load_root_info(t, g);                  // the root record itself was just written
     tree_select(t, g, lane, root);
@@ -777,6 +322,7 @@ __global__ __launch_bounds__(kBlock) void tree_expand_wave_kernel(Tree t, WaveAr
                                                                   const float* __restrict__ lpm,
                                                                   const float* __restrict__ priors220,
                                                                   const float* __restrict__ values, int slot_major) {
+    LZ_EXPAND_SCRATCH(sc);
     const int g = wave_game();
     if (g >= t.B) return;
     const int lane = lane_id();
@@ -805,7 +351,7 @@ __global__ __launch_bounds__(kBlock) void tree_expand_wave_kernel(Tree t, WaveAr
                                                      : (ptrdiff_t)(w.leaf_kind[slot] == kLeafExpand ? w.eval_row[slot] : 0) - g;
             tree_expand<false>(slot_view(t, w, j), g, lane, lp1 ? lp1 + o * 36 : nullptr, lp2 ? lp2 + o * 36 : nullptr,
                                lpm ? lpm + o * 36 : nullptr, priors220 ? priors220 + o * 220 : nullptr, values + o,
-                               nullptr, 0, 0.f);
+                               nullptr, 0, 0.f, sc);
             __threadfence_block();       // the next leaf's loads / atomics come after this leaf's stores / atomics
         }
     }
@@ -1281,37 +827,6 @@ __global__ __launch_bounds__(kBlock) void rng_uniform_kernel(uint64_t seed, cons
     out[g] = lzrng::uniform_draw(seed, game ? game[g] : g, ply ? ply[g] : 0, (uint32_t)purpose);
 }
 
-inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
-inline int st() { return hipGetLastError() == hipSuccess ? LZ_OK : LZ_ERR_LAUNCH; }
-
-Tree make_tree(const LzTreeDesc* d) {
-    Tree t;
-    t.B = (int)d->num_games; t.node_cap = d->node_cap; t.edge_cap = d->edge_cap; t.path_cap = d->path_cap;
-    t.root_state = reinterpret_cast<const Packed*>(d->root_state);
-    t.nodes = reinterpret_cast<Node*>(d->nodes);
-    t.edges = reinterpret_cast<Edge*>(d->edges);
-    t.n_nodes = d->n_nodes; t.n_edges = d->n_edges; t.root_visits = d->root_visits; t.root_W = d->root_w;
-    t.root_init_value = d->root_init_value;
-    t.path = d->path; t.path_len = d->path_len; t.leaf_kind = d->leaf_kind;
-    t.leaf_state = reinterpret_cast<Packed*>(d->leaf_state); t.leaf_value = d->leaf_value;
-    t.root_terminal = d->root_terminal; t.active = d->active;
-    t.leaf_edge = d->leaf_edge; t.leaf_parent = d->leaf_parent;
-    t.c_puct = d->exploration_weight;
-    const bool tr = d->trace_cap > 0 && d->trace_kind && d->trace_leaf && d->trace_heads && d->trace_priors && d->trace_value;
-    t.trace_kind = tr ? d->trace_kind : nullptr;
-    t.trace_leaf = tr ? reinterpret_cast<Packed*>(d->trace_leaf) : nullptr;
-    t.trace_heads = tr ? d->trace_heads : nullptr;
-    t.trace_priors = tr ? d->trace_priors : nullptr;
-    t.trace_value = tr ? d->trace_value : nullptr;
-    t.trace_cap = tr ? (int)d->trace_cap : 0;
-    return t;
-}
-bool tree_ok(const LzTreeDesc* d) {
-    return d && d->num_games >= 0 && d->node_cap >= 2 && d->edge_cap >= kMaxChildren && d->path_cap >= 3 &&
-           d->root_state && d->nodes && d->edges && d->n_nodes && d->n_edges &&
-           d->root_visits && d->root_w && d->root_init_value && d->path && d->path_len && d->leaf_kind &&
-           d->leaf_state && d->leaf_value && d->root_terminal && d->leaf_edge && d->leaf_parent;
-}
 WaveArrays make_wave(const LzTreeWaveDesc* w) {
     WaveArrays a;
     a.K = w->batch_k; a.cap = w->path_cap;

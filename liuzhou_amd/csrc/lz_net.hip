@@ -142,6 +142,19 @@ int lz_prof_net_busy(double* busy_ms) {
     return LZ_OK;
 }
 
+/* internal (not exported): bracket any other kernel of the path like a network launch -- the persistent search kernel
+ * of lz_search.hip, whose `evals` network evaluations happen inside one launch */
+int lz_prof_mark_begin(void* stream) {
+    if (!(g_prof.on && g_prof.used < NetProf::kMax)) return LZ_OK;
+    return hipEventRecord(g_prof.ev[2 * g_prof.used], reinterpret_cast<hipStream_t>(stream)) == hipSuccess ? LZ_OK : LZ_ERR_LAUNCH;
+}
+int lz_prof_mark_end(void* stream, int64_t evals) {
+    if (!(g_prof.on && g_prof.used < NetProf::kMax)) return LZ_OK;
+    (void)hipEventRecord(g_prof.ev[2 * g_prof.used + 1], reinterpret_cast<hipStream_t>(stream));
+    g_prof.used += 1; g_prof.evals += evals;
+    return LZ_OK;
+}
+
 int lz_net_configure(void) {
     const int a = configure_net<64, 16, 8>(), b = configure_net<128, 8, 8>(), c = configure_net<64, 8, 4>(),
               e = configure_net<128, 8, 4>();
@@ -165,24 +178,14 @@ static int net_forward_impl(const LzNetDesc* d, const float* planes, const uint6
     if ((reinterpret_cast<uintptr_t>(d->wfrag) & 15) || (reinterpret_cast<uintptr_t>(d->fparams) & 15)) return LZ_ERR_ALIGN;
     if (d->flags & 4)
         return lz_net_forward_f32_dispatch(d, planes, packed, N, lp1, lp2, lpmc, value_logits, value, n_dev, stream);
-    NetParams P;
-    P.wfrag = reinterpret_cast<const _Float16*>(d->wfrag);
-    P.fp = d->fparams;
-    for (int i = 0; i < d->num_layers; ++i) P.layer_off[i] = d->layer_offsets[i];
-    P.blocks = d->blocks;
-    // timing experiment only (results are wrong): every trunk conv reads the first block's weights, so the weight set
-    // fits the 4 MB XCD L2 -- bounds what L2 misses on the 5.9 MB weight set of 10x128 cost (scripts/exp_c3.py)
-#ifdef LZ_EXP_SAME_LAYER    /* compile-time only, like the other LZ_EXP_* experiments: never in the shipped library */
+    NetParams P = make_net_params(d);
+#ifdef LZ_EXP_SAME_LAYER    /* compile-time only, like the other LZ_EXP_* experiments: never in the shipped library.  Timing
+                             * experiment (results are wrong): every trunk conv reads the first block's weights, so the weight
+                             * set fits the 4 MB XCD L2 -- bounds what L2 misses on the 5.9 MB set of 10x128 cost */
     for (int i = 3; i < 1 + 2 * d->blocks; ++i) P.layer_off[i] = d->layer_offsets[1 + ((i - 1) & 1)];
 #endif
     P.n_dev = reinterpret_cast<const long long*>(n_dev);
-    P.wfrag_bytes = (int)d->wfrag_bytes; P.fparams_bytes = (int)d->fparams_bytes;
     P.debug_stop = getenv("LZ_NET_DEBUG_STOP") ? atoi(getenv("LZ_NET_DEBUG_STOP")) : 0;
-    P.hf_gw = d->head_frag_offsets[0]; P.hf_w1 = d->head_frag_offsets[1]; P.hf_w2 = d->head_frag_offsets[2];
-    P.hf_out = d->head_frag_offsets[3];
-    P.stem_bias = d->off_stem_bias; P.blk0 = d->off_block0; P.trunk_a = d->off_trunk_a; P.trunk_b = d->off_trunk_b;
-    P.head_bias = d->off_head_bias; P.p_gwT = d->off_p_gwT; P.p_a2 = d->off_p_a2; P.p_b2 = d->off_p_b2;
-    P.p_out = d->off_p_out; P.v_w1T = d->off_v_w1T; P.v_b1 = d->off_v_b1; P.v_w2T = d->off_v_w2T; P.v_b2 = d->off_v_b2;
     // flags bit 0 (64 channels): 4-wave workgroups of 8 samples, two per CU -- twice as many workgroups per batch, so
     // that a half-size batch still covers every CU when two of them are evaluated concurrently on two streams
     const bool half_wg = d->channels == 64 && (d->flags & 1);

@@ -750,4 +750,22 @@ __device__ __forceinline__ void net_pass(const NetParams& P, unsigned char* lds,
     }
 }
 
+// kernel-side view of a packed network (host): offsets copied from the descriptor; n_dev / debug_stop left off
+inline NetParams make_net_params(const LzNetDesc* d) {
+    NetParams P;
+    P.wfrag = reinterpret_cast<const _Float16*>(d->wfrag);
+    P.fp = d->fparams;
+    for (int i = 0; i < 32; ++i) P.layer_off[i] = i < d->num_layers ? d->layer_offsets[i] : 0;
+    P.blocks = d->blocks;
+    P.n_dev = nullptr;
+    P.wfrag_bytes = (int)d->wfrag_bytes; P.fparams_bytes = (int)d->fparams_bytes;
+    P.debug_stop = 0;
+    P.hf_gw = d->head_frag_offsets[0]; P.hf_w1 = d->head_frag_offsets[1]; P.hf_w2 = d->head_frag_offsets[2];
+    P.hf_out = d->head_frag_offsets[3];
+    P.stem_bias = d->off_stem_bias; P.blk0 = d->off_block0; P.trunk_a = d->off_trunk_a; P.trunk_b = d->off_trunk_b;
+    P.head_bias = d->off_head_bias; P.p_gwT = d->off_p_gwT; P.p_a2 = d->off_p_a2; P.p_b2 = d->off_p_b2;
+    P.p_out = d->off_p_out; P.v_w1T = d->off_v_w1T; P.v_b1 = d->off_v_b1; P.v_w2T = d->off_v_w2T; P.v_b2 = d->off_v_b2;
+    return P;
+}
+
 }  // namespace

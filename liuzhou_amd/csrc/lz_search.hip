@@ -1,0 +1,181 @@
+// lz_search.hip -- the whole search of one move as ONE kernel launch: a workgroup OWNS its games.
+//
+// Replaces the per-simulation launch pair of lz_tree_search (network kernel + tree kernel, i.e. two kernel
+// boundaries and a device-wide barrier per simulation: 2 x (sims + 1) graph nodes per move) for the reference loop
+//   v1/cpp/portable_mcts.cpp:483-590,832-939 / v1/python/portable_cpp_mcts.py:270-282
+//   (prepare roots -> evaluate -> complete, then sims x (select -> evaluate -> complete)).
+//
+// Games never talk to each other, so nothing in that loop needs the whole grid:
+//   * a workgroup of W waves owns S games for the whole move;
+//   * per simulation it runs ONE network pass on its S pending leaf positions (lz_net_dev.h: the same code, tile
+//     maps and MFMA order as the stand-alone kernel, so the evaluations are bit-identical to it) and then the tree
+//     step of those S games (lz_tree_dev.h: expand + backup of simulation s, selection of simulation s + 1 -- the
+//     same device functions the per-step kernels run), S / W games per wave;
+//   * the only synchronisation is the workgroup barrier between the two phases; leaf states, head rows and values
+//     are handed over through global memory (L2-resident, a few hundred bytes per game and simulation);
+//   * with the 64-channel network two such workgroups (4 waves, 8 games, < 80 KB of LDS each) share a CU: while one
+//     is in its latency-bound tree step the other one has the matrix pipes to itself.  Workgroups that land on a CU
+//     second start half a period late (`stagger`), so the two do not run their phases in lockstep.
+// Every wave runs exactly sims + 1 iterations and leaves: there is no work queue, no spinning, no grid barrier.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include "../../include/liuzhou_hip.h"
+#include "lz_net_dev.h"
+#include "lz_tree_dev.h"
+
+namespace {
+
+constexpr int kCuSlots = 4096;      // entries of the per-launch "which workgroup came second on this CU" table
+
+// (XCC, SE, SH, CU) of the executing wave as a table index (HW_REG_HW_ID: CU_ID[11:8] SH_ID[12] SE_ID[15:13];
+// HW_REG_XCC_ID: XCC_ID[3:0])
+__device__ __forceinline__ int cu_key() {
+    const unsigned hw = __builtin_amdgcn_s_getreg((4 /*HW_ID*/) | (8 << 6) | ((8 - 1) << 11));      // bits 8..15
+    const unsigned xcc = __builtin_amdgcn_s_getreg((20 /*XCC_ID*/) | (0 << 6) | ((4 - 1) << 11));   // bits 0..3
+    return (int)(((xcc & 15u) << 8) | (hw & 255u)) & (kCuSlots - 1);
+}
+
+struct SearchArgs {
+    int sims;
+    const float* noise; int noise_stride; float epsilon;
+    int* cu_slots;              // [kCuSlots] zeroed before the launch, or nullptr (no stagger)
+    int stagger_ticks;          // delay of a CU's second workgroup, in 100 MHz ticks
+    long long* phase_ticks;     // optional [grid][2]: 100 MHz ticks wave 0 spent in network passes / tree steps
+};
+
+template <int C, int S, int W>
+__global__ __launch_bounds__(W * 64, 2) void tree_search_persistent_kernel(NetParams P, Tree t, SearchArgs a, float* lp1,
+                                                                           float* lp2, float* lpm, float* values) {
+    static_assert(S % W == 0, "every wave owns the same number of games");
+    constexpr int GPW = S / W;                                  // games per wave
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    NetCtx<C, S, W> ctx;
+    net_setup<C, S, W>(P, lds, ctx);
+    const int g0 = blockIdx.x * S;
+    const int nvalid = (t.B - g0) < S ? (t.B - g0) : S;
+    // ---- stagger: the second workgroup on a CU waits half a period so the pair alternates its phases ----
+    if (a.cu_slots != nullptr && a.stagger_ticks > 0) {
+        int slot = 0;
+        if (threadIdx.x == 0) slot = atomicAdd(&a.cu_slots[cu_key()], 1);
+        slot = __builtin_amdgcn_readfirstlane(slot);
+        if (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == 0 && (slot & 1)) {
+            const uint64_t t0 = wall_clock64();
+            while ((long long)(wall_clock64() - t0) < (long long)a.stagger_ticks) __builtin_amdgcn_s_sleep(64);
+        }
+        // the other waves wait for wave 0 at the barrier that opens the first pass
+    }
+    long long tk_net = 0, tk_tree = 0;
+    for (int s = 0; s <= a.sims; ++s) {
+        const uint64_t c0 = a.phase_ticks != nullptr ? wall_clock64() : 0;
+        // ---- network pass on the S pending leaves (starts with a workgroup barrier) ----
+        net_pass<C, S, W>(P, lds, ctx, nullptr, reinterpret_cast<const uint64_t*>(t.leaf_state), (int64_t)g0, nvalid, lp1,
+                          lp2, lpm, nullptr, values);
+        __syncthreads();                                       // head rows / values of all S games are visible
+        const uint64_t c1 = a.phase_ticks != nullptr ? wall_clock64() : 0;
+        // ---- tree step of the games this wave owns ----
+        __builtin_amdgcn_s_setprio(3);                          // short bursts between dependent loads go first
+        int wave_s = ctx.wave;
+        asm volatile("" : "+s"(wave_s));                        // nothing of the tree step is hoisted across the pass
+        // expand scratch: the fc1 hidden rows / g vectors of the pass are dead until the next pass stages its input
+        static_assert(W * kExpandScratchBytes <= Cfg<C, S, W>::B_BYTES, "expand scratch must fit the dead head region");
+        const ExpandScratch sc = {reinterpret_cast<float*>(lds + Cfg<C, S, W>::G_OFF + wave_s * kExpandScratchBytes),
+                                  reinterpret_cast<int*>(lds + Cfg<C, S, W>::G_OFF + wave_s * kExpandScratchBytes + 320)};
+#pragma unroll 1
+        for (int j = 0; j < GPW; ++j) {
+            const int g = g0 + wave_s * GPW + j;
+            if (g >= t.B) break;
+            RootInfo root;
+            if (s == 0) {
+                tree_expand<true>(t, g, ctx.lane, lp1, lp2, lpm, nullptr, values, a.noise, a.noise_stride, a.epsilon, sc, &root, s);
+                if (a.sims > 0) {
+                    __threadfence_block();
+                    root = load_root_info(t, g);                // the root record itself was just written
+                    tree_select(t, g, ctx.lane, root);
+                }
+            } else {
+                tree_expand<false>(t, g, ctx.lane, lp1, lp2, lpm, nullptr, values, nullptr, 0, 0.f, sc, &root, s);
+                if (s < a.sims) {
+                    __threadfence_block();
+                    tree_select(t, g, ctx.lane, root);
+                }
+            }
+        }
+        __builtin_amdgcn_s_setprio(0);
+        if (a.phase_ticks != nullptr) {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            const uint64_t c2 = wall_clock64();
+            tk_net += (long long)(c1 - c0); tk_tree += (long long)(c2 - c1);
+        }
+        // the next pass opens with a workgroup barrier: every wave's new leaf states are written by then
+    }
+    if (a.phase_ticks != nullptr && threadIdx.x == 0) {
+        a.phase_ticks[2 * blockIdx.x] = tk_net;
+        a.phase_ticks[2 * blockIdx.x + 1] = tk_tree;
+    }
+}
+
+__global__ void zero_i32_kernel(int* p, int n) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) p[i] = 0;
+}
+
+template <int C, int S, int W>
+int configure_search() {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(tree_search_persistent_kernel<C, S, W>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, Cfg<C, S, W>::LDS_BYTES) == hipSuccess
+               ? LZ_OK : LZ_ERR_LAUNCH;
+}
+
+bool g_search_configured = false;
+
+}  // namespace
+
+// live timing hooks of lz_net.hip (bench.py's roofline probe): the search kernel is bracketed like a network launch
+extern "C" int lz_prof_mark_begin(void* stream);
+extern "C" int lz_prof_mark_end(void* stream, int64_t evals);
+
+extern "C" {
+
+int lz_tree_search_persistent(const LzTreeDesc* d, const LzNetDesc* net, int64_t sims, float* lp1, float* lp2,
+                              float* lpmc, float* values, const float* noise, int64_t noise_stride, float epsilon,
+                              int continue_trees, int32_t* cu_slots, int64_t stagger_us, int64_t* phase_ticks,
+                              void* stream) {
+    if (!tree_ok(d) || !net || sims < 0 || !lp1 || !lp2 || !lpmc || !values || stagger_us < 0) return LZ_ERR_ARG;
+    if (!net->wfrag || !net->fparams) return LZ_ERR_ARG;
+    if (net->blocks < 0 || net->blocks > 15 || net->num_layers != 2 + 2 * net->blocks) return LZ_ERR_ARG;
+    if ((reinterpret_cast<uintptr_t>(net->wfrag) & 15) || (reinterpret_cast<uintptr_t>(net->fparams) & 15)) return LZ_ERR_ALIGN;
+    // built for the 64-channel network (two 4-wave workgroups per CU); the fp32 parity mode and the 128-channel
+    // network (one workgroup fills a CU's LDS: nothing would overlap the tree step) stay on lz_tree_search
+    if (net->channels != 64 || (net->flags & 4)) return LZ_ERR_UNSUPPORTED;
+    const int64_t B = d->num_games;
+    if (B == 0) return LZ_OK;
+    if (!g_search_configured) {
+        const int rc = configure_search<64, 8, 4>();
+        if (rc) return rc;
+        g_search_configured = true;
+    }
+    int rc = continue_trees ? LZ_OK : lz_tree_begin(d, stream);
+    if (rc) return rc;
+    hipStream_t stm = as_stream(stream);
+    if (cu_slots != nullptr && stagger_us > 0)
+        hipLaunchKernelGGL(zero_i32_kernel, dim3(1), dim3(256), 0, stm, cu_slots, kCuSlots);
+    const NetParams P = make_net_params(net);
+    SearchArgs a;
+    a.sims = (int)sims; a.noise = noise; a.noise_stride = (int)noise_stride; a.epsilon = epsilon;
+    a.cu_slots = (cu_slots != nullptr && stagger_us > 0) ? cu_slots : nullptr;
+    a.stagger_ticks = (int)(stagger_us * 100);
+    a.phase_ticks = reinterpret_cast<long long*>(phase_ticks);
+    using K = Cfg<64, 8, 4>;
+    const unsigned grid = (unsigned)((B + 8 - 1) / 8);
+    (void)lz_prof_mark_begin(stream);
+    hipLaunchKernelGGL((tree_search_persistent_kernel<64, 8, 4>), dim3(grid), dim3(K::THREADS), K::LDS_BYTES, stm, P,
+                       make_tree(d), a, lp1, lp2, lpmc, values);
+    (void)lz_prof_mark_end(stream, B * (sims + 1));
+    return st();
+}
+
+int lz_tree_search_persistent_grid(int64_t num_games) { return (int)((num_games + 7) / 8); }
+
+}  // extern "C"

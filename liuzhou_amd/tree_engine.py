@@ -145,6 +145,12 @@ class TreeEngine:
         self.child_visits = z((B, OUT_CAP), torch.int32)
         self.child_prior = z((B, OUT_CAP), torch.float32)
         self.reuse_dropped = z((1,), torch.int32)
+        # persistent search kernel (lz_tree_search_persistent): on unless LZ_TREE_PERSISTENT=0; the CU's second workgroup
+        # starts `stagger_us` late (LZ_TREE_STAGGER_US) so that the pair sharing a CU alternates network pass / tree step
+        self.persistent = os.environ.get("LZ_TREE_PERSISTENT", "1").strip().lower() not in ("0", "off", "false")
+        self.stagger_us = int(os.environ.get("LZ_TREE_STAGGER_US", "40"))
+        self._cu_slots: Optional[torch.Tensor] = None
+        self.phase_ticks: Optional[torch.Tensor] = None
 
     def enable_trace(self, steps: Optional[int] = None) -> Dict[str, torch.Tensor]:
         """Parity tests: record, per step of a search (slot 0 = root step, slot s = s-th simulation), what the expand
@@ -297,12 +303,43 @@ class TreeEngine:
             self.search_waves(net, sims, -(-int(sims) // self.batch_k), noise, epsilon, continue_trees)
             return
         nz_stride = int(noise.shape[1]) if noise is not None else 0
+        if self.persistent_ok(net):
+            # one launch per move: a workgroup owns 8 games, no kernel boundary between simulations (csrc/lz_search.hip)
+            if self._cu_slots is None:
+                self._cu_slots = torch.zeros((4096,), dtype=torch.int32, device=self.device)
+            with torch.cuda.device(self.device):
+                L.check(L.lib().lz_tree_search_persistent(
+                    C.byref(self.desc), C.byref(net.desc), L.i64(sims), L.ptr(self.lp1), L.ptr(self.lp2), L.ptr(self.lpm),
+                    L.ptr(self.values), L.ptr(noise), L.i64(nz_stride), C.c_float(float(epsilon)),
+                    C.c_int(1 if continue_trees else 0), L.ptr(self._cu_slots), L.i64(self.stagger_us),
+                    L.ptr(self.phase_ticks), self._stream()), "tree_search_persistent")
+            return
         fn = L.lib().lz_tree_search_continue if continue_trees else L.lib().lz_tree_search
         with torch.cuda.device(self.device):
             L.check(fn(C.byref(self.desc), C.byref(net.desc), L.i64(sims), L.ptr(self.planes),
                        L.ptr(self.lp1), L.ptr(self.lp2), L.ptr(self.lpm), L.ptr(self.values),
                        L.ptr(noise), L.i64(nz_stride), C.c_float(float(epsilon)), self._stream()),
                     "tree_search")
+
+    def persistent_ok(self, net: FusedNet) -> bool:
+        """Whether search() runs the one-launch-per-move kernel: 64-channel net in fp16 mode, not switched off
+        (`persistent` attribute; env LZ_TREE_PERSISTENT=0)."""
+        return bool(self.persistent) and self.batch_k <= 1 and int(net.desc.channels) == 64 and not (int(net.desc.flags) & 4)
+
+    def enable_phase_ticks(self) -> torch.Tensor:
+        """Measurement aid: int64[workgroups, 2] = 100 MHz ticks each workgroup of the persistent search kernel spent in
+        network passes / tree steps during the LAST search (must be enabled before the search is captured)."""
+        n = int(L.lib().lz_tree_search_persistent_grid(L.i64(self.B)))
+        self.phase_ticks = torch.zeros((n, 2), dtype=torch.int64, device=self.device)
+        return self.phase_ticks
+
+
+def persistent_search_available(net, batch_k: int = 1) -> bool:
+    """Does the search of `net` run as the one-launch-per-move kernel (csrc/lz_search.hip)?  Then one engine over all
+    games already puts two workgroups on every CU, and the two-stream split (DualStreamTreeMCTS) has nothing to add."""
+    if os.environ.get("LZ_TREE_PERSISTENT", "1").strip().lower() in ("0", "off", "false"):
+        return False
+    return isinstance(net, FusedNet) and int(batch_k) <= 1 and int(net.desc.channels) == 64 and not (int(net.desc.flags) & 4)
 
 
 def dirichlet_noise(shape, alpha: float, device, generator=None) -> torch.Tensor:
@@ -753,7 +790,8 @@ class SteadyStateTreeSelfPlay:
         # two streams pay for 64 channels (two 4-wave workgroups share a CU); the 128-channel kernel fills a CU's registers
         # with one workgroup, so its launches cannot overlap -- LZ_DUAL_128=1 tries it anyway (experiment)
         allow = self.net.pack.channels == 64 or os.environ.get("LZ_DUAL_128", "0") == "1"
-        self.dual_stream = bool(dual_stream and allow and int(num_games) >= 2)
+        self.dual_stream = bool(dual_stream and allow and int(num_games) >= 2
+                                and not persistent_search_available(self.net, batch_k))
         if self.dual_stream:
             self.mcts = DualStreamTreeMCTS(self.net, num_games, sims, dev, exploration_weight=exploration_weight,
                                            reuse_tree=reuse_tree, reuse_factor=reuse_factor, batch_k=batch_k, seed=seed)
@@ -821,6 +859,8 @@ def self_play_tree_gpu(model, num_games: int, mcts_simulations: int, temperature
     # two half-batches on two streams (see DualStreamTreeMCTS) once a wave is large enough to fill the chip twice over
     if dual_stream is None:
         dual_stream = use_fused and net.pack.channels == 64 and wave >= 1024 and int(batch_k) <= 1   # waves: large launches already
+    if use_fused and persistent_search_available(net, batch_k):
+        dual_stream = False                                  # the persistent kernel overlaps the phases inside every CU
     cls = DualStreamTreeMCTS if (dual_stream and use_fused and net.pack.channels == 64 and wave >= 2) else PortableTreeMCTS
     mcts = cls(net, wave, mcts_simulations, dev, exploration_weight=exploration_weight,
                add_dirichlet_noise=add_dirichlet_noise, dirichlet_alpha=dirichlet_alpha,
