@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from oracle import lz_oracle as O
-from tests.golden_utils import load, states, unpack_mask, states_equal, FIELDS
+from tests.golden_utils import load, states, unpack_mask, states_equal, FIELDS, row_hash64, group_hash64, state_rows
 
 pytestmark = pytest.mark.gpu
 
@@ -76,6 +76,60 @@ def test_encode_actions_large_random_vs_oracle(v0):
     mask, meta = v0.encode_actions_fast(*t[:10], 36, 144, 36, 4)
     assert np.array_equal(mask.cpu().numpy(), want_mask)
     assert np.array_equal(meta.cpu().numpy(), want_meta)
+
+
+# ---- reference-scale suites (oracle/gen_golden_large.py): the sizes, generators and seeds of the reference's own tests ----
+@pytest.mark.parametrize("aux,key", [(1, "t217"), (4, "t220")])
+def test_encode_actions_reference_suite_10000_garbage_states(v0, aux, key):
+    """The 10 000 synthetic states of tests/v0/cuda/test_fast_legal_mask_cuda.py:74-118,179-228 (its generator, its seed
+    0xF00DCAFE) against the reference CPU operator's outputs: mask bit-exact, metadata by 64-bit row hash."""
+    z = load("g16_garbage_large.npz")
+    t = to_dev(states(z, "s"))
+    assert t[0].shape[0] == 10000
+    mask, meta = v0.encode_actions_fast(*t[:10], 36, 144, 36, aux)
+    assert np.array_equal(mask.cpu().numpy(), unpack_mask(z[f"mask_{key}"], 216 + aux))
+    bad = np.flatnonzero(row_hash64(meta.cpu().numpy()) != z[f"meta_hash_{key}"])
+    assert bad.size == 0, f"metadata rows differ: {bad[:10]}"
+    if aux == 4:
+        planes = v0.states_to_model_input(*t[:5])
+        assert np.array_equal(row_hash64(planes.cpu().numpy().astype(np.int8)), z["model_input_hash"])
+
+
+def test_batch_apply_moves_reference_suite_10000_micro_positions(v0):
+    """The 10 000 per-kind micro-positions of tests/v0/cuda/test_fast_apply_moves_cuda.py:127-247,343-373 (its generator,
+    its seed 0xA11CEB0B): all 12 output tensors equal the reference CPU operator's."""
+    z = load("g17_apply_micro.npz")
+    t = to_dev(states(z, "s"))
+    n = t[0].shape[0]
+    assert n == 10000
+    codes = torch.from_numpy(z["codes"].astype(np.int32)).to(DEV)
+    parents = torch.arange(n, dtype=torch.int64, device=DEV)
+    out = v0.batch_apply_moves(*t, codes, parents)
+    ok, field = states_equal(from_dev(out), states(z, "c"))
+    assert ok, field
+
+
+def test_rules_reference_suite_5000_playout_states(v0):
+    """>= 5 000 reachable states of src/ random playouts (seed 0x7777, tests/v0/test_actions.py:115-159 scale): legal
+    mask bit-exact, metadata by row hash, and EVERY child transition (per-state hash of the children in ascending action
+    order) against the reference's Python rule engine."""
+    z = load("g15_rules_large.npz")
+    st = states(z, "s")
+    t = to_dev(st)
+    n = t[0].shape[0]
+    assert n >= 5000
+    mask, meta = v0.encode_actions_fast(*t[:10], 36, 144, 36, 4)
+    want = unpack_mask(z["legal_mask"], 220)
+    assert np.array_equal(mask.cpu().numpy(), want)
+    meta_h = meta.cpu().numpy()
+    assert np.array_equal(row_hash64(meta_h), z["metadata_hash"])
+    parents, actions = np.nonzero(want)                    # row-major: children grouped by parent, ascending action
+    assert parents.size == int(z["num_children"])
+    codes = torch.from_numpy(np.ascontiguousarray(meta_h[parents, actions])).to(DEV)
+    out = v0.batch_apply_moves(*t, codes, torch.from_numpy(parents.astype(np.int64)).to(DEV))
+    got = group_hash64(row_hash64(state_rows(from_dev(out))), parents, n)
+    bad = np.flatnonzero(got != z["children_hash"])
+    assert bad.size == 0, f"children of states {bad[:10]} differ"
 
 
 def test_encode_actions_empty_batch(v0):

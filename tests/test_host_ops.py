@@ -26,6 +26,9 @@ test_encode_actions_reachable_bit_exact = G.test_encode_actions_reachable_bit_ex
 test_encode_actions_garbage_bit_exact = G.test_encode_actions_garbage_bit_exact
 test_encode_actions_large_random_vs_oracle = G.test_encode_actions_large_random_vs_oracle
 test_encode_actions_empty_batch = G.test_encode_actions_empty_batch
+test_encode_actions_reference_suite_10000_garbage_states = G.test_encode_actions_reference_suite_10000_garbage_states
+test_batch_apply_moves_reference_suite_10000_micro_positions = G.test_batch_apply_moves_reference_suite_10000_micro_positions
+test_rules_reference_suite_5000_playout_states = G.test_rules_reference_suite_5000_playout_states
 test_batch_apply_moves_all_transitions_bit_exact = G.test_batch_apply_moves_all_transitions_bit_exact
 test_batch_apply_moves_inplace = G.test_batch_apply_moves_inplace
 test_states_to_model_input_exact = G.test_states_to_model_input_exact

@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 
 from oracle import lz_oracle as O
-from tests.golden_utils import load, states, unpack_mask, states_equal, FIELDS
+from tests.golden_utils import load, states, unpack_mask, states_equal, FIELDS, row_hash64, group_hash64, state_rows
 
 
 def test_g1_legal_masks_and_metadata_bit_exact():
@@ -63,6 +63,63 @@ def test_g3_garbage_states_match_reference_op(aux, key):
     assert np.array_equal(mask, unpack_mask(z[f"mask_{key}"], T))
     assert np.array_equal(meta, z[f"meta_{key}"].astype(np.int32))
     assert np.array_equal(O.states_to_model_input(st), z["model_input"].astype(np.float32))
+
+
+# ---- reference-scale suites (oracle/gen_golden_large.py) ----
+@pytest.mark.parametrize("aux,key", [(1, "t217"), (4, "t220")])
+def test_g16_reference_mask_suite_10000_states(aux, key):
+    z = load("g16_garbage_large.npz")
+    st = states(z, "s")
+    mask, meta = O.encode_actions(st, 36, 144, 36, aux)
+    assert mask.shape[0] == 10000
+    assert np.array_equal(mask, unpack_mask(z[f"mask_{key}"], 216 + aux))
+    assert np.array_equal(row_hash64(meta), z[f"meta_hash_{key}"])
+    if aux == 4:
+        assert np.array_equal(row_hash64(O.states_to_model_input(st).astype(np.int8)), z["model_input_hash"])
+
+
+def test_g17_reference_apply_suite_10000_micro_positions():
+    z = load("g17_apply_micro.npz")
+    st = states(z, "s")
+    n = st["board"].shape[0]
+    codes = z["codes"].astype(np.int32)
+    out = O.apply_moves(st, codes, np.arange(n, dtype=np.int64), strict=True)       # every action is legal: nothing raises
+    ok, field = states_equal(out, states(z, "c"))
+    assert ok, field
+    ok, field = states_equal(O.apply_moves(st, codes, np.arange(n, dtype=np.int64), strict=False), states(z, "c"))
+    assert ok, field
+
+
+def test_g15_reference_playout_suite_5000_states():
+    z = load("g15_rules_large.npz")
+    st = states(z, "s")
+    n = st["board"].shape[0]
+    assert n >= 5000
+    mask, meta = O.encode_actions(st)
+    want = unpack_mask(z["legal_mask"], 220)
+    assert np.array_equal(mask, want)
+    assert np.array_equal(row_hash64(meta), z["metadata_hash"])
+    parents, actions = np.nonzero(want)
+    assert parents.size == int(z["num_children"])
+    out = O.apply_moves(st, meta[parents, actions], parents.astype(np.int64), strict=True)
+    assert np.array_equal(group_hash64(row_hash64(state_rows(out)), parents, n), z["children_hash"])
+    for i in range(0, n, 97):                                   # Python-semantics index API on a sample
+        assert O.legal_indices_py(O.state_from_batch(st, i)) == list(np.nonzero(want[i])[0])
+
+
+def test_row_hash_helpers_detect_a_single_changed_element():
+    rng = np.random.default_rng(0)
+    a = rng.integers(-5, 40, (64, 220, 4))
+    h = row_hash64(a)
+    b = a.copy(); b[17, 200, 3] += 1
+    assert np.flatnonzero(row_hash64(b) != h).tolist() == [17]
+    items = rng.integers(0, 1 << 62, 30).astype(np.uint64)
+    grp = np.sort(rng.integers(0, 8, 30))
+    g = group_hash64(items, grp, 8)
+    sw = items.copy()
+    j = int(np.flatnonzero(np.diff(grp) == 0)[0])              # swap two neighbours of one group: order matters
+    sw[[j, j + 1]] = sw[[j + 1, j]]
+    assert np.flatnonzero(group_hash64(sw, grp, 8) != g).tolist() == [int(grp[j])]
 
 
 def test_g4_policy_projection():
