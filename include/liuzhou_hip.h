@@ -475,8 +475,8 @@ LZ_API int lz_tree_search_continue(const LzTreeDesc* tree, const LzNetDesc* net,
  * lz_tree_search.
  *   cu_slots:    int32[4096] scratch (zeroed by the call) or NULL; with stagger_us > 0 the second workgroup to arrive
  *                on a CU starts stagger_us microseconds late, so that the pair alternates its phases;
- *   phase_ticks: optional int64[grid][2] = 100 MHz ticks each workgroup spent in network passes / tree steps
- *                (grid = lz_tree_search_persistent_grid(num_games)); NULL in production. */
+ *   phase_ticks: optional int64[grid][4] = 100 MHz ticks each workgroup spent in network passes / tree steps, its
+ *                arrival slot on its CU, the CU key (grid = lz_tree_search_persistent_grid(num_games)); NULL in production. */
 LZ_API int lz_tree_search_persistent(const LzTreeDesc* tree, const LzNetDesc* net, int64_t sims, float* log_p1,
                                      float* log_p2, float* log_pmc, float* values, const float* noise,
                                      int64_t noise_stride, float epsilon, int continue_trees, int32_t* cu_slots,

@@ -43,7 +43,9 @@ struct SearchArgs {
     const float* noise; int noise_stride; float epsilon;
     int* cu_slots;              // [kCuSlots] zeroed before the launch, or nullptr (no stagger)
     int stagger_ticks;          // delay of a CU's second workgroup, in 100 MHz ticks
-    long long* phase_ticks;     // optional [grid][2]: 100 MHz ticks wave 0 spent in network passes / tree steps
+    long long* phase_ticks;     // optional [grid][4]: 100 MHz ticks wave 0 spent in network passes / tree steps, CU slot, CU key
+    int exp_mode;               // timing experiments only (wrong results): 1 = no tree step, 2 = sleep instead of the tree step,
+                                // 3 = tree step at normal wave priority; 0 in production
 };
 
 template <int C, int S, int W>
@@ -57,11 +59,13 @@ __global__ __launch_bounds__(W * 64, 2) void tree_search_persistent_kernel(NetPa
     const int g0 = blockIdx.x * S;
     const int nvalid = (t.B - g0) < S ? (t.B - g0) : S;
     // ---- stagger: the second workgroup on a CU waits half a period so the pair alternates its phases ----
-    if (a.cu_slots != nullptr && a.stagger_ticks > 0) {
-        int slot = 0;
-        if (threadIdx.x == 0) slot = atomicAdd(&a.cu_slots[cu_key()], 1);
-        slot = __builtin_amdgcn_readfirstlane(slot);
-        if (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == 0 && (slot & 1)) {
+    int slot = 0;
+    if (a.cu_slots != nullptr) {
+        __shared__ int s_slot;
+        if (threadIdx.x == 0) s_slot = atomicAdd(&a.cu_slots[cu_key()], 1);
+        __syncthreads();
+        slot = __builtin_amdgcn_readfirstlane(s_slot);
+        if (a.stagger_ticks > 0 && __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == 0 && (slot & 1)) {
             const uint64_t t0 = wall_clock64();
             while ((long long)(wall_clock64() - t0) < (long long)a.stagger_ticks) __builtin_amdgcn_s_sleep(64);
         }
@@ -76,17 +80,21 @@ __global__ __launch_bounds__(W * 64, 2) void tree_search_persistent_kernel(NetPa
         __syncthreads();                                       // head rows / values of all S games are visible
         const uint64_t c1 = a.phase_ticks != nullptr ? wall_clock64() : 0;
         // ---- tree step of the games this wave owns ----
-        __builtin_amdgcn_s_setprio(3);                          // short bursts between dependent loads go first
+        if (!(a.exp_mode & 4)) __builtin_amdgcn_s_setprio(3);   // short bursts between dependent loads go first
         int wave_s = ctx.wave;
         asm volatile("" : "+s"(wave_s));                        // nothing of the tree step is hoisted across the pass
         // expand scratch: the fc1 hidden rows / g vectors of the pass are dead until the next pass stages its input
         static_assert(W * kExpandScratchBytes <= Cfg<C, S, W>::B_BYTES, "expand scratch must fit the dead head region");
         const ExpandScratch sc = {reinterpret_cast<float*>(lds + Cfg<C, S, W>::G_OFF + wave_s * kExpandScratchBytes),
                                   reinterpret_cast<int*>(lds + Cfg<C, S, W>::G_OFF + wave_s * kExpandScratchBytes + 320)};
+        if (a.exp_mode & 2) {
+            const uint64_t t0 = wall_clock64();
+            while ((long long)(wall_clock64() - t0) < 2400) __builtin_amdgcn_s_sleep(16);
+        }
 #pragma unroll 1
         for (int j = 0; j < GPW; ++j) {
             const int g = g0 + wave_s * GPW + j;
-            if (g >= t.B) break;
+            if (g >= t.B || (a.exp_mode & 3)) break;
             RootInfo root;
             if (s == 0) {
                 tree_expand<true>(t, g, ctx.lane, lp1, lp2, lpm, nullptr, values, a.noise, a.noise_stride, a.epsilon, sc, &root, s);
@@ -103,7 +111,13 @@ __global__ __launch_bounds__(W * 64, 2) void tree_search_persistent_kernel(NetPa
                 }
             }
         }
-        __builtin_amdgcn_s_setprio(0);
+        // The instruction arbiter favours the OLDER wave: of the two workgroups on a CU the first to arrive would run its
+        // passes ~20 % faster than the second and leave it alone on the CU at the end.  Alternating a one-step priority
+        // edge between the pair, pass by pass, gives both the same average speed (they finish together).
+        if ((a.exp_mode & 8) ? (((slot + s) & 1) != 0) : ((a.exp_mode & 16) ? ((slot & 1) != 0) : false))
+            __builtin_amdgcn_s_setprio(1);
+        else
+            __builtin_amdgcn_s_setprio(0);
         if (a.phase_ticks != nullptr) {
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             const uint64_t c2 = wall_clock64();
@@ -112,8 +126,10 @@ __global__ __launch_bounds__(W * 64, 2) void tree_search_persistent_kernel(NetPa
         // the next pass opens with a workgroup barrier: every wave's new leaf states are written by then
     }
     if (a.phase_ticks != nullptr && threadIdx.x == 0) {
-        a.phase_ticks[2 * blockIdx.x] = tk_net;
-        a.phase_ticks[2 * blockIdx.x + 1] = tk_tree;
+        a.phase_ticks[4 * blockIdx.x] = tk_net;
+        a.phase_ticks[4 * blockIdx.x + 1] = tk_tree;
+        a.phase_ticks[4 * blockIdx.x + 2] = slot;
+        a.phase_ticks[4 * blockIdx.x + 3] = cu_key();
     }
 }
 
@@ -159,14 +175,15 @@ int lz_tree_search_persistent(const LzTreeDesc* d, const LzNetDesc* net, int64_t
     int rc = continue_trees ? LZ_OK : lz_tree_begin(d, stream);
     if (rc) return rc;
     hipStream_t stm = as_stream(stream);
-    if (cu_slots != nullptr && stagger_us > 0)
+    if (cu_slots != nullptr)
         hipLaunchKernelGGL(zero_i32_kernel, dim3(1), dim3(256), 0, stm, cu_slots, kCuSlots);
     const NetParams P = make_net_params(net);
     SearchArgs a;
     a.sims = (int)sims; a.noise = noise; a.noise_stride = (int)noise_stride; a.epsilon = epsilon;
-    a.cu_slots = (cu_slots != nullptr && stagger_us > 0) ? cu_slots : nullptr;
+    a.cu_slots = cu_slots;
     a.stagger_ticks = (int)(stagger_us * 100);
     a.phase_ticks = reinterpret_cast<long long*>(phase_ticks);
+    a.exp_mode = getenv("LZ_EXP_SEARCH_MODE") ? atoi(getenv("LZ_EXP_SEARCH_MODE")) : 0;
     using K = Cfg<64, 8, 4>;
     const unsigned grid = (unsigned)((B + 8 - 1) / 8);
     (void)lz_prof_mark_begin(stream);

@@ -145,9 +145,11 @@ class TreeEngine:
         self.child_visits = z((B, OUT_CAP), torch.int32)
         self.child_prior = z((B, OUT_CAP), torch.float32)
         self.reuse_dropped = z((1,), torch.int32)
-        # persistent search kernel (lz_tree_search_persistent): on unless LZ_TREE_PERSISTENT=0; the CU's second workgroup
+        # persistent search kernel (lz_tree_search_persistent, one launch per move): built, parity-tested and MEASURED
+        # SLOWER than the two-stream launch pairs at C2 (profiles/r03_experiments.md: 164-170 k against 192-194 k
+        # positions/s), so it is opt-in (LZ_TREE_PERSISTENT=1 / the `persistent` attribute).  The CU's second workgroup
         # starts `stagger_us` late (LZ_TREE_STAGGER_US) so that the pair sharing a CU alternates network pass / tree step
-        self.persistent = os.environ.get("LZ_TREE_PERSISTENT", "1").strip().lower() not in ("0", "off", "false")
+        self.persistent = _persistent_default()
         self.stagger_us = int(os.environ.get("LZ_TREE_STAGGER_US", "40"))
         self._cu_slots: Optional[torch.Tensor] = None
         self.phase_ticks: Optional[torch.Tensor] = None
@@ -327,17 +329,22 @@ class TreeEngine:
         return bool(self.persistent) and self.batch_k <= 1 and int(net.desc.channels) == 64 and not (int(net.desc.flags) & 4)
 
     def enable_phase_ticks(self) -> torch.Tensor:
-        """Measurement aid: int64[workgroups, 2] = 100 MHz ticks each workgroup of the persistent search kernel spent in
-        network passes / tree steps during the LAST search (must be enabled before the search is captured)."""
+        """Measurement aid: int64[workgroups, 4] = 100 MHz ticks each workgroup of the persistent search kernel spent in
+        network passes / tree steps during the LAST search, its arrival slot on its CU and the CU key (must be enabled
+        before the search is captured)."""
         n = int(L.lib().lz_tree_search_persistent_grid(L.i64(self.B)))
-        self.phase_ticks = torch.zeros((n, 2), dtype=torch.int64, device=self.device)
+        self.phase_ticks = torch.zeros((n, 4), dtype=torch.int64, device=self.device)
         return self.phase_ticks
 
 
+def _persistent_default() -> bool:
+    return os.environ.get("LZ_TREE_PERSISTENT", "0").strip().lower() in ("1", "on", "true")
+
+
 def persistent_search_available(net, batch_k: int = 1) -> bool:
-    """Does the search of `net` run as the one-launch-per-move kernel (csrc/lz_search.hip)?  Then one engine over all
-    games already puts two workgroups on every CU, and the two-stream split (DualStreamTreeMCTS) has nothing to add."""
-    if os.environ.get("LZ_TREE_PERSISTENT", "1").strip().lower() in ("0", "off", "false"):
+    """Does the search of `net` run as the one-launch-per-move kernel (csrc/lz_search.hip; opt-in)?  Then one engine over
+    all games already puts two workgroups on every CU, and the two-stream split (DualStreamTreeMCTS) has nothing to add."""
+    if not _persistent_default():
         return False
     return isinstance(net, FusedNet) and int(batch_k) <= 1 and int(net.desc.channels) == 64 and not (int(net.desc.flags) & 4)
 

@@ -27,7 +27,8 @@ torch.manual_seed(20260314)
 model = ChessNet(**MODEL_CONFIGS[name]).eval().to(dev)
 
 
-def run(persistent: bool, stagger: int, ticks: bool):
+def run(persistent: bool, stagger: int, ticks: bool, mode: int = 0):
+    os.environ["LZ_EXP_SEARCH_MODE"] = str(mode)
     os.environ["LZ_TREE_PERSISTENT"] = "1" if persistent else "0"
     os.environ["LZ_TREE_STAGGER_US"] = str(stagger)
     torch.manual_seed(9973)
@@ -47,7 +48,7 @@ def run(persistent: bool, stagger: int, ticks: bool):
         pop.step()
     torch.cuda.synchronize(dev)
     dt = (time.perf_counter() - t0) / steps
-    out = {"persistent": persistent, "stagger_us": stagger, "ms_per_step": round(dt * 1e3, 3),
+    out = {"persistent": persistent, "stagger_us": stagger, "exp_mode": mode, "ms_per_step": round(dt * 1e3, 3),
            "positions_per_s": round(games / dt, 1), "us_per_sim": round(dt * 1e6 / (sims + 1), 2)}
     if pt is not None:
         t = pt.double().cpu()
@@ -55,7 +56,14 @@ def run(persistent: bool, stagger: int, ticks: bool):
                                    "tree_mean": round(float(t[:, 1].mean()) / 100 / (sims + 1), 2),
                                    "net_max": round(float(t[:, 0].max()) / 100 / (sims + 1), 2),
                                    "tree_max": round(float(t[:, 1].max()) / 100 / (sims + 1), 2),
-                                   "wg_total_max": round(float(t.sum(1).max()) / 100 / (sims + 1), 2)}
+                                   "wg_total_max": round(float(t[:, :2].sum(1).max()) / 100 / (sims + 1), 2),
+                                   "wg_total_mean": round(float(t[:, :2].sum(1).mean()) / 100 / (sims + 1), 2),
+                                   "second_slot_wgs": int((t[:, 2].long() & 1).sum()), "distinct_cus": int(t[:, 3].unique().numel()),
+                                   "max_wgs_per_cu": int(torch.bincount(t[:, 3].long()).max())}
+        dump = os.environ.get("LZ_EXP_DUMP_TICKS")
+        if dump:                                              # raw per-workgroup rows: net ticks, tree ticks, slot, CU key
+            import numpy as np
+            np.save(f"{dump}_s{stagger}_m{mode}.npy", pt.cpu().numpy())
     del pop
     torch.cuda.empty_cache()
     print(json.dumps(out), flush=True)
@@ -64,5 +72,7 @@ def run(persistent: bool, stagger: int, ticks: bool):
 for s in settings:
     if s == "off":
         run(False, 0, False)
+    elif ":" in s:                                   # stagger:mode  (timing experiments with wrong results)
+        run(True, int(s.split(":")[0]), True, int(s.split(":")[1]))
     else:
         run(True, int(s), True)

@@ -451,6 +451,31 @@ def test_production_search_path_replayed_in_oracle(dual):
     print(f"production parity dual={dual}: {tot}")
 
 
+def test_persistent_search_kernel_replayed_in_oracle_and_equal_to_the_launch_pairs(monkeypatch):
+    """lz_tree_search_persistent (csrc/lz_search.hip, opt-in: one launch per move, a workgroup owns 8 games): the same
+    production-parity replay in the oracle -- graph replay, subtree reuse, Philox noise, sampled moves, a game count that is
+    not a multiple of the 8 games per workgroup -- and bit-identical root edge records to the per-simulation launch pairs
+    (the same device functions run the network pass and the tree steps in both)."""
+    _need_gpu()
+    from tests.tree_parity import run_production_parity, root_edges
+    ref, _ = run_production_parity(DEV, "b6c64", num_games=77, sims=96, moves=3, seed=31)
+    assert not ref.engine.persistent
+    monkeypatch.setenv("LZ_TREE_PERSISTENT", "1")
+    got, tot = run_production_parity(DEV, "b6c64", num_games=77, sims=96, moves=3, seed=31)
+    assert got.engine.persistent and got.engine.persistent_ok(got.net) and got.use_graph and not got.graph_retry_off
+    assert tot["kept"] > 0
+    for x, y in zip(root_edges(got.engine), root_edges(ref.engine)):
+        assert x.tobytes() == y.tobytes()
+    assert torch.equal(got.engine.chosen_index, ref.engine.chosen_index)
+    # the 128-channel net and the fp32 parity mode are refused by the entry point and stay on the launch pairs
+    from liuzhou_amd.net import ChessNet, MODEL_CONFIGS
+    from liuzhou_amd.net_hip import FusedNet
+    torch.manual_seed(1)
+    big = FusedNet(ChessNet(**MODEL_CONFIGS["b10c128"]).eval().to(DEV))
+    assert not got.engine.persistent_ok(big)
+    assert not got.engine.persistent_ok(FusedNet(ChessNet(**MODEL_CONFIGS["b6c64"]).eval().to(DEV), precision="fp32"))
+
+
 def test_production_search_path_c3_arithmetic():
     """C3's arithmetic and arena sizes on a small population: 10x128 network, 800 simulations per move, 64 games, two
     consecutive moves (the second one continues kept subtrees of several hundred nodes)."""
