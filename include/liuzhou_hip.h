@@ -341,6 +341,8 @@ typedef struct LzTreeDesc {
     float*   trace_priors;         /* [trace_cap][B][220] softmax over the legal set before noise / renormalisation */
     float*   trace_value;          /* [trace_cap][B] evaluator value the step read */
     int64_t  trace_cap;
+    int32_t* eval_count;           /* optional [B]: += 1 for every evaluation a game's expand step CONSUMED (a leaf or root it
+                                    * expanded); terminal leaves, inactive slots and kept roots do not count.  NULL: off */
 } LzTreeDesc;
 
 /* SoA batch -> packed records; packed records -> float32[B,11,6,6] model input (src/neural_network.py:15-65) */

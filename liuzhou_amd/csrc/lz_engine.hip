@@ -278,7 +278,7 @@ __device__ __forceinline__ void tree_select_wave(const Tree& t, const WaveArrays
                 State leaf = unpack(pn == 0 ? root.state : load_state(&nodes[pn].state));
                 int kd, p, q2, ex;
                 index_to_code(leaf.phase, act, kd, p, q2, ex);
-                apply(leaf, kd, p, q2);
+                apply_legal(leaf, kd, p, q2);
                 const Packed ps = pack(leaf);
                 const size_t slot = (size_t)lane * t.B + g;
                 const unsigned long long row = base_row + (unsigned long long)__popcll(need & ((1ull << lane) - 1ull));

@@ -216,15 +216,18 @@ LZ_HD int game_status(const State& s) {
 // ---- transitions --------------------------------------------------------------------------------
 // Illegal actions leave the state untouched (CUDA semantics, fast_apply_moves_cuda.cu:240-546);
 // returns true iff the action was accepted.  move_count / moves_since_capture are handled by apply().
-LZ_HD bool apply_rule(State& s, int kind, int primary, int secondary) {
+// CHECK = false: the caller guarantees a legal action (the tree engine only applies actions it enumerated with
+// legal_actions): the validation -- and the shape sets computed only for it -- is compiled out; results are the same.
+template <bool CHECK>
+LZ_HD bool apply_rule_t(State& s, int kind, int primary, int secondary) {
     const uint64_t full = ((s.black | s.white) & kFull);
     switch (kind) {
     case kActPlace: {
-        if (s.phase != kPlacement || primary < 0 || primary >= kCells) return false;
+        if (CHECK && (s.phase != kPlacement || primary < 0 || primary >= kCells)) return false;
         uint64_t bit = 1ull << primary;
-        if (full & bit) return false;
+        if (CHECK && (full & bit)) return false;
         uint64_t om = s.player == 1 ? s.mw : s.mb;
-        if (om & bit) return false;
+        if (CHECK && (om & bit)) return false;
         uint64_t& own = s.player == 1 ? s.black : s.white;
         own |= bit;
         uint64_t ownm = s.player == 1 ? s.mb : s.mw;
@@ -238,14 +241,14 @@ LZ_HD bool apply_rule(State& s, int kind, int primary, int secondary) {
         return true;
     }
     case kActMark: {
-        if (s.phase != kMarkSelection || s.pm_rem <= 0 || primary < 0 || primary >= kCells) return false;
+        if (CHECK && (s.phase != kMarkSelection || s.pm_rem <= 0 || primary < 0 || primary >= kCells)) return false;
         uint64_t bit = 1ull << primary;
         uint64_t opp = s.player == 1 ? s.white : s.black;
         uint64_t& om = s.player == 1 ? s.mw : s.mb;
-        if (!(opp & bit) || (om & bit)) return false;
+        if (CHECK && (!(opp & bit) || (om & bit))) return false;
         uint64_t U = opp & ~om;
         uint64_t shp = in_shape_set(opp, U);
-        if ((shp & bit) && (U & ~shp)) return false;     // unmarked normal pieces remain
+        if (CHECK && ((shp & bit) && (U & ~shp))) return false;     // unmarked normal pieces remain
         om |= bit;
         s.pm_rem -= 1;
         if (s.pm_rem > 0) return true;
@@ -255,7 +258,7 @@ LZ_HD bool apply_rule(State& s, int kind, int primary, int secondary) {
         return true;
     }
     case kActProcess: {
-        if (s.phase != kRemoval) return false;
+        if (CHECK && (s.phase != kRemoval)) return false;
         uint64_t m = (s.mb | s.mw) & kFull;
         if (!m) { s.phase = kForcedRemoval; s.player = -1; s.forced = 0; return true; }
         s.black &= ~m; s.white &= ~m; s.mb = 0; s.mw = 0;
@@ -263,31 +266,31 @@ LZ_HD bool apply_rule(State& s, int kind, int primary, int secondary) {
         return true;
     }
     case kActForced: {
-        if (s.phase != kForcedRemoval || primary < 0 || primary >= kCells) return false;
+        if (CHECK && (s.phase != kForcedRemoval || primary < 0 || primary >= kCells)) return false;
         uint64_t bit = 1ull << primary;
         if (s.forced == 0) {
-            if (s.player != -1 || !(s.black & bit)) return false;
-            if (in_shape_set(s.black, s.black) & bit) return false;
+            if (CHECK && (s.player != -1 || !(s.black & bit))) return false;
+            if (CHECK && (in_shape_set(s.black, s.black) & bit)) return false;
             s.black &= ~bit; s.forced = 1; s.player = 1;
             return true;
         }
         if (s.forced == 1) {
-            if (s.player != 1 || !(s.white & bit)) return false;
-            if (in_shape_set(s.white, s.white) & bit) return false;
+            if (CHECK && (s.player != 1 || !(s.white & bit))) return false;
+            if (CHECK && (in_shape_set(s.white, s.white) & bit)) return false;
             s.white &= ~bit; s.forced = 2; s.phase = kMovement; s.player = -1;
             return true;
         }
         return false;
     }
     case kActMove: {
-        if (s.phase != kMovement || secondary < 0 || secondary >= 4 || primary < 0 || primary >= kCells) return false;
+        if (CHECK && (s.phase != kMovement || secondary < 0 || secondary >= 4 || primary < 0 || primary >= kCells)) return false;
         int r = primary / 6, c = primary - 6 * r;
-        if ((secondary == 0 && r == 0) || (secondary == 1 && r == 5) || (secondary == 2 && c == 0) ||
-            (secondary == 3 && c == 5)) return false;
+        if (CHECK && ((secondary == 0 && r == 0) || (secondary == 1 && r == 5) || (secondary == 2 && c == 0) ||
+            (secondary == 3 && c == 5))) return false;
         int to = move_dest(primary, secondary);
         uint64_t fb = 1ull << primary, tb = 1ull << to;
         uint64_t& own = s.player == 1 ? s.black : s.white;
-        if (!(own & fb) || (full & tb)) return false;
+        if (CHECK && (!(own & fb) || (full & tb))) return false;
         own = (own & ~fb) | tb;
         int shape = detect_shape(own, to);
         if (shape) { s.pc_req = s.pc_rem = shape; s.phase = kCaptureSelection; return true; }
@@ -296,25 +299,25 @@ LZ_HD bool apply_rule(State& s, int kind, int primary, int secondary) {
         return true;
     }
     case kActNoMoves: {
-        if (s.phase != kMovement || primary < 0 || primary >= kCells) return false;
+        if (CHECK && (s.phase != kMovement || primary < 0 || primary >= kCells)) return false;
         uint64_t bit = 1ull << primary;
         uint64_t& opp = s.player == 1 ? s.white : s.black;
-        if (!(opp & bit)) return false;
+        if (CHECK && (!(opp & bit))) return false;
         uint64_t shp = in_shape_set(opp, opp);
-        if ((shp & bit) && (opp & ~shp)) return false;
+        if (CHECK && ((shp & bit) && (opp & ~shp))) return false;
         opp &= ~bit;
         if (popc(opp) < kLoseThreshold) return true;
         s.phase = kCounterRemoval; s.player = -s.player;
         return true;
     }
     case kActCapture: {
-        if (s.phase != kCaptureSelection || s.pc_rem <= 0 || primary < 0 || primary >= kCells) return false;
+        if (CHECK && (s.phase != kCaptureSelection || s.pc_rem <= 0 || primary < 0 || primary >= kCells)) return false;
         uint64_t bit = 1ull << primary;
         uint64_t& opp = s.player == 1 ? s.white : s.black;
         uint64_t om = s.player == 1 ? s.mw : s.mb;
-        if (!(opp & bit)) return false;
+        if (CHECK && (!(opp & bit))) return false;
         uint64_t shp = in_shape_set(opp, opp & ~om);
-        if ((shp & bit) && (opp & ~shp)) return false;
+        if (CHECK && ((shp & bit) && (opp & ~shp))) return false;
         opp &= ~bit;
         s.pc_rem -= 1;
         if (popc(opp) < kLoseThreshold || s.pc_rem > 0) return true;
@@ -323,12 +326,12 @@ LZ_HD bool apply_rule(State& s, int kind, int primary, int secondary) {
         return true;
     }
     case kActCounter: {
-        if (s.phase != kCounterRemoval || primary < 0 || primary >= kCells) return false;
+        if (CHECK && (s.phase != kCounterRemoval || primary < 0 || primary >= kCells)) return false;
         uint64_t bit = 1ull << primary;
         uint64_t& stuck = s.player == 1 ? s.white : s.black;
-        if (!(stuck & bit)) return false;
+        if (CHECK && (!(stuck & bit))) return false;
         uint64_t shp = in_shape_set(stuck, stuck);
-        if ((shp & bit) && (stuck & ~shp)) return false;
+        if (CHECK && ((shp & bit) && (stuck & ~shp))) return false;
         stuck &= ~bit;
         if (popc(stuck) < kLoseThreshold) return true;
         s.phase = kMovement; s.player = -s.player;
@@ -337,21 +340,26 @@ LZ_HD bool apply_rule(State& s, int kind, int primary, int secondary) {
     default: return false;
     }
 }
+LZ_HD bool apply_rule(State& s, int kind, int primary, int secondary) { return apply_rule_t<true>(s, kind, primary, secondary); }
 
 // apply_action incl. move_count / moves_since_capture bookkeeping
 // (fast_apply_moves_cuda.cu:610-743: placement bumps move_count only when accepted, every other
 //  known kind always; unknown kinds touch nothing but moves_since_capture; move_generator.py:122-137)
-LZ_HD bool apply(State& s, int kind, int primary, int secondary) {
+template <bool CHECK>
+LZ_HD bool apply_t(State& s, int kind, int primary, int secondary) {
     const int phase_before = s.phase;
     const int old_total = popc((s.black | s.white) & kFull);
     const int old_msc = s.msc;
-    bool ok = apply_rule(s, kind, primary, secondary);
+    bool ok = apply_rule_t<CHECK>(s, kind, primary, secondary);
     if (kind == kActPlace) { if (ok) s.move_count += 1; }
     else if (kind >= kActMove && kind <= kActProcess) s.move_count += 1;
     if (phase_before == kPlacement || phase_before == kMarkSelection) s.msc = 0;
     else s.msc = (popc((s.black | s.white) & kFull) < old_total) ? 0 : old_msc + 1;
     return ok;
 }
+LZ_HD bool apply(State& s, int kind, int primary, int secondary) { return apply_t<true>(s, kind, primary, secondary); }
+// a legal action of `s` (enumerated by legal_actions with Python semantics): same result, no validation
+LZ_HD void apply_legal(State& s, int kind, int primary, int secondary) { (void)apply_t<false>(s, kind, primary, secondary); }
 
 // 220-d action index -> (kind, primary, secondary, extra) for the state's phase
 // (v0/python/move_encoder.py:164-247; metadata layout fast_legal_mask.cpp:323-345)

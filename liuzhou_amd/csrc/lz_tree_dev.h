@@ -64,6 +64,7 @@ struct Tree {
     // optional trace of what every expand step consumed (LzTreeDesc.trace_*; nullptr in production)
     int* trace_kind; Packed* trace_leaf; float* trace_heads; float* trace_priors; float* trace_value;
     int trace_cap;
+    int* eval_count;      // optional per-game count of consumed evaluations
 };
 
 // Edge / node records are read with plain (L1 + L2 cached, normal retention) 16-byte loads.  This is safe next to the
@@ -153,8 +154,12 @@ __device__ __forceinline__ void tree_select(const Tree& t, int g, int lane, cons
         double best = -INFINITY;
         int best_k = -1;
         Edge mine[2];
+        mine[1] = Edge{};
+        // up to 2 children per lane, ascending edge index; the second slot only exists for nodes with more than 64
+        // children (a wave-uniform branch: the common case runs half the score arithmetic)
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {                          // up to 2 children per lane, ascending edge index
+        for (int r = 0; r < 2; ++r) {
+            if (r == 1 && ne <= kWave) break;
             const int k = r * kWave + lane;
             if (k < ne) {
                 mine[r] = load_edge(&edges[e0 + k]);
@@ -215,7 +220,7 @@ __device__ __forceinline__ void tree_select(const Tree& t, int g, int lane, cons
             State leaf = unpack(node_state);
             int kd, p, q2, ex;
             index_to_code(leaf.phase, leaf_action, kd, p, q2, ex);
-            apply(leaf, kd, p, q2);
+            apply_legal(leaf, kd, p, q2);                   // an action this engine enumerated: no re-validation
             t.leaf_state[g] = pack(leaf);
         }
     }
@@ -312,6 +317,7 @@ __device__ __forceinline__ void tree_expand(const Tree& t, int g, int lane, cons
     if (kind == kLeafTerminal) {
         backup_value = (double)leaf_value_ld;
     } else {
+        if (t.eval_count != nullptr && lane == 0) t.eval_count[g] += 1;     // this game's wave is the only writer
         const State s = unpack(leaf_packed);
         const Legal L = legal_actions(s, /*fallback_forced=*/0);     // python semantics (move_generator.py:24-70)
         const int n = legal_count(L);
@@ -401,6 +407,7 @@ __device__ __forceinline__ void tree_expand(const Tree& t, int g, int lane, cons
             // renormalise with a sequential fp32 sum in ascending action order (== the oracle's order): scalar loop
             // of v_readlane + add, no further LDS round trip
             float psum = 0.f;
+#pragma unroll 4
             for (int k = 0; k < n; ++k) psum += lzw::lane_bcast(k < kWave ? cval[0] : cval[1], k & 63);
             const bool bad = !(psum > 0.f) || !isfinite(psum);
             // node + edge allocation (per-game bump counters, worst-case sized regions)
@@ -429,7 +436,7 @@ __device__ __forceinline__ void tree_expand(const Tree& t, int g, int lane, cons
                 State c = s;
                 int kd, p, q2, ex;
                 index_to_code(s.phase, a, kd, p, q2, ex);
-                apply(c, kd, p, q2);
+                apply_legal(c, kd, p, q2);
                 uint8_t info = c.player < 0 ? kInfoWhite : 0;
                 if (game_status(c) != 0) {
                     const int tv = (int)terminal_value_for_mover(c);
@@ -502,6 +509,7 @@ Tree make_tree(const LzTreeDesc* d) {
     t.trace_priors = tr ? d->trace_priors : nullptr;
     t.trace_value = tr ? d->trace_value : nullptr;
     t.trace_cap = tr ? (int)d->trace_cap : 0;
+    t.eval_count = d->eval_count;
     return t;
 }
 bool tree_ok(const LzTreeDesc* d) {

@@ -41,7 +41,7 @@ class LzTreeDesc(C.Structure):
                    "root_init_value", "path", "path_len", "leaf_kind", "leaf_state", "leaf_value", "root_terminal",
                    "active", "leaf_edge", "leaf_parent",
                    "trace_kind", "trace_leaf", "trace_heads", "trace_priors", "trace_value")] + \
-               [("trace_cap", C.c_int64)]
+               [("trace_cap", C.c_int64), ("eval_count", C.c_void_p)]
 
 
 class LzTreeWaveDesc(C.Structure):
@@ -145,6 +145,8 @@ class TreeEngine:
         self.child_visits = z((B, OUT_CAP), torch.int32)
         self.child_prior = z((B, OUT_CAP), torch.float32)
         self.reuse_dropped = z((1,), torch.int32)
+        self.eval_count = z((B,), torch.int32)          # evaluations the games' expand steps consumed (LzTreeDesc.eval_count)
+        self.desc.eval_count = self.eval_count.data_ptr()
         # persistent search kernel (lz_tree_search_persistent, one launch per move): built, parity-tested and MEASURED
         # SLOWER than the two-stream launch pairs at C2 (profiles/r03_experiments.md: 164-170 k against 192-194 k
         # positions/s), so it is opt-in (LZ_TREE_PERSISTENT=1 / the `persistent` attribute).  The CU's second workgroup
@@ -538,6 +540,12 @@ class PortableTreeMCTS:
             n += int(self.engine.wbuf["eval_total"].item()) + int(self.engine.wbuf["eval_count"].item())
         return n
 
+    @property
+    def consumed_evals(self) -> int:
+        """Evaluations the searches actually consumed (expanded leaves and fresh roots): `leaf_evals` minus terminal
+        leaves, inactive slots and the unused evaluation of kept roots.  One host read."""
+        return int(self.engine.eval_count.sum(dtype=torch.int64).item())
+
     def _finish_waves(self) -> None:
         """batch_k > 1: games whose waves found fewer open leaves than batch_k still have budget (narrow trees)."""
         if self.batch_k <= 1:
@@ -584,6 +592,7 @@ class PortableTreeMCTS:
         self._have_trees = False
         self._root_evals = 0
         self.extra_rounds = 0
+        self.engine.eval_count.zero_()
         self.get_timing(reset=True)
         if self.batch_k > 1:
             self.engine.wbuf["eval_total"].zero_(); self.engine.wbuf["eval_count"].zero_()
@@ -704,6 +713,10 @@ class DualStreamTreeMCTS:
     def leaf_evals(self) -> int:
         return sum(p.leaf_evals for p in self.parts)
 
+    @property
+    def consumed_evals(self) -> int:
+        return sum(p.consumed_evals for p in self.parts)
+
     def prepare(self, state: GpuStateBatch) -> None:
         for (a, b), part in zip(self.bounds, self.parts):
             part.prepare(state._map(lambda t, a=a, b=b: t[a:b]))
@@ -815,6 +828,10 @@ class SteadyStateTreeSelfPlay:
     @property
     def leaf_evals(self) -> int:
         return self.mcts.leaf_evals
+
+    @property
+    def consumed_evals(self) -> int:
+        return self.mcts.consumed_evals
 
     def preroll(self, n: int = 120) -> None:
         self.pop.preroll(n)

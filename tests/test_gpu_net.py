@@ -7,9 +7,11 @@ from tests.golden_utils import load, states, FIELDS
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
-# fp16-operand kernel vs the fp32 module on nets with perturbed BatchNorm statistics: 2x the largest deviation observed on
-# MI355X (round 3: see the values this test prints)
-PROB_TOL, VLOGIT_TOL, VALUE_TOL = 3e-3, 3e-2, 3e-3
+# fp16-operand kernel vs the fp32 module on nets with perturbed BatchNorm statistics.  Observed on MI355X (round 3, the
+# values this test prints): probabilities <= 5.3e-6, scalar value <= 3.0e-6, 101 value logits <= 9.8e-5.  So the
+# PRODUCTION fp16 kernel meets north_star's 1e-5 bar on the policy probabilities and the value; the bounds are that bar
+# (about 2x what is observed), and 2x the observed maximum for the raw value logits.
+PROB_TOL, VLOGIT_TOL, VALUE_TOL = 1e-5, 2e-4, 1e-5
 
 
 def _planes(n, seed=0):
@@ -196,7 +198,7 @@ def test_fused_fp16_kernel_against_autocast_and_its_effect_on_the_search():
     d_f32 = max(float((f[k].exp() - r32[k].exp()).abs().max()) for k in range(3))
     d_ref = max(float((r16[k].exp() - r32[k].exp()).abs().max()) for k in range(3))
     print(f"max |dprob|: fused vs autocast {d_auto:.2e}, fused vs fp32 {d_f32:.2e}, autocast vs fp32 {d_ref:.2e}")
-    assert d_auto < 5e-5 and d_f32 < 5e-5          # observed 6e-6 / 3e-6 (random-init 6x64)
+    assert d_auto < 1.5e-5 and d_f32 < 1e-5        # observed 5.1e-6 / 2.1e-6 (random-init 6x64)
     assert d_f32 <= 4 * d_ref + 1e-6               # our fp16 path is not further from fp32 than the reference's own
     st = states(load("g1_rules.npz"), "s")
     idx = np.random.default_rng(12).integers(0, st["board"].shape[0], 96)
