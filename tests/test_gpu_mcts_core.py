@@ -102,3 +102,127 @@ def test_mcts_core_with_a_python_forward_callback():
     assert pol and abs(sum(p for _, p in pol) - 1.0) < 1e-9
     with pytest.raises(RuntimeError):
         core.set_torchscript_runner(object())
+
+
+def test_mcts_core_against_the_oracle_tree():
+    """f4 parity proper: `MCTSCore` (one game on the device tree engine, split-phase protocol, a Python forward callback)
+    against `oracle.OracleTree` driven by the SAME evaluations -- the oracle must ask for the same position at every
+    simulation and end with the same children: action indices and visit counts bit-exact, value sums equal as doubles
+    (same additions in the same order), priors within 1e-6 (the kernel forms them from the head rows itself), over a
+    search, an advance_root that keeps the subtree, and a second search.  Semantics: variant P (v1/python/portable_mcts.py),
+    which `MCTSCore` documents as its deliberate deviation from v0/src/mcts/mcts_core.cpp:270-278."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from liuzhou_amd import v0_core
+    from liuzhou_amd.net import ChessNet, MODEL_CONFIGS, bucket_logits_to_scalar
+    from oracle import lz_oracle as O
+    torch.manual_seed(7)
+    model = ChessNet(**MODEL_CONFIGS["tiny"]).eval().to(DEV)
+    log = []
+
+    def forward(x):
+        with torch.inference_mode():
+            lp1, lp2, lpm, raw = model(x.to(DEV))
+            val = bucket_logits_to_scalar(raw)
+        log.append((x.detach().cpu().numpy().copy(), lp1.cpu().numpy().copy(), lp2.cpu().numpy().copy(),
+                    lpm.cpu().numpy().copy(), float(val.reshape(-1)[0])))
+        return lp1, lp2, lpm, val
+
+    st = states(load("g1_rules.npz"), "s")
+    for i in (3, 400, 1200, 2000):
+        one = {f: np.ascontiguousarray(np.asarray(st[f])[i:i + 1]) for f in FIELDS}
+        one["moves_since_capture"][:] = 0                      # the reference's coercion does not carry this field
+        cfg = v0_core.MCTSConfig()
+        cfg.device, cfg.num_simulations, cfg.exploration_weight, cfg.add_dirichlet_noise = DEV, 40, 1.0, False
+        core = v0_core.MCTSCore(cfg)
+        core.set_forward_callback(forward)
+        del log[:]
+        core.set_root_state(_state_like(st, i))
+        core.run_simulations(40)
+        tree = O.OracleTree(O.state_from_batch(one, 0), 1.0)
+
+        def replay(calls):
+            """Feed the oracle the evaluations MCTSCore consumed, in order; returns the number of positions compared."""
+            used, k = 0, 0
+            steps = [True] + [False] * len(calls)              # the root step, then one selection per remaining call
+            for is_root in steps:
+                if k >= len(calls) and not is_root:
+                    break
+                pend = tree.prepare_root() if is_root else tree.select()
+                if is_root and not pend:
+                    continue                                   # kept (or terminal) root: MCTSCore did not evaluate it either
+                planes, lp1, lp2, lpm, val = calls[k]
+                k += 1
+                if not pend:
+                    continue                                   # terminal leaf: MCTSCore evaluated it, nobody reads the result
+                cs = tree.pending_state()
+                want_planes = O.states_to_model_input(O.batch_from_states([cs]))
+                assert np.array_equal(planes.reshape(1, 11, 6, 6), want_planes), f"game {i} call {k}: another leaf"
+                mask = np.zeros((1, 220), bool)
+                mask[0, O.legal_indices_py(cs)] = True
+                pri, _ = O.project_policy(lp1.reshape(1, 36), lp2.reshape(1, 36), lpm.reshape(1, 36), mask)
+                tree.complete(pri[0], val)
+                used += 1
+            assert k == len(calls), "MCTSCore made more evaluations than the oracle's search has steps"
+            return used
+
+        assert replay(list(log)) >= 30
+
+        def compare():
+            stats = core.get_root_children_stats()
+            idx, vis, vs, pr, pl = tree.root_children()
+            assert [s["action_index"] for s in stats] == idx.tolist()
+            assert [int(s["visit_count"]) for s in stats] == vis.tolist()
+            np.testing.assert_allclose([s["prior"] for s in stats], pr, atol=1e-6, rtol=0)
+            # value sums: MCTSCore reports them from the root mover's side, the oracle from the child mover's
+            rp = int(core._root.current_player.item())
+            want = [float(w) if int(p) == rp else -float(w) for w, p in zip(vs, pl)]
+            assert [s["value_sum"] for s in stats] == want
+            return stats
+
+        stats = compare()
+        assert core.root_visit_count == 40
+        # advance_root keeps the played child's subtree on both sides; the next search continues it
+        best = max(stats, key=lambda s: (s["visit_count"], -s["action_index"]))
+        core.advance_root(best["action_index"])
+        tree.advance(int(best["action_index"]))
+        del log[:]
+        core.run_simulations(24)
+        assert replay(list(log)) >= (0 if tree.root_terminal() else 10)
+        compare()
+
+
+def test_mcts_core_root_noise_is_fresh_for_every_root():
+    """the reference's generator is stateful (mcts_core.cpp:132,316) -- every set_root_state / advance_root
+    draws fresh Dirichlet noise.  Two consecutive set_root_state calls on the same position must not mix the same noise."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from liuzhou_amd import v0_core
+    from liuzhou_amd.net import ChessNet, MODEL_CONFIGS, bucket_logits_to_scalar
+    torch.manual_seed(7)
+    model = ChessNet(**MODEL_CONFIGS["tiny"]).eval().to(DEV)
+
+    def forward(x):
+        with torch.inference_mode():
+            lp1, lp2, lpm, raw = model(x.to(DEV))
+        return lp1, lp2, lpm, bucket_logits_to_scalar(raw)
+
+    st = states(load("g1_rules.npz"), "s")
+    cfg = v0_core.MCTSConfig()
+    cfg.device, cfg.num_simulations, cfg.add_dirichlet_noise, cfg.seed = DEV, 8, True, 4242
+    core = v0_core.MCTSCore(cfg)
+    core.set_forward_callback(forward)
+    priors = []
+    for _ in range(3):
+        core.set_root_state(_state_like(st, 10))
+        core.run_simulations(1)
+        priors.append([s["prior"] for s in core.get_root_children_stats()])
+    assert len(priors[0]) > 1
+    assert priors[0] != priors[1] and priors[1] != priors[2] and priors[0] != priors[2]
+    # a large simulation budget is refused with a clear message instead of an arena error deep inside the engine
+    big = v0_core.MCTSConfig()
+    big.device, big.num_simulations = DEV, 5000
+    core2 = v0_core.MCTSCore(big)
+    core2.set_forward_callback(forward)
+    with pytest.raises(ValueError, match="16384"):
+        core2.set_root_state(_state_like(st, 10))
