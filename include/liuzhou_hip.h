@@ -456,8 +456,11 @@ LZ_API int lz_root_collect(const void* root_states, const void* child_states, co
 /* AdvanceRoots (src/mcts.py:577-592, portable_mcts.py:74-87, portable_mcts.cpp:739-769): after the host has
  * played `played_action[g]` (220-d index, -1: none) and refreshed root_state, promote that child to root and keep
  * its subtree (compacted in place) with its statistics.  Games with reset[g] != 0, inactive games, children that
- * were never expanded, a child state different from root_state[g], or a kept subtree that leaves no room for
- * `next_sims` more simulations (counted in *dropped, device int32, may be NULL) start a fresh tree instead.
+ * were never expanded or a child state different from root_state[g] start a fresh tree instead.  The reference's tree
+ * is unbounded; here a kept subtree that would leave no room for `next_sims` more simulations in the game's arena is
+ * PRUNED to its oldest part that fits (a prefix in expansion order -- closed under "parent of"; edges whose child fell
+ * past the cut keep their statistics and are expanded afresh when visited).  `dropped`: device int32[2], may be NULL:
+ * [0] += subtrees forgotten whole (only if not even the first 64-node chunk fits), [1] += subtrees pruned.
  * Follow with lz_tree_search_continue (or lz_tree_expand(is_root=1) + the split-phase loop): kept roots are not
  * re-evaluated, they only get a fresh noise mix (portable_mcts.py:617-621). */
 LZ_API int lz_tree_advance(const LzTreeDesc* tree, const int32_t* played_action, const uint8_t* reset,

@@ -364,8 +364,13 @@ __global__ __launch_bounds__(kBlock) void tree_expand_wave_kernel(Tree t, WaveAr
 //   2. slide the kept nodes down to their rank (new id <= old id, chunk loads complete before chunk stores);
 //   3. slide the kept edges down (edge runs ascend with their owner's id, so compaction keeps every run
 //      contiguous), translating owner / child ids by rank and child edge offsets from the moved nodes.
-// A game whose child was never expanded, was re-seated, or whose kept subtree would not leave room for the next
-// search (`dropped` counts those) simply starts a fresh tree from root_state, exactly like lz_tree_begin.
+// A game whose child was never expanded or was re-seated simply starts a fresh tree from root_state, exactly like
+// lz_tree_begin.  A kept subtree that would not leave room for the next search in the game's arena (the reference's
+// tree is unbounded) is PRUNED, not dropped: marking stops at the first 64-node chunk that does not fit, so the oldest
+// part of the subtree -- a prefix in expansion order, which is closed under "parent of" and holds the root's and the
+// upper levels' statistics -- survives; edges whose child fell past the cut keep their visit count and value sum and
+// point to no node again (the next visit expands that position afresh).  `dropped[1]` counts pruned games, `dropped[0]`
+// the (now only defensive) whole-subtree drops.
 constexpr int kMarkWords = 256;        // subtree reuse supports node_cap <= 16384
 __device__ __forceinline__ int wave_sum_i32(int v) {
 #pragma unroll
@@ -424,6 +429,8 @@ __global__ __launch_bounds__(kBlock) void tree_advance_kernel(Tree t, const int*
     if (c > 0) {
         // ---- pass 1: marks + per-word prefix counts ----
         const int words = (nn + 63) >> 6;
+        const int node_budget = t.node_cap - reserve_nodes, edge_budget = t.edge_cap - reserve_edges;
+        bool cut = false;
         for (int w = 0; w < words; ++w) {
             const int id = w * kWave + lane;
             const bool valid = id < nn;
@@ -440,13 +447,25 @@ __global__ __launch_bounds__(kBlock) void tree_advance_kernel(Tree t, const int*
                 if (nb == bal) break;
                 bal = nb;
             }
+            const int chunk_nodes = __popcll(bal), chunk_edges = wave_sum_i32(kept ? (cnt > 0 ? cnt : 0) : 0);
+            if (kept_nodes + chunk_nodes > node_budget || kept_edges + chunk_edges > edge_budget) {
+                // no room for this chunk: the subtree is cut here (expansion order), the rest is forgotten
+                for (int r = w + lane; r < words; r += kWave) { mark[r] = 0ull; nprefix[r] = kept_nodes; eprefix[r] = kept_edges; }
+                cut = true;
+                break;
+            }
             if (lane == 0) { mark[w] = bal; nprefix[w] = kept_nodes; eprefix[w] = kept_edges; }
-            kept_nodes += __popcll(bal);
-            kept_edges += wave_sum_i32(kept ? cnt : 0);
+            kept_nodes += chunk_nodes;
+            kept_edges += chunk_edges;
         }
-        if (kept_nodes + reserve_nodes > t.node_cap || kept_edges + reserve_edges > t.edge_cap || words > kMarkWords) {
-            c = -1;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (words > kMarkWords || kept_nodes == 0) {             // defensive: nothing of the subtree fits (not reachable
+            c = -1;                                              // with arenas that hold one search plus its reserve)
             if (lane == 0 && dropped != nullptr) atomicAdd(dropped, 1);
+        } else if (cut && lane == 0 && dropped != nullptr) {
+            atomicAdd(dropped + 1, 1);
         }
     }
     if (c <= 0) {
@@ -488,9 +507,13 @@ __global__ __launch_bounds__(kBlock) void tree_advance_kernel(Tree t, const int*
         if (kept) {
             rec.owner = (uint16_t)rank_of(rec.owner);
             if (rec.child >= 0) {
-                const int nc = rank_of(rec.child);
-                rec.child = nc;
-                rec.cbegin = nodes[nc].edge_begin;
+                if ((mark[rec.child >> 6] >> (rec.child & 63)) & 1ull) {
+                    const int nc = rank_of(rec.child);
+                    rec.child = nc;
+                    rec.cbegin = nodes[nc].edge_begin;
+                } else {                                         // the child fell past the cut of a pruned subtree
+                    rec.child = -1; rec.cbegin = 0; rec.cn = 0;
+                }
             }
             edges[run + __popcll(bal & lt)] = rec;
         }

@@ -144,7 +144,7 @@ class TreeEngine:
         self.child_action = z((B, OUT_CAP), torch.int32)
         self.child_visits = z((B, OUT_CAP), torch.int32)
         self.child_prior = z((B, OUT_CAP), torch.float32)
-        self.reuse_dropped = z((1,), torch.int32)
+        self.reuse_dropped = z((2,), torch.int32)      # [0] kept subtrees dropped whole (defensive), [1] pruned to fit
         self.eval_count = z((B,), torch.int32)          # evaluations the games' expand steps consumed (LzTreeDesc.eval_count)
         self.desc.eval_count = self.eval_count.data_ptr()
         # persistent search kernel (lz_tree_search_persistent, one launch per move): built, parity-tested and MEASURED
@@ -839,7 +839,8 @@ class SteadyStateTreeSelfPlay:
     def prepare(self) -> None:
         """Kernel loading and graph capture before anything is timed (the searches run here are discarded)."""
         self.mcts.prepare(self.pop.states)
-        self.mcts.engine.reuse_dropped.zero_() if hasattr(self.mcts, "engine") else [p.engine.reuse_dropped.zero_() for p in self.mcts.parts]
+        for e in ([self.mcts.engine] if hasattr(self.mcts, "engine") else [p.engine for p in self.mcts.parts]):
+            e.reuse_dropped.zero_()
         torch.cuda.synchronize(self.dev)
 
     def step(self) -> None:

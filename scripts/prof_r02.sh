@@ -21,4 +21,4 @@ for shape in "b10c128 16384 full" "b6c64 4096 full" "b6c64 2048 half"; do
   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_write_$name" -- python3 "$ROOT/scripts/prof_net_once.py" $1 $2 $3 > "$OUT/pmc_write_$name.log" 2>&1
   echo "pmc $name done"
 done
-find "$OUT" -name "*.csv" | wc -l
+find "$OUT" -name "*.csv" | wc -l; du -sh "$OUT"

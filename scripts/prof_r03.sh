@@ -30,4 +30,10 @@ for d in sorted(glob.glob("$OUT/sq*_*/")):
     for c, v in sorted(acc.items()):
         print("   %-60s %-32s mean %.5g over %d launches" % (c[0], c[1], sum(v) / len(v), len(v)))
 PY
-find "$OUT" -name "*.csv" | wc -l
+# summaries are made HERE (gpurun copies back at most 64 MiB of gpurun_out/): tracked files land in profiles/ of this
+# copy of the repo and are mirrored under $OUT/summary; raw traces above 2 MiB are dropped afterwards
+python3 "$ROOT/scripts/summarize_profiles_r02.py" r03 > "$OUT/summary.log" 2>&1 || tail -5 "$OUT/summary.log"
+python3 "$ROOT/scripts/summarize_profiles_r03.py" > "$OUT/summary_r03.log" 2>&1 || tail -5 "$OUT/summary_r03.log"
+mkdir -p "$OUT/summary" && cp "$ROOT"/profiles/r03_* "$ROOT/profiles/traffic.json" "$OUT/summary/" 2>/dev/null
+find "$OUT" -type f -size +2M -delete
+find "$OUT" -name "*.csv" | wc -l; du -sh "$OUT"

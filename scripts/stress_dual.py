@@ -34,6 +34,6 @@ for mv in range(40):
         for t, f in zip(st.tensors(), fresh.tensors()):
             t.index_copy_(0, fin, f)
         plies.index_fill_(0, fin, 0); done.index_fill_(0, fin, False); reset.index_fill_(0, fin, 1)
-print("moves with a difference:", bad, "| dropped subtrees:", int(single.engine.reuse_dropped.item()),
-      [int(p.engine.reuse_dropped.item()) for p in dual.parts])
+print("moves with a difference:", bad, "| dropped subtrees:", int(single.engine.reuse_dropped[0].item()),
+      [int(p.engine.reuse_dropped[0].item()) for p in dual.parts])
 assert bad == 0

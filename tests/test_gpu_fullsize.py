@@ -98,7 +98,7 @@ def _checked_step(pop, sims, first_move):
 
 
 def _dropped(pop):
-    return sum(int(e.reuse_dropped.item()) for e in _engines(pop))
+    return [sum(int(e.reuse_dropped[k].item()) for e in _engines(pop)) for k in (0, 1)]
 
 
 def test_c2_full_size_three_moves_and_same_seed_same_games():
@@ -113,7 +113,7 @@ def test_c2_full_size_three_moves_and_same_seed_same_games():
         steps = [_checked_step(pop, 200, first_move=(k == 0)) for k in range(3)]
         kept_any = any(int((e.buf["root_visits"] > 200).sum()) > 0 for e in _engines(pop))
         assert kept_any, "no game kept a subtree over three moves"
-        print(f"C2 full size: dropped subtrees {_dropped(pop)}")
+        print(f"C2 full size: [dropped, pruned] subtrees {_dropped(pop)}")
         runs.append(steps)
         del pop
         torch.cuda.empty_cache()
@@ -137,4 +137,4 @@ def test_c3_full_size_one_move_and_one_continued_move():
     e = _engines(pop)[0]
     assert int((e.buf["root_visits"] > 800).sum()) > 0, "no game continued a kept subtree"
     assert not pop.mcts.graph_retry_off
-    print(f"C3 full size: arena factor {e.reuse_factor}, dropped subtrees {_dropped(pop)}")
+    print(f"C3 full size: arena factor {e.reuse_factor}, [dropped, pruned] subtrees {_dropped(pop)}")

@@ -185,7 +185,7 @@ def test_tree_reuse_falls_back_to_fresh_roots():
         fresh_expected = np.zeros(B, bool); fresh_expected[::4] = True; fresh_expected[1::4] = True; fresh_expected[2::4] = True
         assert not np.any(kind[fresh_expected] == 3)
         rest = ~fresh_expected & ~term
-        dropped = int(eng.reuse_dropped.item())
+        dropped = int(eng.reuse_dropped[0].item())
         if expect_drop:
             assert dropped > 0 and not np.any(kind == 3)
         else:
@@ -195,6 +195,91 @@ def test_tree_reuse_falls_back_to_fresh_roots():
         vis = eng.child_visits.cpu().numpy(); cnt = eng.child_count.cpu().numpy()
         for g in np.nonzero(kind == 1)[0]:
             assert int(vis[g, :cnt[g]].sum()) == sims
+
+
+def test_advance_prunes_a_subtree_that_does_not_fit_instead_of_dropping_it():
+    """The reference's tree is unbounded; ours lives in a per-game arena.  A kept subtree that would leave no room for the
+    next search is cut to its oldest part (expansion order): the arena stays structurally sound, the new root's own
+    statistics are exactly the played child's, `pruned` counts the games, nothing is dropped whole, and the next search
+    adds exactly `sims` visits."""
+    _need_gpu()
+    from liuzhou_amd.tree_engine import TreeEngine
+    from tests.tree_parity import hash_evaluator, unpack_packed, EDGE_DT, NODE_DT
+    from oracle import lz_oracle as O
+    z = load("g1_rules.npz")
+    st = states(z, "s")
+    idx = np.random.default_rng(11).integers(0, st["board"].shape[0], 24)
+    cur = {f: np.ascontiguousarray(np.asarray(st[f])[idx]) for f in FIELDS}
+    B, sims = 24, 320
+    eng = TreeEngine(B, sims, DEV, 1.0, reuse_factor=0.3)         # room for 96 kept nodes: most kept subtrees are larger
+    node_budget, edge_budget = eng.node_cap - (sims + 1), eng.edge_cap - (sims + 1) * 72
+
+    def search(first):
+        for s in range(sims + 1):
+            if s:
+                eng.select()
+            leaf = unpack_packed(eng.buf["leaf_state"].cpu().numpy())
+            pri, val = hash_evaluator(leaf)
+            eng.expand(is_root=(s == 0), values=torch.from_numpy(val).to(DEV), priors220=torch.from_numpy(pri).to(DEV))
+        eng.finish(torch.full((B,), 0.1, device=DEV), None)
+
+    def arena(g):
+        nn, ne = int(eng.buf["n_nodes"][g]), int(eng.buf["n_edges"][g])
+        nodes = eng.buf["nodes"].view(B, eng.node_cap, 6)[g, :nn].contiguous().cpu().numpy().view(NODE_DT).reshape(nn)
+        edges = eng.buf["edges"].view(B, eng.edge_cap, 4)[g, :ne].contiguous().cpu().numpy().view(EDGE_DT).reshape(ne)
+        return nodes, edges
+
+    eng.set_roots(to_gpu_batch(cur, DEV)); eng.begin(); search(True)
+    pruned_total = 0
+    for move in range(3):
+        chosen = eng.chosen_index.cpu().numpy()
+        term = eng.terminal_mask.cpu().numpy()
+        before = [arena(g) for g in range(B)]
+        nxt = [O.state_from_batch(cur, i) if term[i] else O.apply_index(O.state_from_batch(cur, i), int(chosen[i]))
+               for i in range(B)]
+        cur = O.batch_from_states(nxt)
+        eng.set_roots(to_gpu_batch(cur, DEV))
+        eng.advance()
+        kind = eng.buf["leaf_kind"].cpu().numpy()
+        for g in range(B):
+            nodes, edges = arena(g)
+            if kind[g] != 3:
+                continue
+            assert nodes.size <= node_budget and edges.size <= edge_budget
+            # structure: runs inside the arena, owners / parents / child links consistent, ids ascend from parent to child
+            for i, nd in enumerate(nodes):
+                e0, n = int(nd["edge_begin"]), int(nd["nedges"])
+                assert n >= 1 and e0 >= 0 and e0 + n <= edges.size
+                assert (edges["owner"][e0:e0 + n] == i).all()
+                assert int(nd["parent"]) == (-1 if i == 0 else int(nd["parent"])) and int(nd["parent"]) < i
+                for e in edges[e0:e0 + n]:
+                    c = int(e["child"])
+                    if c >= 0:
+                        assert i < c < nodes.size and int(nodes[c]["parent"]) == i
+                        assert int(e["cbegin"]) == int(nodes[c]["edge_begin"]) and int(e["cn"]) == int(nodes[c]["nedges"])
+            # the new root's own statistics are the played child's, bit for bit (action, N | info, W, P)
+            onodes, oedges = before[g]
+            r0 = onodes[0]
+            run = oedges[int(r0["edge_begin"]):int(r0["edge_begin"]) + int(r0["nedges"])]
+            ce = run[run["act"] == chosen[g]][0]
+            oc = onodes[int(ce["child"])]
+            want = oedges[int(oc["edge_begin"]):int(oc["edge_begin"]) + int(oc["nedges"])]
+            got = edges[int(nodes[0]["edge_begin"]):int(nodes[0]["edge_begin"]) + int(nodes[0]["nedges"])]
+            for f in ("act", "n_info", "W", "P"):
+                assert got[f].tobytes() == want[f].tobytes(), (move, g, f)
+            assert int(eng.buf["root_visits"][g]) == int(ce["n_info"] & 0xFFFFFF)
+        dropped, pruned = eng.reuse_dropped.tolist()
+        assert dropped == 0
+        pruned_total = pruned
+        rv0 = eng.buf["root_visits"].cpu().numpy().copy()
+        search(False)
+        rv1 = eng.buf["root_visits"].cpu().numpy()
+        live = ~eng.terminal_mask.cpu().numpy()
+        assert ((rv1 - rv0)[live & (kind == 3)] == sims).all()
+        vis = eng.child_visits.cpu().numpy(); cnt = eng.child_count.cpu().numpy()
+        for g in np.nonzero(live & (kind == 1))[0]:
+            assert int(vis[g, :cnt[g]].sum()) == sims
+    assert pruned_total > 0, "no subtree was pruned: the test did not exercise the cut"
 
 
 def test_tree_finish_policy_target_options_and_uniform_openings():
@@ -264,7 +349,7 @@ def test_fused_search_with_subtree_reuse_accumulates_visits():
                                           for g in range(B)])
             v0_core.self_play_step_inplace(*cur.tensors(), plies, done, all_idx, out.chosen_action_codes,
                                            out.terminal_mask, out.chosen_valid_mask, 512, 2.0)
-        assert int(mcts.engine.reuse_dropped.item()) == 0
+        assert mcts.engine.reuse_dropped.tolist() == [0, 0]
         assert prev_child_visits.max() > 1
 
 

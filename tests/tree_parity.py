@@ -223,7 +223,7 @@ def run_injected_reuse_parity(device, num_games=48, sims=48, moves=4, seed=3, c=
             cur[i] = O.apply_index(cur[i], pick)
             if not t.advance(pick):
                 trees[i] = O.OracleTree(cur[i], c)
-    assert int(eng.reuse_dropped.item()) == 0
+    assert eng.reuse_dropped.tolist() == [0, 0]
     return eng, kept_total
 
 
@@ -329,7 +329,7 @@ def run_injected_wave_parity(device, num_games=48, sims=50, batch_k=16, moves=3,
             cur[i] = O.apply_index(cur[i], pick)
             if not t.advance(pick):
                 trees[i] = O.OracleTree(cur[i], c)
-    assert int(eng.reuse_dropped.item()) == 0
+    assert eng.reuse_dropped.tolist() == [0, 0]
     return eng, waves_total, short_waves
 
 
@@ -479,7 +479,7 @@ def run_production_parity(device, model_name="b6c64", num_games=128, sims=200, m
             for k in ("evals", "kept"):
                 totals[k] += st[k]
             totals["max_prior_err"] = max(totals["max_prior_err"], st["max_prior_err"])
-            assert int(part.engine.reuse_dropped.item()) == 0
+            assert part.engine.reuse_dropped.tolist() == [0, 0]
             u = part._uniforms.cpu().numpy()
             for i in range(a, b):
                 t = trees[i]
