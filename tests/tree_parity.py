@@ -439,7 +439,9 @@ def run_production_parity(device, model_name="b6c64", num_games=128, sims=200, m
     from tests.golden_utils import load, states as gstates
     dev = torch.device(device)
     torch.manual_seed(20260314)
-    net = FusedNet(ChessNet(**MODEL_CONFIGS[model_name]).eval().to(dev))
+    module = ChessNet(**MODEL_CONFIGS[model_name]).eval().to(dev)
+    net = FusedNet(module)
+    net32 = FusedNet(module, precision="fp32")       # an independent kernel (fp32 operands, <= 1e-5 of the reference's module)
     if states is None:
         z = load("g1_rules.npz")
         st_all = gstates(z, "s")
@@ -464,6 +466,14 @@ def run_production_parity(device, model_name="b6c64", num_games=128, sims=200, m
             d = max(float(np.abs(got - heads).max()), float(np.abs(v.cpu().numpy() - values).max()))
             totals["net_max_err"] = max(totals["net_max_err"], d)
             assert d <= 1e-6, f"step {s}: network rows inside the captured search differ from a direct launch by {d}"
+            # ... and not only with itself: the fp32-operand kernel (lz_net_f32.hip, pinned to the reference's own outputs
+            # by g9) evaluates the same states -- fp16 rounding only (observed 9.4e-5 on log-probs, 2e-6 on values)
+            q1, q2, qm, _, qv = net32.forward_packed(torch.from_numpy(np.ascontiguousarray(packed)).to(dev))
+            ref = torch.cat([q1, q2, qm], dim=1).cpu().numpy()
+            live = ref > -12.0
+            d32 = max(float(np.abs(heads - ref)[live].max()), float(np.abs(qv.cpu().numpy() - values).max()) * 10.0)
+            totals["net_fp32_err"] = max(totals.get("net_fp32_err", 0.0), d32)
+            assert d32 <= 1e-3, f"step {s}: network rows inside the captured search are {d32} away from the fp32 kernel"
         return check
 
     for mv in range(moves):
