@@ -45,7 +45,8 @@ class _Stepper:
     def reset(self) -> None:
         # loss, policy*w, value, bucket, aux, seen, wsum, valid, |soft|
         self.acc = torch.zeros(9, dtype=torch.float64, device=self.dev)
-        self.mix_abs_sum, self.batches, self.skip_loss, self.skip_grad = 0.0, 0, 0, 0
+        self.mix_abs_dev = torch.zeros((), dtype=torch.float64, device=self.dev)
+        self.batches, self.skip_loss, self.skip_grad = 0, 0, 0
 
     def step(self, b_states, b_masks, b_policy, b_values, b_soft) -> bool:
         opt, scaler, dev = self.optimizer, self.scaler, self.dev
@@ -55,16 +56,24 @@ class _Stepper:
         loss, parts = fused_policy_value_loss(lp1, lp2, lpm, vlogits, b_masks, b_policy, b_values, b_soft,
                                               soft_label_alpha=self.alpha, anti_draw_penalty=self.anti_draw,
                                               policy_draw_weight=self.draw_w)
-        if not _all_ranks_true(bool(torch.isfinite(loss).item()), self.ddp, dev):
+        # ONE host read per step for both finite checks of the reference (train_bridge.py:388-420 reads the loss flag and
+        # then one flag per parameter tensor: ~130 device round trips per step).  The backward runs before the read; a
+        # non-finite loss makes non-finite gradients, which are thrown away below exactly as if backward had not run
+        # (no unscale_, no scaler.update(): the scaler never saw the step).  Finiteness is the same before and after
+        # unscale_ (a division by the finite scale), so the gradient flag is taken on the scaled gradients.
+        if scaler is not None:
+            scaler.scale(loss).backward()
+        else:
+            loss.backward()
+        grads = [p.grad for p in self.model.parameters() if p.grad is not None]
+        g_ok = torch.stack([torch.isfinite(g).all() for g in grads]).all() if grads else torch.ones((), dtype=torch.bool, device=dev)
+        loss_ok, grads_ok = (bool(v) for v in torch.stack([torch.isfinite(loss.detach()).all(), g_ok]).tolist())
+        if not _all_ranks_true(loss_ok, self.ddp, dev):
             self.skip_loss += 1
             opt.zero_grad(set_to_none=True)
             return False
         if scaler is not None:
-            scaler.scale(loss).backward()
             scaler.unscale_(opt)
-        else:
-            loss.backward()
-        grads_ok = all(p.grad is None or bool(torch.isfinite(p.grad).all().item()) for p in self.model.parameters())
         if not _all_ranks_true(grads_ok, self.ddp, dev):
             self.skip_grad += 1
             opt.zero_grad(set_to_none=True)
@@ -88,14 +97,14 @@ class _Stepper:
                                  parts["bucket_value_loss"] * cnt, parts["wdl_aux_loss"] * cnt,
                                  torch.tensor(cnt, device=dev), wsum, (b_policy.sum(dim=1) > 1e-8).sum(),
                                  b_soft.abs().mean()]).to(torch.float64)
-        self.mix_abs_sum += float(mixed.abs().mean().item())
+        self.mix_abs_dev += mixed.abs().mean().to(torch.float64)        # summed on the device, read once per epoch
         self.batches += 1
         return True
 
     def epoch_stats(self, epoch: int, extra: Dict[str, Any], more_sums: Optional[List[float]] = None):
-        red = torch.cat([self.acc, torch.tensor([self.mix_abs_sum, float(self.batches), float(self.skip_loss),
-                                                 float(self.skip_grad)] + list(more_sums or []),
-                                                dtype=torch.float64, device=self.dev)])
+        red = torch.cat([self.acc, self.mix_abs_dev.view(1),
+                         torch.tensor([float(self.batches), float(self.skip_loss), float(self.skip_grad)] + list(more_sums or []),
+                                      dtype=torch.float64, device=self.dev)])
         if self.ddp:
             dist.all_reduce(red, op=dist.ReduceOp.SUM)
         r = red.tolist()
