@@ -40,6 +40,7 @@ class _Stepper:
         self.model, self.train_model, self.optimizer, self.scheduler, self.scaler = model, train_model, optimizer, scheduler, scaler
         self.amp, self.alpha, self.anti_draw, self.draw_w = amp, alpha, anti_draw, draw_w
         self.clip, self.ddp, self.dev = float(grad_clip_norm), ddp, dev
+        self._nominal_rows: Optional[int] = None
         self.reset()
 
     def reset(self) -> None:
@@ -48,7 +49,24 @@ class _Stepper:
         self.mix_abs_dev = torch.zeros((), dtype=torch.float64, device=self.dev)
         self.batches, self.skip_loss, self.skip_grad = 0, 0, 0
 
+    def _conv_mode(self, rows: int):
+        """MIOpen searches for convolution kernels the first time it sees a shape: 12 - 20 s for the nominal batch of this
+        network (once per process) and 2 - 11 s for EVERY new last-batch size -- and an iteration of the staged loop has a
+        different sample count, hence a different remainder, every time (measured: `profiles/r03_train.md`).  Immediate
+        mode (`torch.backends.miopen.immediate`) picks a kernel without searching: same samples/s for 10x128, 11 % lower
+        for 6x64.  LZ_TRAIN_MIOPEN = auto (default: the nominal batch size searches once, any other size runs immediate),
+        immediate (never search) or find (PyTorch's default behaviour)."""
+        mode = os.environ.get("LZ_TRAIN_MIOPEN", "auto").strip().lower()
+        if self._nominal_rows is None:
+            self._nominal_rows = int(rows)
+        imm = mode == "immediate" or (mode == "auto" and int(rows) != self._nominal_rows)
+        return torch.backends.miopen.flags(immediate=True) if (imm and hasattr(torch.backends, "miopen")) else nullcontext()
+
     def step(self, b_states, b_masks, b_policy, b_values, b_soft) -> bool:
+        with self._conv_mode(int(b_states.shape[0])):
+            return self._step(b_states, b_masks, b_policy, b_values, b_soft)
+
+    def _step(self, b_states, b_masks, b_policy, b_values, b_soft) -> bool:
         opt, scaler, dev = self.optimizer, self.scaler, self.dev
         opt.zero_grad(set_to_none=True)
         with (torch.amp.autocast("cuda", enabled=True) if self.amp else nullcontext()):
@@ -222,6 +240,7 @@ def train_network_from_tensors(model, samples: TensorSelfPlayBatch, *, batch_siz
     stepper = _Stepper(model, train_model, optimizer, scheduler, scaler, amp=amp, alpha=alpha,
                        anti_draw=float(anti_draw_penalty), draw_w=draw_w, grad_clip_norm=grad_clip_norm,
                        ddp=strategy == "ddp", dev=dev)
+    stepper._nominal_rows = bsz                       # the one batch size worth a MIOpen kernel search (see _conv_mode)
     for epoch in range(n_epochs):
         perm = torch.randperm(n, device=dev)
         stepper.reset()
@@ -290,6 +309,7 @@ def train_network_streaming(model, dataloader, *, total_samples: int, batch_size
     stepper = _Stepper(model, train_model, optimizer, scheduler, scaler, amp=amp, alpha=alpha,
                        anti_draw=float(anti_draw_penalty), draw_w=float(max(0.0, policy_draw_weight)),
                        grad_clip_norm=grad_clip_norm, ddp=strategy == "ddp", dev=dev)
+    stepper._nominal_rows = bsz                       # the one batch size worth a MIOpen kernel search (see _conv_mode)
     epoch_stats: List[Dict[str, Any]] = []
     first_batch_sec, first_done = 0.0, False
     total_filtered, seen_all = 0, 0
