@@ -127,6 +127,9 @@ def test_c3_full_size_one_move_and_one_continued_move():
     one fresh move and one move that continues the kept subtrees, arenas sized from free memory as in bench.py."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()                                    # give back what earlier tests' allocations left cached
     free, _ = torch.cuda.mem_get_info(torch.device(DEV))
     if free < 150 * (1 << 30):
         pytest.skip("C3's tree arenas need most of a 288 GB device")
@@ -138,3 +141,6 @@ def test_c3_full_size_one_move_and_one_continued_move():
     assert int((e.buf["root_visits"] > 800).sum()) > 0, "no game continued a kept subtree"
     assert not pop.mcts.graph_retry_off
     print(f"C3 full size: arena factor {e.reuse_factor}, [dropped, pruned] subtrees {_dropped(pop)}")
+    del pop, e
+    gc.collect()
+    torch.cuda.empty_cache()
