@@ -44,8 +44,9 @@ struct SearchArgs {
     int* cu_slots;              // [kCuSlots] zeroed before the launch, or nullptr (no stagger)
     int stagger_ticks;          // delay of a CU's second workgroup, in 100 MHz ticks
     long long* phase_ticks;     // optional [grid][4]: 100 MHz ticks wave 0 spent in network passes / tree steps, CU slot, CU key
-    int exp_mode;               // timing experiments only (wrong results): 1 = no tree step, 2 = sleep instead of the tree step,
-                                // 3 = tree step at normal wave priority; 0 in production
+    int exp_mode;               // timing experiments (builds with -DLZ_EXP_SEARCH_MODES only; bit flags): 1 = no tree step and
+                                // 2 = sleep instead of it (WRONG results), 4 = tree step at normal wave priority, 8 = priority
+                                // edge alternating between the CU's two workgroups, 16 = younger workgroup favoured; 0 otherwise
 };
 
 template <int C, int S, int W>
@@ -183,7 +184,11 @@ int lz_tree_search_persistent(const LzTreeDesc* d, const LzNetDesc* net, int64_t
     a.cu_slots = cu_slots;
     a.stagger_ticks = (int)(stagger_us * 100);
     a.phase_ticks = reinterpret_cast<long long*>(phase_ticks);
+    a.exp_mode = 0;
+#ifdef LZ_EXP_SEARCH_MODES  /* experiment builds only (scripts/exp_persistent.py, profiles/r03_experiments.md): modes that skip
+                             * or replace the tree step give WRONG results and must not be reachable in the shipped library */
     a.exp_mode = getenv("LZ_EXP_SEARCH_MODE") ? atoi(getenv("LZ_EXP_SEARCH_MODE")) : 0;
+#endif
     using K = Cfg<64, 8, 4>;
     const unsigned grid = (unsigned)((B + 8 - 1) / 8);
     (void)lz_prof_mark_begin(stream);

@@ -2,6 +2,9 @@
 
     python scripts/exp_persistent.py [games] [sims] [steps] [model]
 
+The `stagger:mode` settings (timing modes that skip / replace the tree step) need an experiment build of the library:
+    hipcc ... -DLZ_EXP_SEARCH_MODES -o /tmp/libexp.so ...   and   LZ_HIP_LIB=/tmp/libexp.so python scripts/exp_persistent.py
+(the shipped library ignores LZ_EXP_SEARCH_MODE).
 For each setting (LZ_TREE_PERSISTENT off = two streams of per-simulation launches; on with several staggers) the
 steady-state self-play harness runs `steps` timed steps after a 2 s soak; with the persistent kernel the in-kernel
 phase clocks (100 MHz ticks per workgroup in network passes / tree steps) of the last search are printed too."""
