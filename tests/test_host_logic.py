@@ -134,3 +134,46 @@ def test_trajectory_buffer_device_cursor_bookkeeping():
     assert rows.tolist() == [5, 6] and int(cur.item()) == 7
     out = buf.build()
     assert out.num_samples == 7 and float(out.value_targets[0]) == 0.25
+
+
+def test_bench_clock_sampler_reads_sysfs_in_process(tmp_path, monkeypatch):
+    """the power / clock sampler of bench.py must not start child processes (a `rocm-smi` child runs an
+    `env` hop under a profiler's preload).  It reads the device's hwmon nodes in-process, and is off under a profiler."""
+    import importlib.util
+    import subprocess
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("lz_bench", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    hw = tmp_path / "hwmon" / "hwmon3"
+    hw.mkdir(parents=True)
+    (hw / "power1_input").write_text("1341000000\n")          # microwatts
+    (hw / "freq1_input").write_text("1919000000\n")           # Hz
+
+    def no_children(*a, **k):
+        raise AssertionError("the sampler started a child process")
+    monkeypatch.setattr(subprocess, "run", no_children)
+    monkeypatch.setattr(subprocess, "Popen", no_children)
+    s = bench.ClockSampler("0000:00:00.0", period=0.01, sysfs_base=str(tmp_path))
+    assert s.available and "power1_input" in s.source and "freq1_input" in s.source
+    t0 = time.perf_counter()
+    s.start()
+    time.sleep(0.1)
+    out = s.stop(t0, time.perf_counter())
+    assert out["samples_in_timed_region"] >= 2 and out["failed_samples"] == 0
+    assert out["power_w_mean"] == 1341.0 and out["sclk_mhz_mean"] == 1919.0
+    # pp_dpm_sclk fallback (no freq1_input): the starred level
+    (hw / "freq1_input").unlink()
+    (tmp_path / "pp_dpm_sclk").write_text("0: 132Mhz\n1: 2100Mhz *\n")
+    s2 = bench.ClockSampler("0000:00:00.0", period=0.01, sysfs_base=str(tmp_path))
+    s2._once()
+    assert s2.samples and s2.samples[-1][2] == 2100.0
+    # nothing to read: unavailable, never raises
+    s3 = bench.ClockSampler("0000:00:00.0", sysfs_base=str(tmp_path / "missing"))
+    assert isinstance(s3.available, bool)
+    for var in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES"):
+        monkeypatch.setenv(var, "/opt/rocm/lib/librocprofiler-sdk-tool.so")
+        assert bench._under_profiler()
+        monkeypatch.delenv(var)
+    assert not bench._under_profiler() or any("rocprof" in os.environ.get(k, "").lower() for k in os.environ)
