@@ -7,7 +7,8 @@ v1/python/portable_mcts.py:123-138,418-506 visit accounting; self_play_gpu_runne
 
   * every non-terminal root ends a move with exactly `sims` new visits: sum of its children's visits == root visits for a
     fresh root, == root visits - 1 for a kept root (its own expansion visit), and root visits >= sims;
-  * no overflow / not-representable counter fired; dropped subtrees are reported;
+  * no overflow counter fired, every row fits the exact 360-byte record of the C4 gather (not-representable counter 0, round
+    trip bit-exact); dropped / pruned subtrees are reported;
   * trajectory rows are well formed: model input == the operator's encoding of the state that was searched, legal mask ==
     lz_encode_actions_fast of it, the policy target is a distribution on the legal set;
   * the same seed plays the same moves again (bit-identical picks and policies).
@@ -94,6 +95,15 @@ def _checked_step(pop, sims, first_move):
     assert torch.equal(a_sign[rows].to(torch.int64), before.current_player.to(torch.int64))
     if p.tail is not None:
         p.tail.check_overflow()
+    # the wire format of the C4 gather holds every row of the step exactly (`not representable` counter == 0)
+    from liuzhou_amd.trajectory_buffer import TensorSelfPlayBatch
+    from liuzhou_amd.trajectory_codec import pack_batch, unpack_records
+    mine = TensorSelfPlayBatch(a_state[rows], a_legal[rows], a_policy[rows], a_value[rows], a_soft[rows])
+    rec, bad = pack_batch(mine, return_bad=True)
+    assert int(bad.item()) == 0, "rows the 360-byte record cannot represent"
+    back = unpack_records(rec)
+    assert torch.equal(back.state_tensors, mine.state_tensors) and torch.equal(back.legal_masks, mine.legal_masks)
+    assert torch.equal(back.policy_targets, mine.policy_targets)
     return np.concatenate(chosen), pol.clone()
 
 
