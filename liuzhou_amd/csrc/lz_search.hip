@@ -79,6 +79,10 @@ __global__ __launch_bounds__(W * 64, 2) void tree_search_persistent_kernel(NetPa
         net_pass<C, S, W>(P, lds, ctx, nullptr, reinterpret_cast<const uint64_t*>(t.leaf_state), (int64_t)g0, nvalid, lp1,
                           lp2, lpm, nullptr, values);
         __syncthreads();                                       // head rows / values of all S games are visible
+        // Unlike the per-step kernels (whose L1 starts empty at every launch), this kernel reads edge records in the selection
+        // of simulation s that its own device atomics update in the backup of simulation s + 1.  The atomics execute at L2;
+        // an agent-scope acquire drops whatever copy of those lines the CU's L1 may still hold from the previous simulation.
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         const uint64_t c1 = a.phase_ticks != nullptr ? wall_clock64() : 0;
         // ---- tree step of the games this wave owns ----
         if (!(a.exp_mode & 4)) __builtin_amdgcn_s_setprio(3);   // short bursts between dependent loads go first
