@@ -298,27 +298,36 @@ LZ_API int lz_prof_net_busy(double* busy_ms);
 /* Replaces the reference's portable full-tree search and its split-phase C++ twin:
  *   v1/python/portable_mcts.py:264-746 (PortableMCTS.search_batch) == src/mcts.py:280-548 with batch_K=1,
  *   v1/cpp/portable_mcts.cpp:448-979 (PrepareRoots / SelectLeaves / CompletePending / AdvanceRoots).
- * All buffers are caller-allocated device memory; per game g the regions are
- *   nodes  [g*node_cap  .. +node_cap)   node_cap >= sims + 2
- *   edges  [g*edge_cap  .. +edge_cap)   edge_cap >= (sims + 1) * 72   (worst case, no overflow path)
- *   path   [g*path_cap  .. +path_cap)   path_cap >= node_cap + 1
- * With subtree reuse (lz_tree_advance) the arenas additionally hold the kept subtree: size them
- * (reuse_factor * sims + 2) nodes (<= 16384) and proportionally more edges; a kept subtree that would not leave
- * room for the next search is dropped (fresh root) and counted.
+ * All buffers are caller-allocated device memory.  Per game g:
+ *   nodes  [g*node_cap  .. +node_cap)   node_cap >= sims + 2 (+ the kept subtree with lz_tree_advance), <= 65536
+ *   path   [g*path_cap  .. +path_cap)   path_cap >= 3; a descent stops at path_cap - 1 levels (a game lasts <= 144
+ *                                       plies, so 160 entries hold every reachable path)
+ * Per engine: ONE edge pool `edges` of pool_chunks x edge_chunk 32-byte records, handed to the games in chunks
+ * (round 4; it replaces per-game regions of (sims + 1) * 72 edges, the worst case no game ever reaches):
+ *   chunk_list [g*chunk_cap .. +chunk_cap)  ids of the chunks game g owns, in the order it took them; n_chunks[g]
+ *   free_chunks[pool_chunks], pool_top[1]   stack of free chunk ids and its height; the caller initialises them to
+ *                                           0 .. pool_chunks-1 and pool_chunks, n_chunks / n_edges to 0
+ *   pool_stats[2]   [0] += expansions refused because no chunk was free (the leaf stays unexpanded, its value is still
+ *                   backed up, the next visit tries again -- results then differ from an unbounded tree, so size the
+ *                   pool so that this stays 0); [1] = min(free chunks seen) (initialise to pool_chunks)
+ * Every edge index in a record or hand-off array (node edge_begin, edge cbegin, path, leaf_edge) is an index into the
+ * pool; (pool_chunks + 1) * edge_chunk <= 2^31.  chunk_cap * (edge_chunk - 71) >= node_cap * 72 makes the node arena the
+ * only per-game bound (required by lz_tree_advance).  A kept subtree that would not leave room for the next search in
+ * the NODE arena is pruned and counted (lz_tree_advance).
  * States are 32-byte packed bitboard records (lz_pack_states). */
 typedef struct LzTreeDesc {
     int64_t num_games;
-    int32_t node_cap, edge_cap, path_cap, reserved;
+    int32_t node_cap, edge_chunk /* edges per chunk: power of two >= 128 */, path_cap, chunk_cap;
     double  exploration_weight;
     const void* root_state;        /* packed [B]: current game states (input of lz_tree_begin) */
     void*    nodes;                /* [B*node_cap] 48-byte records {packed state, int32 edge_begin, int32 nedges (-1 =
                                       not expanded), int32 parent node (-1 root), 4 B pad} */
-    void*    edges;                /* [B*edge_cap] 32-byte records {double W (value sum, child mover's view), float P,
-                                      uint32 N | info<<24, int32 child node or -1, int32 child edge_begin, uint8 action,
-                                      uint8 child nedges, uint16 owner node, 4 B pad};
+    void*    edges;                /* [pool_chunks*edge_chunk] 32-byte records {double W (value sum, child mover's view),
+                                      float P, uint32 N | info<<24, int32 child node or -1, int32 child edge_begin (pool
+                                      index), uint8 action, uint8 child nedges, 6 B pad};
                                       info: bit0 child mover white, bit1 terminal, bits2-3 terminal value + 1 */
     int32_t* n_nodes;              /* [B] */
-    int32_t* n_edges;              /* [B] */
+    int32_t* n_edges;              /* [B] next free pool index in the game's open chunk (multiple of edge_chunk: none) */
     int32_t* root_visits;          /* [B] */
     double*  root_w;               /* [B] */
     float*   root_init_value;      /* [B] */
@@ -343,6 +352,12 @@ typedef struct LzTreeDesc {
     int64_t  trace_cap;
     int32_t* eval_count;           /* optional [B]: += 1 for every evaluation a game's expand step CONSUMED (a leaf or root it
                                     * expanded); terminal leaves, inactive slots and kept roots do not count.  NULL: off */
+    int32_t* chunk_list;           /* [B*chunk_cap] */
+    int32_t* n_chunks;             /* [B] */
+    int32_t* free_chunks;          /* [pool_chunks] */
+    int32_t* pool_top;             /* [1] */
+    int32_t* pool_stats;           /* [2] */
+    int64_t  pool_chunks;
 } LzTreeDesc;
 
 /* SoA batch -> packed records; packed records -> float32[B,11,6,6] model input (src/neural_network.py:15-65) */
@@ -457,14 +472,15 @@ LZ_API int lz_root_collect(const void* root_states, const void* child_states, co
  * played `played_action[g]` (220-d index, -1: none) and refreshed root_state, promote that child to root and keep
  * its subtree (compacted in place) with its statistics.  Games with reset[g] != 0, inactive games, children that
  * were never expanded or a child state different from root_state[g] start a fresh tree instead.  The reference's tree
- * is unbounded; here a kept subtree that would leave no room for `next_sims` more simulations in the game's arena is
- * PRUNED to its oldest part that fits (a prefix in expansion order -- closed under "parent of"; edges whose child fell
- * past the cut keep their statistics and are expanded afresh when visited).  `dropped`: device int32[2], may be NULL:
- * [0] += subtrees forgotten whole (only if not even the first 64-node chunk fits), [1] += subtrees pruned.
+ * is unbounded; here a kept subtree that would leave no room for `next_sims` more simulations in the game's NODE arena
+ * is PRUNED to its oldest part that fits (a prefix in expansion order -- closed under "parent of"; edges whose child fell
+ * past the cut keep their statistics and are expanded afresh when visited).  Edge room is pooled per engine and does not
+ * bound a single game.  `dropped` / `pruned`: device int32[1] each, may be NULL: += subtrees forgotten whole (defensive:
+ * only if not even the first 64-node chunk fits) / += subtrees pruned.
  * Follow with lz_tree_search_continue (or lz_tree_expand(is_root=1) + the split-phase loop): kept roots are not
  * re-evaluated, they only get a fresh noise mix (portable_mcts.py:617-621). */
 LZ_API int lz_tree_advance(const LzTreeDesc* tree, const int32_t* played_action, const uint8_t* reset,
-                           int64_t next_sims, int32_t* dropped, void* stream);
+                           int64_t next_sims, int32_t* dropped, int32_t* pruned, void* stream);
 /* lz_tree_search without the begin: searches the trees prepared by lz_tree_advance. */
 LZ_API int lz_tree_search_continue(const LzTreeDesc* tree, const LzNetDesc* net, int64_t sims, float* planes,
                                    float* log_p1, float* log_p2, float* log_pmc, float* values, const float* noise,

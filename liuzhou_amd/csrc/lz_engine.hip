@@ -9,10 +9,12 @@
 //   backup : leaf -> root, N += 1, W += v, v = -v iff the mover changes   (portable_mcts.py:123-138)
 //   root   : expanded without backup, optional Dirichlet mix on the priors (portable_mcts.py:451-463)
 //
-// Layout in HBM (sized for the worst case, 288 GB makes this affordable -- no overflow paths):
-//   per game g: node arena  [S+2] x 48 B  { packed 32-byte state, edge_begin, n_edges }
-//               edge arena  [(S+1)*72] x 32 B { W f64, P f32, N|info u32, child i32, child edges i32+u8, action u8 }
-//               path        [S+2] edge ids of the current simulation
+// Layout in HBM:
+//   per game g: node arena  [node_cap] x 48 B  { packed 32-byte state, edge_begin, n_edges, parent }
+//               path        [path_cap] edge ids of the current simulation
+//   per engine: edge pool   [pool_chunks x chunk] x 32 B { W f64, P f32, N|info u32, child i32, child edges i32+u8,
+//               action u8 }, handed to the games in chunks (lz_tree_dev.h) -- sized for the mean fan-out, not for 72
+//               children per node; a refused allocation is counted, never a fault
 // A wave owns one game: lanes enumerate legal actions with ballots + popcount prefixes, evaluate PUCT
 // scores for up to 2 children per lane and reduce with shuffles; there is no cross-wave communication.
 #include <hip/hip_runtime.h>
@@ -156,7 +158,7 @@ __device__ __forceinline__ void tree_select_wave(const Tree& t, const WaveArrays
     to_collect = to_collect < w.K ? to_collect : w.K;
     const bool live = t.root_terminal[g] == 0 && root.ne > 0 && to_collect > 0;
     const Node* nodes = t.nodes + (size_t)g * t.node_cap;
-    const Edge* edges = t.edges + (size_t)g * t.edge_cap;
+    const Edge* edges = t.edges;                               // pool indices
     int found = 0;
     if (live) {
         int d = 0;
@@ -175,7 +177,7 @@ __device__ __forceinline__ void tree_select_wave(const Tree& t, const WaveArrays
                     const int k = r * kWave + lane;
                     sc[r] = __builtin_nan("");                          // no child: never a candidate
                     if (k < ne) {
-                        mine[r] = load_edge(&edges[e0 + k]);
+                        mine[r] = load_edge(&edges[(size_t)(e0 + k)]);
                         const int n = edge_n(mine[r].n_info);
                         double q = 0.0;
                         if (n > 0) {
@@ -361,38 +363,36 @@ __global__ __launch_bounds__(kBlock) void tree_expand_wave_kernel(Tree t, WaveAr
 // src/mcts.py:577-592, portable_mcts.py:74-87, portable_mcts.cpp:739-769.  One wave per game, in place:
 //   1. mark the subtree of the chosen child: node ids ascend in expansion order, so a node is kept iff its parent
 //      is kept -- 64 nodes per step, marks as 64-bit ballots in LDS, same-chunk chains resolved by iterating;
-//   2. slide the kept nodes down to their rank (new id <= old id, chunk loads complete before chunk stores);
-//   3. slide the kept edges down (edge runs ascend with their owner's id, so compaction keeps every run
-//      contiguous), translating owner / child ids by rank and child edge offsets from the moved nodes.
-// A game whose child was never expanded or was re-seated simply starts a fresh tree from root_state, exactly like
-// lz_tree_begin.  A kept subtree that would not leave room for the next search in the game's arena (the reference's
-// tree is unbounded) is PRUNED, not dropped: marking stops at the first 64-node chunk that does not fit, so the oldest
-// part of the subtree -- a prefix in expansion order, which is closed under "parent of" and holds the root's and the
-// upper levels' statistics -- survives; edges whose child fell past the cut keep their visit count and value sum and
-// point to no node again (the next visit expands that position afresh).  `dropped[1]` counts pruned games, `dropped[0]`
-// the (now only defensive) whole-subtree drops.
-constexpr int kMarkWords = 256;        // subtree reuse supports node_cap <= 16384
-__device__ __forceinline__ int wave_sum_i32(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
+//   2. slide the kept nodes down to their rank (new id <= old id, chunk loads complete before chunk stores) and give
+//      every kept edge run its new place: the runs are packed, in node order, into the game's OWN chunks from the
+//      first one on (greedy, a run never straddles a chunk).  The runs were laid down in this order by the same
+//      greedy rule, and packing a subsequence never gets ahead of packing the whole sequence, so a run's new place
+//      is never behind its old one in the game's chunk order: the copy is safe in place;
+//   3. copy the runs node by node (all loads of a run before its stores), translating child ids by rank and child
+//      edge offsets from the moved nodes; chunks behind the last used one go back to the pool.
+// A game whose child was never expanded or was re-seated gives all its chunks back and starts a fresh tree from
+// root_state, exactly like lz_tree_begin.  Edge room is pooled, so only the NODE arena bounds a kept subtree: one that
+// would not leave `reserve_nodes` nodes for the next search (the reference's tree is unbounded) is PRUNED, not dropped:
+// marking stops at the first 64-node chunk that does not fit, so the oldest part of the subtree -- a prefix in
+// expansion order, which is closed under "parent of" and holds the root's and the upper levels' statistics --
+// survives; edges whose child fell past the cut keep their visit count and value sum and point to no node again (the
+// next visit expands that position afresh).  `pruned` counts pruned games, `dropped` the (only defensive) whole-subtree
+// drops.  Dynamic LDS: per wave ceil(node_cap / 64) mark words + as many prefix counts.
+constexpr int kMarkWordsMax = 1024;        // subtree reuse supports node_cap <= 65536
 
 __global__ __launch_bounds__(kBlock) void tree_advance_kernel(Tree t, const int* __restrict__ played_action,
                                                               const uint8_t* __restrict__ reset, int reserve_nodes,
-                                                              int reserve_edges, int* __restrict__ dropped) {
-    __shared__ uint64_t s_mark[kWavesPerBlock][kMarkWords];
-    __shared__ int s_nprefix[kWavesPerBlock][kMarkWords];
-    __shared__ int s_eprefix[kWavesPerBlock][kMarkWords];
+                                                              int mark_words, int* __restrict__ dropped,
+                                                              int* __restrict__ pruned) {
+    extern __shared__ uint64_t s_adv[];
     const int lane = lane_id();
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int g = wave_game();
     if (g >= t.B) return;
     Node* nodes = t.nodes + (size_t)g * t.node_cap;
-    Edge* edges = t.edges + (size_t)g * t.edge_cap;
-    uint64_t* mark = s_mark[wv];
-    int* nprefix = s_nprefix[wv];
-    int* eprefix = s_eprefix[wv];
+    Edge* edges = t.edges;                                      // pool indices
+    uint64_t* mark = s_adv + (size_t)wv * mark_words;
+    int* nprefix = reinterpret_cast<int*>(s_adv + (size_t)kWavesPerBlock * mark_words) + (size_t)wv * mark_words;
     const uint64_t lt = (1ull << lane) - 1ull;
     auto rank_of = [&](int id) { return nprefix[id >> 6] + __popcll(mark[id >> 6] & ((1ull << (id & 63)) - 1ull)); };
 
@@ -407,11 +407,11 @@ __global__ __launch_bounds__(kBlock) void tree_advance_kernel(Tree t, const int*
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             const int k = r * kWave + lane;
-            const uint64_t hit = __ballot(k < ne && (int)edges[e0 + (k < ne ? k : 0)].act == played);
+            const uint64_t hit = __ballot(k < ne && (int)edges[(size_t)(e0 + (k < ne ? k : 0))].act == played);
             if (found < 0 && hit) found = r * kWave + __ffsll((unsigned long long)hit) - 1;
         }
         if (found >= 0) {
-            const Edge E = edges[e0 + found];
+            const Edge E = edges[(size_t)(e0 + found)];
             if (E.child > 0 && !(edge_info(E.n_info) & kInfoTerminal)) {
                 const Packed cs = nodes[E.child].state;     // must be the state the host moved to
                 if (cs.w0 == rs.w0 && cs.w1 == rs.w1 && cs.w2 == rs.w2 && cs.w3 == rs.w3) {
@@ -420,22 +420,22 @@ __global__ __launch_bounds__(kBlock) void tree_advance_kernel(Tree t, const int*
             }
         }
     }
-    const int nn = t.n_nodes[g], n_e = t.n_edges[g];
-    int kept_nodes = 0, kept_edges = 0;
-    if (c > 0 && ((nn + 63) >> 6) > kMarkWords) {              // more nodes than the LDS mark words cover: fresh root
-        c = -1;                                                 // (lz_tree_advance refuses such arenas; belt and braces)
+    const int nn = t.n_nodes[g];
+    const int words = (nn + 63) >> 6;
+    int kept_nodes = 0;
+    if (c > 0 && words > mark_words) {                          // more nodes than the mark words cover: fresh root
+        c = -1;                                                 // (cannot happen: mark_words covers node_cap)
         if (lane == 0 && dropped != nullptr) atomicAdd(dropped, 1);
     }
     if (c > 0) {
         // ---- pass 1: marks + per-word prefix counts ----
-        const int words = (nn + 63) >> 6;
-        const int node_budget = t.node_cap - reserve_nodes, edge_budget = t.edge_cap - reserve_edges;
+        const int node_budget = t.node_cap - reserve_nodes;
         bool cut = false;
         for (int w = 0; w < words; ++w) {
             const int id = w * kWave + lane;
             const bool valid = id < nn;
-            int parent = -1, cnt = 0;
-            if (valid) { parent = nodes[id].parent; cnt = nodes[id].nedges; }
+            int parent = -1;
+            if (valid) parent = nodes[id].parent;
             const bool cand = valid && id > c && parent >= c;   // descendants have larger ids than their ancestors
             bool kept = valid && id == c;
             if (cand && parent < w * kWave) kept = (mark[parent >> 6] >> (parent & 63)) & 1ull;
@@ -447,33 +447,37 @@ __global__ __launch_bounds__(kBlock) void tree_advance_kernel(Tree t, const int*
                 if (nb == bal) break;
                 bal = nb;
             }
-            const int chunk_nodes = __popcll(bal), chunk_edges = wave_sum_i32(kept ? (cnt > 0 ? cnt : 0) : 0);
-            if (kept_nodes + chunk_nodes > node_budget || kept_edges + chunk_edges > edge_budget) {
+            const int chunk_nodes = __popcll(bal);
+            if (kept_nodes + chunk_nodes > node_budget) {
                 // no room for this chunk: the subtree is cut here (expansion order), the rest is forgotten
-                for (int r = w + lane; r < words; r += kWave) { mark[r] = 0ull; nprefix[r] = kept_nodes; eprefix[r] = kept_edges; }
+                for (int r = w + lane; r < words; r += kWave) { mark[r] = 0ull; nprefix[r] = kept_nodes; }
                 cut = true;
                 break;
             }
-            if (lane == 0) { mark[w] = bal; nprefix[w] = kept_nodes; eprefix[w] = kept_edges; }
+            if (lane == 0) { mark[w] = bal; nprefix[w] = kept_nodes; }
             kept_nodes += chunk_nodes;
-            kept_edges += chunk_edges;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (words > kMarkWords || kept_nodes == 0) {             // defensive: nothing of the subtree fits (not reachable
+        if (kept_nodes == 0) {                                   // defensive: nothing of the subtree fits (not reachable
             c = -1;                                              // with arenas that hold one search plus its reserve)
             if (lane == 0 && dropped != nullptr) atomicAdd(dropped, 1);
-        } else if (cut && lane == 0 && dropped != nullptr) {
-            atomicAdd(dropped + 1, 1);
+        } else if (cut && lane == 0 && pruned != nullptr) {
+            atomicAdd(pruned, 1);
         }
     }
     if (c <= 0) {
-        if (lane == 0) begin_game(t, g);
+        release_chunks_wave(t, g, 0, lane);
+        if (lane == 0) begin_game(t, g, /*release=*/false);
         return;
     }
-    // ---- pass 2: nodes ----
-    const int words = (nn + 63) >> 6;
+    // ---- pass 2: nodes, and the new places of their edge runs ----
+    const int* list = t.chunk_list + (size_t)g * t.chunk_cap;
+    const int n_chunks = t.n_chunks[g];
+    const int CH = t.chunk;
+    int ci = 0, off = 0;                                         // chunk being filled (index into the list), its fill
+    int cbase = list[0] * CH;
     for (int w = 0; w < words; ++w) {
         const uint64_t m = mark[w];
         if (!m) continue;
@@ -481,47 +485,69 @@ __global__ __launch_bounds__(kBlock) void tree_advance_kernel(Tree t, const int*
         const bool kept = (m >> lane) & 1ull;
         Node rec;
         int cnt = 0;
-        if (kept) { rec = nodes[id]; cnt = rec.nedges; }
-        int incl = cnt;
+        if (kept) { rec = nodes[id]; cnt = rec.nedges > 0 ? rec.nedges : 0; }
+        int begin = 0, start = 0;
+        for (;;) {
+            const int c2 = lane >= start ? cnt : 0;
+            int incl = c2;
 #pragma unroll
-        for (int o = 1; o < kWave; o <<= 1) { const int up = __shfl_up(incl, o); if (lane >= o) incl += up; }
+            for (int o = 1; o < kWave; o <<= 1) { const int up = __shfl_up(incl, o); if (lane >= o) incl += up; }
+            const uint64_t over = __ballot(c2 > 0 && off + incl > CH);
+            const int first = over ? __ffsll((unsigned long long)over) - 1 : kWave;   // first run that does not fit
+            if (lane >= start && lane < first) begin = cbase + off + incl - c2;
+            const int placed = first == kWave ? __shfl(incl, kWave - 1) : (__shfl(incl, first) - __shfl(c2, first));
+            off += placed;
+            if (!over) break;
+            ci = ci + 1 < n_chunks ? ci + 1 : ci;               // (always within the list: see the header comment)
+            cbase = list[ci] * CH;
+            off = 0;
+            start = first;
+        }
         if (kept) {
-            rec.edge_begin = eprefix[w] + incl - cnt;
+            rec.old_begin = rec.edge_begin;
+            rec.edge_begin = begin;
             rec.parent = id == c ? -1 : rank_of(rec.parent);
             nodes[nprefix[w] + __popcll(m & lt)] = rec;
         }
     }
     __threadfence_block();
-    // ---- pass 3: edges ----
-    int run = 0;
-    for (int base = 0; base < n_e; base += kWave) {
-        const int e = base + lane;
-        const bool valid = e < n_e;
-        Edge rec;
-        bool kept = false;
-        if (valid) {
-            rec = edges[e];
-            kept = (mark[rec.owner >> 6] >> (rec.owner & 63)) & 1ull;
-        }
-        const uint64_t bal = __ballot(kept);
-        if (kept) {
-            rec.owner = (uint16_t)rank_of(rec.owner);
-            if (rec.child >= 0) {
-                if ((mark[rec.child >> 6] >> (rec.child & 63)) & 1ull) {
-                    const int nc = rank_of(rec.child);
-                    rec.child = nc;
-                    rec.cbegin = nodes[nc].edge_begin;
-                } else {                                         // the child fell past the cut of a pruned subtree
-                    rec.child = -1; rec.cbegin = 0; rec.cn = 0;
+    // ---- pass 3: edge runs, node by node in the new order ----
+    for (int base = 0; base < kept_nodes; base += kWave) {
+        const int id = base + lane;
+        int ob = 0, nb = 0, cnt = 0;
+        if (id < kept_nodes) { const Node nr = nodes[id]; ob = nr.old_begin; nb = nr.edge_begin; cnt = nr.nedges; }
+        const int lim = kept_nodes - base < kWave ? kept_nodes - base : kWave;
+        for (int j = 0; j < lim; ++j) {
+            const int n_j = lzw::lane_bcast(cnt, j), ob_j = lzw::lane_bcast(ob, j), nb_j = lzw::lane_bcast(nb, j);
+            Edge rec[2];
+            bool has[2];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int k = r * kWave + lane;
+                has[r] = k < n_j;
+                if (r == 1 && n_j <= kWave) { has[r] = false; continue; }
+                if (has[r]) {
+                    rec[r] = edges[(size_t)(ob_j + k)];
+                    if (rec[r].child >= 0) {
+                        if ((mark[rec[r].child >> 6] >> (rec[r].child & 63)) & 1ull) {
+                            const int nc = rank_of(rec[r].child);
+                            rec[r].child = nc;
+                            rec[r].cbegin = nodes[nc].edge_begin;
+                        } else {                                 // the child fell past the cut of a pruned subtree
+                            rec[r].child = -1; rec[r].cbegin = 0; rec[r].cn = 0;
+                        }
+                    }
                 }
             }
-            edges[run + __popcll(bal & lt)] = rec;
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+                if (has[r]) edges[(size_t)(nb_j + r * kWave + lane)] = rec[r];
         }
-        run += __popcll(bal);
     }
+    release_chunks_wave(t, g, ci + 1, lane);
     if (lane == 0) {
         t.n_nodes[g] = kept_nodes;
-        t.n_edges[g] = kept_edges;
+        t.n_edges[g] = cbase + off;          // off == chunk: "no open chunk" (the next run takes a new one)
         t.root_visits[g] = new_n;
         t.root_W[g] = new_w;
         t.root_init_value[g] = 0.f;
@@ -581,7 +607,7 @@ __global__ __launch_bounds__(kBlock) void tree_finish_kernel(Tree t, const float
     float* prow = policy_dense + (size_t)g * 220;
     for (int j = lane; j < 220; j += kWave) prow[j] = 0.f;
     const Node* nodes = t.nodes + (size_t)g * t.node_cap;
-    const Edge* edges = t.edges + (size_t)g * t.edge_cap;
+    const Edge* edges = t.edges;                               // pool indices
     const int ne = nodes[0].nedges;
     const State root = unpack(nodes[0].state);
     const bool term = t.root_terminal[g] != 0 || ne <= 0;
@@ -603,7 +629,7 @@ __global__ __launch_bounds__(kBlock) void tree_finish_kernel(Tree t, const float
     for (int r = 0; r < 2; ++r) {
         const int k = r * kWave + lane;
         ok[r] = k < ne;
-        const Edge e = edges[e0 + (ok[r] ? k : 0)];
+        const Edge e = edges[(size_t)(e0 + (ok[r] ? k : 0))];
         const int n = ok[r] ? edge_n(e.n_info) : 0;
         v[r] = (float)n;
         pr[r] = ok[r] ? e.P : 0.f;
@@ -944,14 +970,19 @@ int lz_tree_finish(const LzTreeDesc* d, const float* temperatures, const float* 
 }
 
 int lz_tree_advance(const LzTreeDesc* d, const int32_t* played_action, const uint8_t* reset, int64_t next_sims,
-                    int32_t* dropped, void* stream) {
+                    int32_t* dropped, int32_t* pruned, void* stream) {
     if (!tree_ok(d) || next_sims < 0) return LZ_ERR_ARG;
     if (d->num_games == 0) return LZ_OK;
-    if (d->node_cap > kMarkWords * kWave) return LZ_ERR_UNSUPPORTED;   // LDS mark words / 16-bit owner ids: <= 16384 nodes
-    const int64_t rn = next_sims + 1, re = (next_sims + 1) * kMaxChildren;
-    if (rn > d->node_cap || re > d->edge_cap) return LZ_ERR_ARG;
-    hipLaunchKernelGGL(tree_advance_kernel, dim3(gw(d->num_games)), dim3(kBlock), 0, as_stream(stream), make_tree(d),
-                       played_action, reset, (int)rn, (int)re, dropped);
+    const int words = (d->node_cap + kWave - 1) / kWave;
+    if (words > kMarkWordsMax) return LZ_ERR_UNSUPPORTED;             // LDS mark words: <= 65536 nodes per game
+    const int64_t rn = next_sims + 1;
+    if (rn > d->node_cap) return LZ_ERR_ARG;
+    // a game's chunk list must be able to hold the worst case of its node arena (72 children everywhere), so that the
+    // node budget is the only thing that can cut a kept subtree
+    if ((int64_t)d->chunk_cap * (d->edge_chunk - (kMaxChildren - 1)) < (int64_t)d->node_cap * kMaxChildren) return LZ_ERR_ARG;
+    const size_t lds = (size_t)kWavesPerBlock * words * (sizeof(uint64_t) + sizeof(int));
+    hipLaunchKernelGGL(tree_advance_kernel, dim3(gw(d->num_games)), dim3(kBlock), lds, as_stream(stream), make_tree(d),
+                       played_action, reset, (int)rn, words, dropped, pruned);
     return st();
 }
 

@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "lz_soa.h"
 #include "lz_wave.h"
@@ -602,6 +603,119 @@ __global__ __launch_bounds__(kBlock) void root_puct_kernel(const float* __restri
     if (lane == 0) root_values[root] = sw / fmaxf(sv, 1.0f);
 }
 
+// ---- the same allocation with the two IEEE divisions of a pull replaced by exact equivalents (round 4) ------------
+// A pull is VALU-issue bound (one wave per root, 8 waves per SIMD take turns): ~45 instructions, 20 of them the two
+// correctly rounded fp32 divisions  u = (c*p*sqrt_total) / (1 + visits)  and  q = value_sum / visits, ~10 more the
+// correctly rounded sqrtf.  Here
+//   * sqrt_total comes from a table: total == sim while pulls succeed (a pull that finds no candidate changes nothing,
+//     so every later one fails too), and table[sim] = sqrtf(sim + 1) is the same correctly rounded value;
+//   * x / d with d an INTEGER <= 2^17 is computed as (float)((double)x * rd[d]), rd[d] = 1.0 / d in double: the
+//     product is within 2^-52 of x / d, while x / d (24-bit x, normal quotient) stays at least 2^-42 (relative) away
+//     from every rounding boundary of fp32 -- x = m * d has no solution for a 25-bit odd midpoint m -- so the rounded
+//     result IS the correctly rounded quotient.  The bound needs a normal quotient: waves whose priors or leaf values
+//     hold non-zero magnitudes below 2^-100 (never seen; the denormal range allows exact ties) take the division path.
+//   * rd[1 + visits] / rd[visits] sit in registers per action; only the pulled action reloads one entry, one pull ahead.
+// Bit-identical visits / value sums by construction; checked against the division kernel and the reference op (g6).
+constexpr int kPuctTable = 65536;                 // pulls covered by the tables
+__device__ float g_puct_sqrt[kPuctTable];         // sqrtf(sim + 1)
+__device__ double g_puct_recip[kPuctTable + 3];   // 1.0 / d, d = 1 .. kPuctTable + 2 ([0] unused)
+__global__ void puct_tables_kernel() {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < kPuctTable) g_puct_sqrt[i] = sqrtf((float)i + 1.0f);
+    if (i < kPuctTable + 3) g_puct_recip[i] = i > 0 ? 1.0 / (double)i : 0.0;
+}
+
+__device__ __forceinline__ float div_by_int(float x, double rd) { return (float)((double)x * rd); }
+
+template <int SLOTS, bool EXACT_DIV>
+__device__ __forceinline__ void puct_pulls(int sims, int lane, int live, const float (&cp)[SLOTS], const float (&lv)[SLOTS],
+                                           float (&vis)[SLOTS], float (&vs)[SLOTS]) {
+    float q[SLOTS];
+    double rd_u[SLOTS], rd_next[SLOTS];                          // 1 / (1 + visits), 1 / (2 + visits)
+    int nv[SLOTS];
+#pragma unroll
+    for (int j = 0; j < SLOTS; ++j) { q[j] = 0.f; nv[j] = 0; rd_u[j] = 1.0; rd_next[j] = 0.5; }
+    for (int sim = 0; sim < sims; ++sim) {
+        const float sqrt_total = g_puct_sqrt[sim];               // uniform address: a scalar load
+        float sc[SLOTS];
+        float best = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < SLOTS; ++j) {
+            sc[j] = __builtin_nanf("");
+            if (j < live) {
+                const float x = cp[j] * sqrt_total;
+                const float u = EXACT_DIV ? x / (1.0f + vis[j]) : div_by_int(x, rd_u[j]);
+                sc[j] = q[j] + u;
+                best = sc[j] > best ? sc[j] : best;
+            }
+        }
+        const float m = lzw::wave_max_nonan(best);               // `best` is -inf or a score that won a `>`: never NaN
+        int chosen = -1;
+#pragma unroll
+        for (int j = 0; j < SLOTS; ++j) {
+            if (j < live && chosen < 0) {
+                const unsigned long long hit = __ballot(sc[j] == m);
+                if (hit != 0ull) chosen = j * kWave + __builtin_ctzll(hit);
+            }
+        }
+        if (chosen < 0) break;                                   // no candidate now means none later either
+#pragma unroll
+        for (int j = 0; j < SLOTS; ++j) {
+            if (chosen == j * kWave + lane) {
+                nv[j] += 1;
+                vis[j] += 1.0f;
+                vs[j] += lv[j];
+                const double rd_q = rd_u[j];                     // 1 / visits
+                rd_u[j] = rd_next[j];                            // 1 / (1 + visits)
+                if (!EXACT_DIV) rd_next[j] = g_puct_recip[nv[j] + 2];   // needed at this action's next pull
+                q[j] = EXACT_DIV ? vs[j] / vis[j] : div_by_int(vs[j], rd_q);
+            }
+        }
+    }
+}
+
+template <int SLOTS>
+__global__ __launch_bounds__(kBlock) void root_puct_fast_kernel(const float* __restrict__ priors,
+                                                                const float* __restrict__ leaf,
+                                                                const uint8_t* __restrict__ valid, int64_t R,
+                                                                int A, int sims, float c,
+                                                                float* __restrict__ visits,
+                                                                float* __restrict__ value_sum,
+                                                                float* __restrict__ root_values) {
+    const int lane = lane_id();
+    const int64_t root = wave_item();
+    if (root >= R) return;
+    float cp[SLOTS], lv[SLOTS], vis[SLOTS], vs[SLOTS];
+    int live = 0;
+    bool tiny = false;
+#pragma unroll
+    for (int j = 0; j < SLOTS; ++j) {
+        const int a = j * kWave + lane;
+        const bool ok = a < A && valid[root * A + (a < A ? a : 0)] != 0;
+        // an action that may not be chosen carries a NaN score: never greater, never equal to the maximum
+        cp[j] = ok ? c * priors[root * A + a] : __builtin_nanf("");
+        lv[j] = a < A ? leaf[root * A + a] : 0.f;
+        vis[j] = 0.f; vs[j] = 0.f;
+        if (__ballot(ok) != 0ull) live = j + 1;
+        const float acp = fabsf(cp[j]), alv = fabsf(lv[j]);
+        tiny = tiny || (ok && ((acp != 0.f && acp < 0x1p-100f) || (alv != 0.f && alv < 0x1p-100f)));
+    }
+    // wave-uniform: the plain divisions for this root (two instantiations of the loop, one real branch)
+    if (__ballot(tiny) != 0ull) puct_pulls<SLOTS, true>(sims, lane, live, cp, lv, vis, vs);
+    else puct_pulls<SLOTS, false>(sims, lane, live, cp, lv, vis, vs);
+    float sv = 0.f, sw = 0.f;
+#pragma unroll
+    for (int j = 0; j < SLOTS; ++j) {
+        const int a = j * kWave + lane;
+        if (a < A) { visits[root * A + a] = vis[j]; value_sum[root * A + a] = vs[j]; }
+        sv += vis[j];
+        sw += vs[j];
+    }
+    sv = wave_sum(sv);
+    sw = wave_sum(sw);
+    if (lane == 0) root_values[root] = sw / fmaxf(sv, 1.0f);
+}
+
 // =================================================================================================
 // root_finalize_from_visits (+ sampled pick): fill kernel, then one wave per root.
 // =================================================================================================
@@ -1149,6 +1263,22 @@ int lz_root_puct_allocate_visits(const float* priors, const float* leaf, const u
     if (!priors || !leaf || !valid || !visits || !value_sum || !root_values) return LZ_ERR_ARG;
     const dim3 grid(grid_waves(R)), block(kBlock);
     hipStream_t st = as_stream(stream);
+    // table-driven pulls (bit-identical, about half the instructions) for budgets the tables cover;
+    // LZ_ROOT_PUCT_DIV=1 forces the division kernel (tests compare the two)
+    const char* force = getenv("LZ_ROOT_PUCT_DIV");
+    if (sims <= kPuctTable && !(force && force[0] == '1')) {
+        static bool tables_ready[64] = {};
+        int device = 0;
+        if (hipGetDevice(&device) != hipSuccess || device < 0 || device >= 64) return LZ_ERR_LAUNCH;
+        if (!tables_ready[device]) {   // once per device; a capture in progress simply records the fill with the search
+            hipLaunchKernelGGL(puct_tables_kernel, dim3((kPuctTable + 3 + 255) / 256), dim3(256), 0, st);
+            tables_ready[device] = true;
+        }
+        if (A <= 64) hipLaunchKernelGGL(root_puct_fast_kernel<1>, grid, block, 0, st, priors, leaf, valid, R, (int)A, (int)sims, c, visits, value_sum, root_values);
+        else if (A <= 128) hipLaunchKernelGGL(root_puct_fast_kernel<2>, grid, block, 0, st, priors, leaf, valid, R, (int)A, (int)sims, c, visits, value_sum, root_values);
+        else hipLaunchKernelGGL(root_puct_fast_kernel<4>, grid, block, 0, st, priors, leaf, valid, R, (int)A, (int)sims, c, visits, value_sum, root_values);
+        return launch_status();
+    }
     if (A <= 64) hipLaunchKernelGGL(root_puct_kernel<1>, grid, block, 0, st, priors, leaf, valid, R, (int)A, sims, c, visits, value_sum, root_values);
     else if (A <= 128) hipLaunchKernelGGL(root_puct_kernel<2>, grid, block, 0, st, priors, leaf, valid, R, (int)A, sims, c, visits, value_sum, root_values);
     else hipLaunchKernelGGL(root_puct_kernel<4>, grid, block, 0, st, priors, leaf, valid, R, (int)A, sims, c, visits, value_sum, root_values);

@@ -149,7 +149,7 @@ int configure_search() {
                ? LZ_OK : LZ_ERR_LAUNCH;
 }
 
-bool g_search_configured = false;
+bool g_search_configured[64] = {};          // per device: the dynamic-LDS attribute belongs to the device's code object
 
 }  // namespace
 
@@ -172,10 +172,12 @@ int lz_tree_search_persistent(const LzTreeDesc* d, const LzNetDesc* net, int64_t
     if (net->channels != 64 || (net->flags & 4)) return LZ_ERR_UNSUPPORTED;
     const int64_t B = d->num_games;
     if (B == 0) return LZ_OK;
-    if (!g_search_configured) {
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess || device < 0 || device >= 64) return LZ_ERR_LAUNCH;
+    if (!g_search_configured[device]) {
         const int rc = configure_search<64, 8, 4>();
         if (rc) return rc;
-        g_search_configured = true;
+        g_search_configured[device] = true;
     }
     int rc = continue_trees ? LZ_OK : lz_tree_begin(d, stream);
     if (rc) return rc;
@@ -186,7 +188,7 @@ int lz_tree_search_persistent(const LzTreeDesc* d, const LzNetDesc* net, int64_t
     SearchArgs a;
     a.sims = (int)sims; a.noise = noise; a.noise_stride = (int)noise_stride; a.epsilon = epsilon;
     a.cu_slots = cu_slots;
-    a.stagger_ticks = (int)(stagger_us * 100);
+    a.stagger_ticks = (int)((stagger_us > 10000 ? 10000 : stagger_us) * 100);     // 100 MHz ticks; clamped to 10 ms
     a.phase_ticks = reinterpret_cast<long long*>(phase_ticks);
     a.exp_mode = 0;
 #ifdef LZ_EXP_SEARCH_MODES  /* experiment builds only (scripts/exp_persistent.py, profiles/r03_experiments.md): modes that skip

@@ -37,26 +37,34 @@ struct Edge {
     int32_t cbegin;      // child's first edge (valid when child >= 0)
     uint8_t act;         // 220-d action index
     uint8_t cn;          // child's edge count (valid when child >= 0)
-    uint16_t owner;      // node that owns this edge run (subtree compaction, lz_tree_advance)
-    uint8_t pad[4];
+    uint8_t pad[6];
 };
 static_assert(sizeof(Edge) == 32, "edge record is 32 bytes");
 // 48-byte node record
 struct Node {
     Packed state;
-    int32_t edge_begin, nedges;      // nedges = -1: not expanded
+    int32_t edge_begin, nedges;      // first edge (index into the engine's edge pool), nedges = -1: not expanded
     int32_t parent;                  // parent node (-1 for the root)
-    int32_t pad;
+    int32_t old_begin;               // scratch of lz_tree_advance: where the run lay before the compaction
 };
 static_assert(sizeof(Node) == 48, "node record is 48 bytes");
 __device__ __forceinline__ int edge_n(uint32_t ni) { return (int)(ni & 0xFFFFFFu); }
 __device__ __forceinline__ uint8_t edge_info(uint32_t ni) { return (uint8_t)(ni >> 24); }
 
+// Edge storage (round 4): ONE pool per engine, cut into chunks of `chunk` edges (a power of two).  A game owns a list of
+// chunks (chunk_list[g][0 .. n_chunks[g])), takes a new one from the free stack (free_chunks / pool_top) when the run
+// of a new node does not fit into what is left of its open chunk -- runs never straddle chunks -- and gives chunks back
+// when its tree is reset or compacted.  Every edge index in a record (Node::edge_begin, Edge::cbegin, path entries,
+// leaf_edge) is an index into the pool, so the descent never looks at the chunk list.  Expand kernels only pop, begin /
+// advance kernels only push: a pop never meets a push of the same launch.
 struct Tree {
-    int B, node_cap, edge_cap, path_cap;
+    int B, node_cap, chunk, path_cap, chunk_cap;
     const Packed* root_state;
     Node* nodes; Edge* edges;
-    int* n_nodes; int* n_edges; int* root_visits; double* root_W; float* root_init_value;
+    int* n_nodes; int* n_edges;      // n_edges[g]: next free pool index of the game's open chunk (multiple of chunk: none)
+    int* chunk_list; int* n_chunks; int* free_chunks; int* pool_top;
+    int* pool_stats;                 // [0] expansions refused because the pool was empty, [1] fewest free chunks seen
+    int* root_visits; double* root_W; float* root_init_value;
     int* path; int* path_len; int* leaf_kind; Packed* leaf_state; float* leaf_value;
     uint8_t* root_terminal; const uint8_t* active;
     int* leaf_edge; int* leaf_parent;      // edge / node the pending leaf hangs from (written by select)
@@ -99,7 +107,43 @@ __device__ __forceinline__ double terminal_value_for_mover(const State& s) {   /
 
 
 // ---- begin a search: fresh tree per game -----------------------------------------------------------------
-__device__ __forceinline__ void begin_game(const Tree& t, int g) {
+// give chunks [keep, n_chunks) of game g back to the pool (one thread)
+__device__ __forceinline__ void release_chunks(const Tree& t, int g, int keep) {
+    const int nc = t.n_chunks[g];
+    if (nc > keep) {
+        const int base = atomicAdd(t.pool_top, nc - keep);
+        const int* list = t.chunk_list + (size_t)g * t.chunk_cap;
+        for (int i = keep; i < nc; ++i) t.free_chunks[base + (i - keep)] = list[i];
+    }
+    t.n_chunks[g] = keep < nc ? keep : nc;
+}
+// the same by a whole wave
+__device__ __forceinline__ void release_chunks_wave(const Tree& t, int g, int keep, int lane) {
+    const int nc = t.n_chunks[g];
+    if (nc > keep) {
+        int base = 0;
+        if (lane == 0) base = atomicAdd(t.pool_top, nc - keep);
+        base = __builtin_amdgcn_readfirstlane(base);
+        const int* list = t.chunk_list + (size_t)g * t.chunk_cap;
+        for (int i = keep + lane; i < nc; i += kWave) t.free_chunks[base + (i - keep)] = list[i];
+        if (lane == 0) t.n_chunks[g] = keep;
+    }
+}
+// one thread takes a chunk from the pool for game g: its first pool index, or -1 (pool empty / list full; counted)
+__device__ __forceinline__ int take_chunk(const Tree& t, int g) {
+    const int nc = t.n_chunks[g];
+    if (nc >= t.chunk_cap) { atomicAdd(t.pool_stats, 1); return -1; }
+    const int top = atomicSub(t.pool_top, 1) - 1;
+    if (top < 0) { atomicAdd(t.pool_top, 1); atomicAdd(t.pool_stats, 1); return -1; }
+    atomicMin(t.pool_stats + 1, top);
+    const int cid = t.free_chunks[top];
+    t.chunk_list[(size_t)g * t.chunk_cap + nc] = cid;
+    t.n_chunks[g] = nc + 1;
+    return cid * t.chunk;
+}
+
+__device__ __forceinline__ void begin_game(const Tree& t, int g, bool release = true) {
+    if (release) release_chunks(t, g, 0);
     const Packed rs = t.root_state[g];
     Node& root = t.nodes[(size_t)g * t.node_cap];
     root.state = rs;
@@ -139,7 +183,7 @@ __device__ __forceinline__ RootInfo load_root_info(const Tree& t, int g) {
 __device__ __forceinline__ void tree_select(const Tree& t, int g, int lane, const RootInfo& root) {
     if (t.root_terminal[g]) { if (lane == 0) t.leaf_kind[g] = kLeafInactive; return; }
     const Node* nodes = t.nodes + (size_t)g * t.node_cap;
-    const Edge* edges = t.edges + (size_t)g * t.edge_cap;
+    const Edge* edges = t.edges;                               // pool indices
     int* path = t.path + (size_t)g * t.path_cap;
     int node = 0, depth = 0;
     int parent_n = root.visits;
@@ -162,7 +206,7 @@ __device__ __forceinline__ void tree_select(const Tree& t, int g, int lane, cons
             if (r == 1 && ne <= kWave) break;
             const int k = r * kWave + lane;
             if (k < ne) {
-                mine[r] = load_edge(&edges[e0 + k]);
+                mine[r] = load_edge(&edges[(size_t)(e0 + k)]);
                 const int n = edge_n(mine[r].n_info);
                 double q = 0.0;
                 if (n > 0) {
@@ -250,7 +294,7 @@ __device__ __forceinline__ void tree_expand(const Tree& t, int g, int lane, cons
                                             ExpandScratch sc, RootInfo* root_after = nullptr, int step = -1) {
     const int kind = t.leaf_kind[g];
     Node* nodes = t.nodes + (size_t)g * t.node_cap;
-    Edge* edges = t.edges + (size_t)g * t.edge_cap;
+    Edge* edges = t.edges;                                     // pool indices
     const int* path = t.path + (size_t)g * t.path_cap;
     // ---- independent loads, all in flight together ----
     RootInfo root{};
@@ -291,7 +335,7 @@ __device__ __forceinline__ void tree_expand(const Tree& t, int g, int lane, cons
                 for (int r = 0; r < 2; ++r) {
                     const int k = r * kWave + lane;
                     ok[r] = k < ne;
-                    pr[r] = ok[r] ? keep * edges[e0 + k].P + epsilon * noise[(size_t)g * noise_stride + k] : 0.f;
+                    pr[r] = ok[r] ? keep * edges[(size_t)(e0 + k)].P + epsilon * noise[(size_t)g * noise_stride + k] : 0.f;
                 }
                 float psum = 0.f;
 #pragma unroll
@@ -306,7 +350,7 @@ __device__ __forceinline__ void tree_expand(const Tree& t, int g, int lane, cons
                 const float denom = psum < 1e-8f ? 1e-8f : psum;
 #pragma unroll
                 for (int r = 0; r < 2; ++r)
-                    if (ok[r]) edges[e0 + r * kWave + lane].P = pr[r] / denom;
+                    if (ok[r]) edges[(size_t)(e0 + r * kWave + lane)].P = pr[r] / denom;
             }
         }
         return;
@@ -326,7 +370,7 @@ __device__ __forceinline__ void tree_expand(const Tree& t, int g, int lane, cons
             backup_value = -1.0;
             if (lane == 0) {
                 if (IS_ROOT) { nodes[0].nedges = 0; t.root_terminal[g] = 1; t.root_init_value[g] = -1.f; }
-                else atomicOr(&edges[leaf_edge].n_info, (uint32_t)kInfoTerminal << 24);   // value bits stay 0 (= -1)
+                else atomicOr(&edges[(size_t)leaf_edge].n_info, (uint32_t)kInfoTerminal << 24);   // value bits stay 0 (= -1)
             }
         } else {
             // gather per-lane logits / priors of the legal actions in ascending index order
@@ -410,28 +454,37 @@ __device__ __forceinline__ void tree_expand(const Tree& t, int g, int lane, cons
 #pragma unroll 4
             for (int k = 0; k < n; ++k) psum += lzw::lane_bcast(k < kWave ? cval[0] : cval[1], k & 63);
             const bool bad = !(psum > 0.f) || !isfinite(psum);
-            // node + edge allocation (per-game bump counters, worst-case sized regions)
+            // node + edge allocation: the node from the game's bump counter, the run of n edges from the game's open
+            // chunk of the pool, or from a new chunk when it does not fit there (runs never straddle chunks)
             int node_id = 0, e0 = 0;
             if (lane == 0) {
-                if (IS_ROOT) { node_id = 0; e0 = ne_ld; t.n_edges[g] = e0 + n; }
-                else {
-                    node_id = nn_ld; t.n_nodes[g] = node_id + 1;
-                    e0 = ne_ld; t.n_edges[g] = e0 + n;
-                    Edge& in = edges[leaf_edge];
-                    in.child = node_id; in.cbegin = e0; in.cn = (uint8_t)n;
-                    nodes[node_id].state = leaf_packed;
-                    nodes[node_id].parent = leaf_parent;
+                e0 = ne_ld;
+                const int off = e0 & (t.chunk - 1);
+                if (off == 0 || off + n > t.chunk) e0 = take_chunk(t, g);
+                if (e0 >= 0) {
+                    t.n_edges[g] = e0 + n;
+                    if (IS_ROOT) node_id = 0;
+                    else {
+                        node_id = nn_ld; t.n_nodes[g] = node_id + 1;
+                        Edge& in = edges[(size_t)leaf_edge];
+                        in.child = node_id; in.cbegin = e0; in.cn = (uint8_t)n;
+                        nodes[node_id].state = leaf_packed;
+                        nodes[node_id].parent = leaf_parent;
+                    }
+                    nodes[node_id].edge_begin = e0;
+                    nodes[node_id].nedges = n;
                 }
-                nodes[node_id].edge_begin = e0;
-                nodes[node_id].nedges = n;
                 if (IS_ROOT) t.root_init_value[g] = value_ld;
             }
             e0 = __builtin_amdgcn_readfirstlane(e0);
             node_id = __builtin_amdgcn_readfirstlane(node_id);
+            // pool exhausted (counted in pool_stats[0]; the engine sizes the pool so that this does not happen): the leaf
+            // stays unexpanded -- its value is still backed up, the next visit evaluates and tries again
+            const int n_write = e0 >= 0 ? n : 0;
             // Phase B: one pass (two only when a movement position has more than 64 legal moves)
-            for (int r = 0; r < (n > kWave ? 2 : 1); ++r) {
+            for (int r = 0; r < (n_write > kWave ? 2 : 1); ++r) {
                 const int k = r * kWave + lane;
-                if (k >= n) continue;
+                if (k >= n_write) continue;
                 const int a = r == 0 ? cact[0] : cact[1];
                 State c = s;
                 int kd, p, q2, ex;
@@ -450,9 +503,8 @@ __device__ __forceinline__ void tree_expand(const Tree& t, int g, int lane, cons
                 rec.cbegin = 0;
                 rec.act = (uint8_t)a;
                 rec.cn = 0;
-                rec.owner = (uint16_t)node_id;
-                rec.pad[0] = rec.pad[1] = rec.pad[2] = rec.pad[3] = 0;
-                edges[e0 + k] = rec;
+                rec.pad[0] = rec.pad[1] = rec.pad[2] = rec.pad[3] = rec.pad[4] = rec.pad[5] = 0;
+                edges[(size_t)(e0 + k)] = rec;
             }
             backup_value = (double)value_ld;
         }
@@ -470,7 +522,7 @@ __device__ __forceinline__ void tree_expand(const Tree& t, int g, int lane, cons
             const uint64_t F = __ballot(in && (pe & kPathFlip) != 0u);
             const int above = in ? __popcll(F >> (lane + 1)) : 0;   // flips at offsets > j inside the chunk
             if (in) {
-                Edge* e = &edges[pe & ~kPathFlip];
+                Edge* e = &edges[(size_t)(pe & ~kPathFlip)];
                 const double v = ((above + flips_above) & 1) ? -backup_value : backup_value;
                 atomicAdd(&e->n_info, 1u);
                 unsafeAtomicAdd(&e->W, v);
@@ -491,7 +543,10 @@ inline int st() { return hipGetLastError() == hipSuccess ? LZ_OK : LZ_ERR_LAUNCH
 
 Tree make_tree(const LzTreeDesc* d) {
     Tree t;
-    t.B = (int)d->num_games; t.node_cap = d->node_cap; t.edge_cap = d->edge_cap; t.path_cap = d->path_cap;
+    t.B = (int)d->num_games; t.node_cap = d->node_cap; t.chunk = d->edge_chunk; t.path_cap = d->path_cap;
+    t.chunk_cap = d->chunk_cap;
+    t.chunk_list = d->chunk_list; t.n_chunks = d->n_chunks; t.free_chunks = d->free_chunks; t.pool_top = d->pool_top;
+    t.pool_stats = d->pool_stats;
     t.root_state = reinterpret_cast<const Packed*>(d->root_state);
     t.nodes = reinterpret_cast<Node*>(d->nodes);
     t.edges = reinterpret_cast<Edge*>(d->edges);
@@ -513,7 +568,10 @@ Tree make_tree(const LzTreeDesc* d) {
     return t;
 }
 bool tree_ok(const LzTreeDesc* d) {
-    return d && d->num_games >= 0 && d->node_cap >= 2 && d->edge_cap >= kMaxChildren && d->path_cap >= 3 &&
+    return d && d->num_games >= 0 && d->node_cap >= 2 && d->path_cap >= 3 &&
+           d->edge_chunk >= 128 && (d->edge_chunk & (d->edge_chunk - 1)) == 0 && d->chunk_cap >= 1 &&
+           d->pool_chunks >= 1 && (d->pool_chunks + 1) * (int64_t)d->edge_chunk <= (int64_t)1 << 31 &&
+           d->chunk_list && d->n_chunks && d->free_chunks && d->pool_top && d->pool_stats &&
            d->root_state && d->nodes && d->edges && d->n_nodes && d->n_edges &&
            d->root_visits && d->root_w && d->root_init_value && d->path && d->path_len && d->leaf_kind &&
            d->leaf_state && d->leaf_value && d->root_terminal && d->leaf_edge && d->leaf_parent;

@@ -53,6 +53,21 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 #undef LZW_REDUCE
 
+// The same maximum for inputs that are never NaN, one fused v_max_f32_dpp per step (the select form above costs a DPP
+// move + compare + select; `fmaxf` makes the compiler add a canonicalising v_max per operand).  Lanes without a DPP
+// source keep their value; two wait states separate a VALU write from a DPP read of the same register.
+__device__ __forceinline__ float wave_max_nonan(float v) {
+    asm volatile("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+                 "s_nop 1"
+                 : "+v"(v));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
 // value of `v` in lane `src` (src must be wave-uniform): v_readlane, no LDS
 __device__ __forceinline__ int lane_bcast(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
 __device__ __forceinline__ float lane_bcast(float v, int src) {

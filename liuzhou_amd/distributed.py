@@ -19,6 +19,7 @@ import torch.distributed as dist
 from .trajectory_buffer import TensorSelfPlayBatch
 
 _FIELDS = ("state_tensors", "legal_masks", "policy_targets", "value_targets", "soft_value_targets")
+EXPANDED_ROW_BYTES = 11 * 36 * 4 + 220 + 220 * 4 + 4 + 4            # one row of the five-tensor contract (2 692 B)
 
 
 def split_games(total_games: int, parts: int) -> List[int]:
@@ -76,6 +77,15 @@ def _gather_compact(batch: TensorSelfPlayBatch, dst: int, group) -> Optional[Ten
         for req in dist.batch_isend_irecv(ops):
             req.wait()
     buf = buf.to(dev)
+    # the destination expands every rank's records to the 2 692-byte five-tensor rows next to whatever else lives on
+    # its device (at C4 rank 0 still holds its own tree arenas): refuse before allocating rather than fail half-way
+    need = int(buf.shape[0]) * EXPANDED_ROW_BYTES
+    free, _total = torch.cuda.mem_get_info(dev)
+    free += torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)     # cached blocks torch can reuse
+    if need > free:
+        raise RuntimeError(f"gather_trajectories: rank {dst} needs {need / 2**30:.1f} GiB to expand {int(buf.shape[0])} "
+                           f"rows but only {free / 2**30:.1f} GiB of device memory are free; release the search engines "
+                           "(arenas) first or gather in several pieces")
     return unpack_records(buf)
 
 
@@ -140,9 +150,15 @@ def broadcast_checkpoint(model: torch.nn.Module, src: int = 0, group=None) -> No
     by_dtype: Dict[torch.dtype, List[torch.Tensor]] = {}
     for t in list(model.parameters()) + list(model.buffers()):
         by_dtype.setdefault(t.dtype, []).append(t.data)
+    direct = dist.get_backend(group) == "nccl"
     for _dt, ts in sorted(by_dtype.items(), key=lambda kv: str(kv[0])):
         flat = torch.cat([t.reshape(-1) for t in ts])
-        dist.broadcast(flat, src=src, group=group)
+        if flat.is_cuda and not direct:                               # gloo rehearsal of the RCCL path: through host memory
+            host = flat.cpu()
+            dist.broadcast(host, src=src, group=group)
+            flat = host.to(flat.device)
+        else:
+            dist.broadcast(flat, src=src, group=group)
         off = 0
         for t in ts:
             n = t.numel()

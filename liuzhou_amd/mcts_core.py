@@ -181,7 +181,7 @@ class MCTSCore:
     set_eval_batcher = set_torchscript_runner
 
     # ---- tree ----
-    NODE_LIMIT = 16384          # tree_advance_kernel: LDS mark words / 16-bit owner ids (csrc/lz_engine.hip)
+    NODE_LIMIT = 65536          # tree_advance_kernel marks a game's nodes in LDS: 1024 words of 64 (csrc/lz_engine.hip)
 
     def _capacity(self) -> int:
         return max(1024, 4 * int(self.cfg.num_simulations))
@@ -191,7 +191,7 @@ class MCTSCore:
         self._root_like = state
         cap = self._capacity()
         if cap + 2 > self.NODE_LIMIT:
-            # the reference's tree is unbounded; ours is an arena of at most 16 384 nodes per game
+            # the reference's tree is unbounded; ours is an arena of at most 65 536 nodes per game
             raise ValueError(f"MCTSCore: num_simulations={self.cfg.num_simulations} needs an arena of {cap} nodes, above the "
                              f"{self.NODE_LIMIT}-node limit of a device tree (use num_simulations <= {(self.NODE_LIMIT - 2) // 4})")
         if self._engine is None or self._engine.max_sims < cap:
@@ -314,6 +314,17 @@ class MCTSCore:
 
     def get_eval_stats(self) -> Dict[str, object]:
         return {"eval_calls": self._eval_calls, "eval_leaves": self._eval_leaves, "full512_calls": 0, "hist": []}
+
+    def get_tree_stats(self) -> Dict[str, int]:
+        """Not in the reference (its tree is unbounded): how often advance_root could not keep the whole subtree of the
+        played move -- `reuse_pruned`: cut to its oldest part that fits the node arena (statistics of positions past the
+        cut restart from zero when they are visited again), `reuse_dropped`: forgotten whole -- and the state of the edge
+        pool (`refused_expansions` must stay 0)."""
+        if self._engine is None:
+            return {"reuse_dropped": 0, "reuse_pruned": 0, "refused_expansions": 0, "node_cap": 0}
+        d, p = (int(v) for v in self._engine.reuse_dropped.tolist())
+        return {"reuse_dropped": d, "reuse_pruned": p, "node_cap": int(self._engine.node_cap),
+                "refused_expansions": int(self._engine.pool_status()["refused_expansions"])}
 
     @property
     def root_value(self) -> float:

@@ -41,6 +41,9 @@ class _Stepper:
         self.amp, self.alpha, self.anti_draw, self.draw_w = amp, alpha, anti_draw, draw_w
         self.clip, self.ddp, self.dev = float(grad_clip_norm), ddp, dev
         self._nominal_rows: Optional[int] = None
+        self._row_hist: Dict[int, int] = {}               # batch sizes seen so far
+        self._conv_counts = [0, 0]                        # steps in [search-once, immediate] mode (reported per epoch)
+        self._conv_logged = False
         self.reset()
 
     def reset(self) -> None:
@@ -57,9 +60,23 @@ class _Stepper:
         for 6x64.  LZ_TRAIN_MIOPEN = auto (default: the nominal batch size searches once, any other size runs immediate),
         immediate (never search) or find (PyTorch's default behaviour)."""
         mode = os.environ.get("LZ_TRAIN_MIOPEN", "auto").strip().lower()
+        # nominal = the row count that is worth one kernel search.  The callers set it to their batch size; when the
+        # loader's batches regularly have another size (its own batch size, rows dropped by the non-finite filter), the
+        # size seen most often takes over after its third occurrence instead of every step running immediate mode
+        rows = int(rows)
+        self._row_hist[rows] = self._row_hist.get(rows, 0) + 1
         if self._nominal_rows is None:
-            self._nominal_rows = int(rows)
+            self._nominal_rows = rows
+        elif rows != self._nominal_rows and self._row_hist[rows] >= 3 and \
+                self._row_hist[rows] > self._row_hist.get(self._nominal_rows, 0):
+            self._nominal_rows = rows
+            self._conv_logged = False
         imm = mode == "immediate" or (mode == "auto" and int(rows) != self._nominal_rows)
+        self._conv_counts[1 if imm else 0] += 1
+        if not self._conv_logged:
+            self._conv_logged = True
+            print(f"[liuzhou_amd.train] MIOpen mode {mode}: batches of {self._nominal_rows} rows search once, every other "
+                  f"size runs immediate mode", flush=True)
         return torch.backends.miopen.flags(immediate=True) if (imm and hasattr(torch.backends, "miopen")) else nullcontext()
 
     def step(self, b_states, b_masks, b_policy, b_values, b_soft) -> bool:
@@ -132,7 +149,9 @@ class _Stepper:
                  "avg_wdl_aux_loss": r[4] / max(1, seen), "samples": seen, "valid_policy_samples": int(round(r[7])),
                  "policy_weight_sum": r[6], "soft_alpha": self.alpha, "avg_soft_abs": r[8] / max(1, int(round(r[10]))),
                  "avg_mix_abs": r[9] / max(1, int(round(r[10]))),
-                 "skipped_non_finite_loss_batches": int(round(r[11])), "skipped_non_finite_grad_batches": int(round(r[12]))}
+                 "skipped_non_finite_loss_batches": int(round(r[11])), "skipped_non_finite_grad_batches": int(round(r[12])),
+                 "miopen_nominal_rows": self._nominal_rows, "miopen_immediate_steps": int(self._conv_counts[1]),
+                 "miopen_search_mode_steps": int(self._conv_counts[0])}
         stats.update(extra)
         return stats, r[13:]
 

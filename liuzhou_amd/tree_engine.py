@@ -34,14 +34,16 @@ OUT_CAP = 80
 
 
 class LzTreeDesc(C.Structure):
-    _fields_ = [("num_games", C.c_int64), ("node_cap", C.c_int32), ("edge_cap", C.c_int32), ("path_cap", C.c_int32),
-                ("reserved", C.c_int32), ("exploration_weight", C.c_double)] + \
+    _fields_ = [("num_games", C.c_int64), ("node_cap", C.c_int32), ("edge_chunk", C.c_int32), ("path_cap", C.c_int32),
+                ("chunk_cap", C.c_int32), ("exploration_weight", C.c_double)] + \
                [(n, C.c_void_p) for n in (
                    "root_state", "nodes", "edges", "n_nodes", "n_edges", "root_visits", "root_w",
                    "root_init_value", "path", "path_len", "leaf_kind", "leaf_state", "leaf_value", "root_terminal",
                    "active", "leaf_edge", "leaf_parent",
                    "trace_kind", "trace_leaf", "trace_heads", "trace_priors", "trace_value")] + \
-               [("trace_cap", C.c_int64), ("eval_count", C.c_void_p)]
+               [("trace_cap", C.c_int64), ("eval_count", C.c_void_p)] + \
+               [(n, C.c_void_p) for n in ("chunk_list", "n_chunks", "free_chunks", "pool_top", "pool_stats")] + \
+               [("pool_chunks", C.c_int64)]
 
 
 class LzTreeWaveDesc(C.Structure):
@@ -52,28 +54,57 @@ class LzTreeWaveDesc(C.Structure):
 
 
 WAVE_PATH_CAP = 64             # entries per leaf path of a wave (the kernel follows descents up to 48 levels)
-REUSE_EDGES_PER_NODE = 40      # arena sizing for kept subtrees (average fan-out is ~25; overflow drops the subtree)
+EDGE_CHUNK = 1024              # edges per chunk of the engine's edge pool (32 KB); a run of <= 72 edges never straddles chunks
+POOL_EDGES_PER_NODE = 40       # pool sizing: mean fan-out is ~25 (placement <= 36, movement ~20-30), 40 leaves 60 % head-room
+POOL_NODES_PER_SIM = 4         # pool sizing: a game's tree (kept subtree + new search) averages < 2 x sims nodes
+MAX_NODE_CAP = 65536           # lz_tree_advance marks a game's nodes in LDS: 1024 words of 64
+PATH_CAP = 192                 # a game lasts <= 144 plies (game_state.py:87-89), so no descent is deeper than that
+REUSE_FACTOR_CAP = 40.0
 
 
-def auto_reuse_factor(num_games: int, sims: int, device, memory_fraction: float = 0.80, cap: float = 16.0) -> float:
-    """Room for kept subtrees, as a multiple of `sims` nodes per game: as much as fits in `memory_fraction` of the
-    device's free memory (a kept subtree that would leave no room for the next search is dropped, so more room = fewer
-    deviations from the reference's unbounded tree; measured on C2: 2 425 / 224 / 12 / 0 drops per 1.2 M moves at
-    factor 3 / 6 / 10 / 16; C3: 278 per 0.5 M moves at factor 4, 0-3 at 10.75), at most `cap` and at most what 16 384 nodes per game
-    allow.  The arenas are the one large consumer of the 288 GB: nothing else on the path needs more than a few GB."""
+def auto_reuse_factor(num_games: int, sims: int, device, memory_fraction: float = 0.10, cap: float = REUSE_FACTOR_CAP) -> float:
+    """Room for kept subtrees in the per-game NODE arena, as a multiple of `sims` nodes: a kept subtree that would leave
+    no room for the next search is pruned, so more room = fewer deviations from the reference's unbounded tree (runs of
+    near-forced moves keep almost the whole tree several times in a row).  Since round 4 only the 48-byte node records
+    are per game (edges come from the engine's pool), so the factor is `cap` unless `memory_fraction` of the free memory
+    or the 65 536-node limit say less (C3: 40 -> 32 802 nodes = 1.5 MB per game, 25.8 GB; rounds 1-3 had worst-case edge
+    regions per game and reached 11-12 with 210 GB)."""
     free, _total = torch.cuda.mem_get_info(torch.device(device))
     per_game = free * float(memory_fraction) / max(1, int(num_games))
-    base = (sims + 2) * 48 + (sims + 1) * MAX_CHILDREN * 32 + (sims + 3) * 4
-    per_factor = sims * (48 + REUSE_EDGES_PER_NODE * 32 + 4)
-    f = (per_game - base) / max(1, per_factor)
-    f = min(float(cap), f, (16384 - sims - 2) / max(1, sims))
+    f = (per_game / 48.0 - (sims + 2)) / max(1, sims)
+    f = min(float(cap), f, (MAX_NODE_CAP - sims - 2) / max(1, sims))
     return max(1.0, float(int(f * 4) / 4.0))
+
+
+def chunk_cap_for(node_cap: int, chunk: int) -> int:
+    """Entries of a game's chunk list: the worst case of its node arena (72 children everywhere), so that only the node
+    arena bounds a single game (include/liuzhou_hip.h)."""
+    return -(-int(node_cap) * MAX_CHILDREN // (int(chunk) - (MAX_CHILDREN - 1))) + 1
+
+
+def auto_pool_chunks(num_games: int, max_sims: int, node_cap: int, chunk: int, device, memory_fraction: float = 0.5) -> int:
+    """Chunks of the engine's edge pool.  Never more than the worst case (every node of every game with 72 children:
+    then an allocation cannot fail, which is what small engines get); large engines get the MEAN case with head-room --
+    POOL_NODES_PER_SIM x sims nodes x POOL_EDGES_PER_NODE edges per game, at least 64 worst-case games -- because the sum
+    over thousands of games is stable although single games vary by 20x; bounded by `memory_fraction` of the free memory
+    and by the 2^31 pool indices (64 GB)."""
+    worst = int(num_games) * chunk_cap_for(node_cap, chunk)
+    # per game: the mean case rounded up to whole chunks, + 1 for the open, partly filled chunk every game holds
+    mean = int(num_games) * (-(-min(int(node_cap), POOL_NODES_PER_SIM * (int(max_sims) + 1)) * POOL_EDGES_PER_NODE // int(chunk)) + 1)
+    floor = min(int(num_games), 64) * chunk_cap_for(node_cap, chunk)
+    n = min(worst, max(mean, floor))
+    free, _total = torch.cuda.mem_get_info(torch.device(device))
+    n = min(n, int(free * float(memory_fraction)) // (int(chunk) * 32), (1 << 31) // int(chunk) - 2)
+    return max(n, 2)
 
 
 class TreeEngine:
     def __init__(self, num_games: int, max_sims: int, device, exploration_weight: float = 1.0,
-                 reuse_factor: float = 0.0, batch_k: int = 1) -> None:
-        """`reuse_factor` > 0 reserves room for kept subtrees of up to reuse_factor * max_sims nodes (advance()).
+                 reuse_factor: float = 0.0, batch_k: int = 1, edge_chunk: int = EDGE_CHUNK,
+                 pool_chunks: Optional[int] = None) -> None:
+        """`reuse_factor` > 0 reserves room for kept subtrees of up to reuse_factor * max_sims nodes in every game's node
+        arena (advance(); < 0: auto_reuse_factor).  Edges live in ONE pool per engine, handed out in chunks of `edge_chunk`
+        records (`pool_chunks`: None = auto_pool_chunks).
         `batch_k` > 1: the legacy search's waves (src/mcts.py `batch_K`): up to batch_k distinct leaves per game are
         collected, evaluated together and backed up per wave (select_wave / expand_wave / search)."""
         dev = torch.device(device)
@@ -86,24 +117,37 @@ class TreeEngine:
         self.reuse_factor = float(reuse_factor)
         extra = int(max(0.0, float(reuse_factor)) * self.max_sims)
         self.node_cap = self.max_sims + 2 + extra
-        self.edge_cap = (self.max_sims + 1) * MAX_CHILDREN + extra * REUSE_EDGES_PER_NODE
-        self.path_cap = self.node_cap + 1
-        if extra and self.node_cap > 16384:
-            raise ValueError(f"subtree reuse supports at most 16384 nodes per game, got {self.node_cap}")
+        self.path_cap = min(self.node_cap + 1, PATH_CAP)
+        if self.node_cap > MAX_NODE_CAP:
+            raise ValueError(f"at most {MAX_NODE_CAP} nodes per game, got {self.node_cap}")
+        self.edge_chunk = int(edge_chunk)
+        if self.edge_chunk < 128 or self.edge_chunk & (self.edge_chunk - 1):
+            raise ValueError(f"edge_chunk must be a power of two >= 128, got {edge_chunk}")
+        self.chunk_cap = chunk_cap_for(self.node_cap, self.edge_chunk)
+        self.pool_chunks = int(pool_chunks) if pool_chunks is not None else \
+            auto_pool_chunks(B, self.max_sims, self.node_cap, self.edge_chunk, dev)
+        if (self.pool_chunks + 1) * self.edge_chunk > (1 << 31):
+            raise ValueError(f"edge pool of {self.pool_chunks} x {self.edge_chunk} records exceeds 2^31 pool indices")
         z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)
         self.buf: Dict[str, torch.Tensor] = {
             "root_state": z((B, 4), torch.int64),
             "nodes": z((B * self.node_cap, 6), torch.int64),            # 48-byte node records
-            "edges": z((B * self.edge_cap, 4), torch.int64),            # 32-byte edge records
+            "edges": torch.empty((self.pool_chunks * self.edge_chunk, 4), dtype=torch.int64, device=dev),   # 32-byte records
             "n_nodes": z((B,), torch.int32), "n_edges": z((B,), torch.int32), "root_visits": z((B,), torch.int32),
             "root_w": z((B,), torch.float64), "root_init_value": z((B,), torch.float32),
             "path": z((B * self.path_cap,), torch.int32), "path_len": z((B,), torch.int32),
             "leaf_kind": z((B,), torch.int32), "leaf_state": z((B, 4), torch.int64), "leaf_value": z((B,), torch.float32),
             "root_terminal": z((B,), torch.uint8), "active": torch.ones((B,), dtype=torch.uint8, device=dev),
             "leaf_edge": z((B,), torch.int32), "leaf_parent": z((B,), torch.int32),
+            "chunk_list": z((B * self.chunk_cap,), torch.int32), "n_chunks": z((B,), torch.int32),
+            "free_chunks": torch.arange(self.pool_chunks, dtype=torch.int32, device=dev),
+            "pool_top": torch.full((1,), self.pool_chunks, dtype=torch.int32, device=dev),
+            # [0] expansions refused because the pool was empty (0 in a correctly sized engine), [1] fewest free chunks seen
+            "pool_stats": torch.tensor([0, self.pool_chunks], dtype=torch.int32, device=dev),
         }
         d = LzTreeDesc()
-        d.num_games, d.node_cap, d.edge_cap, d.path_cap = B, self.node_cap, self.edge_cap, self.path_cap
+        d.num_games, d.node_cap, d.edge_chunk, d.path_cap = B, self.node_cap, self.edge_chunk, self.path_cap
+        d.chunk_cap, d.pool_chunks = self.chunk_cap, self.pool_chunks
         d.exploration_weight = float(exploration_weight)
         for name, t in self.buf.items():
             setattr(d, name, t.data_ptr())
@@ -171,20 +215,40 @@ class TreeEngine:
         self.desc.trace_cap = n
         return self.trace
 
-    def root_edge_records(self, g: int):
-        """The root's edge records of game g, read from the arena (host copy: inspection / adapters, not the hot loop):
-        list of {action_index, prior, visit_count, value_sum (child mover's side), child_white, terminal}."""
+    _NODE_DT = [("w0", "<u8"), ("w1", "<u8"), ("w2", "<u8"), ("w3", "<u8"), ("edge_begin", "<i4"), ("nedges", "<i4"),
+                ("parent", "<i4"), ("old_begin", "<i4")]
+    _EDGE_DT = [("W", "<f8"), ("P", "<f4"), ("n_info", "<u4"), ("child", "<i4"), ("cbegin", "<i4"),
+                ("act", "u1"), ("cn", "u1"), ("pad", "V6")]
+
+    def game_nodes(self, g: int, count: Optional[int] = None):
+        """Host copy of game g's node records (numpy structured array; inspection / tests, not the hot loop)."""
         import numpy as np
-        node = self.buf["nodes"].view(self.B, self.node_cap, 6)[g, 0].cpu().numpy()
-        e0, ne = int(node[4] & 0xFFFFFFFF), int(np.int32(node[4] >> 32))
+        nn = int(self.buf["n_nodes"][g]) if count is None else int(count)
+        return self.buf["nodes"].view(self.B, self.node_cap, 6)[g, :nn].contiguous().cpu().numpy().view(np.dtype(self._NODE_DT)).reshape(nn)
+
+    def edge_run(self, begin: int, count: int):
+        """Host copy of `count` edge records from pool index `begin` (a node's run: Node.edge_begin / nedges)."""
+        import numpy as np
+        return self.buf["edges"][int(begin):int(begin) + int(count)].contiguous().cpu().numpy().view(np.dtype(self._EDGE_DT)).reshape(int(count))
+
+    def root_edge_records(self, g: int):
+        """The root's edge records of game g, read from the pool (host copy: inspection / adapters, not the hot loop):
+        list of {action_index, prior, visit_count, value_sum (child mover's side), child_white, terminal}."""
+        node = self.game_nodes(g, 1)[0]
+        e0, ne = int(node["edge_begin"]), int(node["nedges"])
         if ne <= 0:
             return []
-        dt = np.dtype([("W", "<f8"), ("P", "<f4"), ("n_info", "<u4"), ("child", "<i4"), ("cbegin", "<i4"),
-                       ("act", "u1"), ("cn", "u1"), ("owner", "<u2"), ("pad", "V4")])
-        recs = self.buf["edges"].view(self.B, self.edge_cap, 4)[g, e0:e0 + ne].contiguous().cpu().numpy().view(dt).reshape(ne)
+        recs = self.edge_run(e0, ne)
         return [{"action_index": int(r["act"]), "prior": float(r["P"]), "visit_count": int(r["n_info"] & 0xFFFFFF),
                  "value_sum": float(r["W"]), "child_white": bool((r["n_info"] >> 24) & 1),
                  "terminal": bool((r["n_info"] >> 24) & 2)} for r in recs]
+
+    def pool_status(self) -> Dict[str, int]:
+        """Edge pool: chunks, free now, fewest free seen since construction, refused expansions (must stay 0)."""
+        refused, low = (int(v) for v in self.buf["pool_stats"].tolist())
+        return {"chunks": self.pool_chunks, "chunk_edges": self.edge_chunk, "free": int(self.buf["pool_top"].item()),
+                "fewest_free": low, "refused_expansions": refused,
+                "bytes": self.pool_chunks * self.edge_chunk * 32}
 
     def hbm_bytes(self) -> int:
         return sum(t.numel() * t.element_size() for t in self.buf.values())
@@ -295,7 +359,8 @@ class TreeEngine:
         sims = self.max_sims if next_sims is None else int(next_sims)
         with torch.cuda.device(self.device):
             L.check(L.lib().lz_tree_advance(C.byref(self.desc), L.ptr(pa), L.ptr(reset), L.i64(sims),
-                                            L.ptr(self.reuse_dropped), self._stream()), "tree_advance")
+                                            L.ptr(self.reuse_dropped[0:1]), L.ptr(self.reuse_dropped[1:2]),
+                                            self._stream()), "tree_advance")
 
     def search(self, net: FusedNet, sims: int, noise: Optional[torch.Tensor] = None, epsilon: float = 0.25,
                continue_trees: bool = False) -> None:
@@ -312,12 +377,19 @@ class TreeEngine:
             if self._cu_slots is None:
                 self._cu_slots = torch.zeros((4096,), dtype=torch.int32, device=self.device)
             with torch.cuda.device(self.device):
-                L.check(L.lib().lz_tree_search_persistent(
+                rc = L.lib().lz_tree_search_persistent(
                     C.byref(self.desc), C.byref(net.desc), L.i64(sims), L.ptr(self.lp1), L.ptr(self.lp2), L.ptr(self.lpm),
                     L.ptr(self.values), L.ptr(noise), L.i64(nz_stride), C.c_float(float(epsilon)),
                     C.c_int(1 if continue_trees else 0), L.ptr(self._cu_slots), L.i64(self.stagger_us),
-                    L.ptr(self.phase_ticks), self._stream()), "tree_search_persistent")
-            return
+                    L.ptr(self.phase_ticks), self._stream())
+            if rc in (-2, -3) and not torch.cuda.is_current_stream_capturing():
+                # LZ_ERR_UNSUPPORTED / LZ_ERR_LAUNCH (e.g. the kernel's ~80 KB of dynamic LDS refused on this part): the
+                # header promises the launch-pair search as the fallback -- nothing has run yet, so take it, for good
+                print(f"[liuzhou_amd] persistent search kernel unavailable (status {rc}); using lz_tree_search", flush=True)
+                self.persistent = False
+            else:
+                L.check(rc, "tree_search_persistent")
+                return
         fn = L.lib().lz_tree_search_continue if continue_trees else L.lib().lz_tree_search
         with torch.cuda.device(self.device):
             L.check(fn(C.byref(self.desc), C.byref(net.desc), L.i64(sims), L.ptr(self.planes),
@@ -406,6 +478,7 @@ class PortableTreeMCTS:
                 raise ValueError("an external evaluator supports batch_k = 1 only")
             self._eval_device = None if isinstance(net, PriorEvaluator) else next(net.parameters()).device
         self.rng = GameRng(num_games, device, seed=seed, game_offset=game_offset, game_stride=game_stride)
+        self._game0 = self.rng.game.clone()
         self._uniforms = torch.zeros((self.engine.B,), dtype=torch.float32, device=self.engine.device)
         self.injected_noise: Optional[torch.Tensor] = None       # parity runs: [B, <= OUT_CAP] instead of the RNG's draws
         self.injected_uniforms: Optional[torch.Tensor] = None
@@ -580,6 +653,21 @@ class PortableTreeMCTS:
         """Forget the kept subtrees: the next search_batch starts every game from a fresh root."""
         self._have_trees = False
 
+    def reset_run(self, seed: int) -> None:
+        """A cached engine starts another run (self_play_tree_gpu called again with the same network and shape): fresh
+        trees, RNG keys and counters as after construction; arenas, descriptors and captured graphs are kept."""
+        self._have_trees = False
+        self.rng.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        self.rng.game.copy_(self._game0)
+        self.rng.ply.zero_()
+        self._root_evals = 0
+        self.extra_rounds = 0
+        self.engine.eval_count.zero_()
+        self.engine.reuse_dropped.zero_()
+        self.get_timing(reset=True)
+        if self.batch_k > 1:
+            self.engine.wbuf["eval_total"].zero_(); self.engine.wbuf["eval_count"].zero_()
+
     def prepare(self, state: GpuStateBatch) -> None:
         """Set-up outside any timed region: load every kernel and capture the graphs (a fresh search, and a continued
         one with subtree reuse) by searching `state` once or twice; the trees built here are thrown away."""
@@ -735,6 +823,10 @@ class DualStreamTreeMCTS:
         for p in self.parts:
             p.reset_trees()
 
+    def reset_run(self, seed: int) -> None:
+        for p in self.parts:
+            p.reset_run(seed)
+
     @property
     def graph_retry_off(self) -> bool:
         return any(p.graph_retry_off for p in self.parts)
@@ -852,6 +944,26 @@ class SteadyStateTreeSelfPlay:
         self.positions += self.B
 
 
+from collections import OrderedDict
+
+_ENGINE_CACHE: "OrderedDict[tuple, object]" = OrderedDict()
+
+
+def _engine_cache_limit() -> int:
+    """Search engines kept alive between self_play_tree_gpu calls (LZ_ENGINE_CACHE, default 1; 0 = off).  An engine owns
+    its arenas (C3: ~90 GB), so the default keeps only the last one."""
+    try:
+        return max(0, int(os.environ.get("LZ_ENGINE_CACHE", "1")))
+    except ValueError:
+        return 1
+
+
+def clear_engine_cache() -> None:
+    """Drop the cached engines (and give their arenas back to the allocator)."""
+    _ENGINE_CACHE.clear()
+    torch.cuda.empty_cache()
+
+
 def self_play_tree_gpu(model, num_games: int, mcts_simulations: int, temperature_init: float, temperature_final: float,
                        temperature_threshold: int, exploration_weight: float, device: str,
                        add_dirichlet_noise: bool = True, dirichlet_alpha: float = 0.3, dirichlet_epsilon: float = 0.25,
@@ -887,12 +999,35 @@ def self_play_tree_gpu(model, num_games: int, mcts_simulations: int, temperature
     if use_fused and persistent_search_available(net, batch_k):
         dual_stream = False                                  # the persistent kernel overlaps the phases inside every CU
     cls = DualStreamTreeMCTS if (dual_stream and use_fused and net.pack.channels == 64 and wave >= 2) else PortableTreeMCTS
-    mcts = cls(net, wave, mcts_simulations, dev, exploration_weight=exploration_weight,
-               add_dirichlet_noise=add_dirichlet_noise, dirichlet_alpha=dirichlet_alpha,
-               dirichlet_epsilon=dirichlet_epsilon, sample_moves=sample_moves, reuse_tree=reuse_tree,
-               reuse_factor=reuse_factor, policy_target_temperature=policy_target_temperature,
-               policy_target_prior_pseudocount=policy_target_prior_pseudocount, batch_k=batch_k, seed=seed,
-               collect_timing=collect_timing)
+    t_setup = time.perf_counter()
+    kw = dict(exploration_weight=float(exploration_weight), add_dirichlet_noise=bool(add_dirichlet_noise),
+              dirichlet_alpha=float(dirichlet_alpha), dirichlet_epsilon=float(dirichlet_epsilon),
+              sample_moves=bool(sample_moves), reuse_tree=bool(reuse_tree), reuse_factor=float(reuse_factor),
+              policy_target_temperature=policy_target_temperature,
+              policy_target_prior_pseudocount=float(policy_target_prior_pseudocount), batch_k=int(batch_k),
+              collect_timing=bool(collect_timing))
+    # Engines (arenas, descriptors) and their captured graphs are kept between calls with the same network buffers and
+    # shape -- the worker calls this once per chunk and the staged loop once per iteration, and construction + capture
+    # were 12.5 % of a C2 run.  `FusedNet.refresh()` writes new weights into the same buffers, so a
+    # cached graph stays valid across checkpoints.  A PriorEvaluator / external module is never cached.
+    key = None
+    if use_fused and _engine_cache_limit() > 0:
+        key = (cls.__name__, int(net.pack.wfrag.data_ptr()), int(net.pack.fparams.data_ptr()), int(net.desc.flags),
+               str(dev), wave, int(mcts_simulations), tuple(sorted((k, repr(v)) for k, v in kw.items())),
+               os.environ.get("LZ_TREE_GRAPH", "on"), os.environ.get("LZ_TREE_PERSISTENT", "0"))
+    mcts = _ENGINE_CACHE.pop(key, None) if key is not None else None
+    cache_hit = mcts is not None
+    if mcts is None:
+        if key is not None:
+            while len(_ENGINE_CACHE) >= _engine_cache_limit():      # make room BEFORE allocating the new arenas
+                _ENGINE_CACHE.popitem(last=False)
+            torch.cuda.empty_cache()
+        mcts = cls(net, wave, mcts_simulations, dev, seed=seed, **kw)
+    else:
+        mcts.reset_run(seed)
+    if key is not None:
+        _ENGINE_CACHE[key] = mcts
+    setup_sec = time.perf_counter() - t_setup
     buffer = TensorTrajectoryBuffer(dev, TOTAL_ACTION_DIM, max_steps_hint=max_game_plies, concurrent_games_hint=wave)
     outcome = torch.zeros((3,), dtype=torch.int64, device=dev)
     lengths = torch.zeros((int(num_games),), dtype=torch.int64, device=dev)
@@ -962,7 +1097,10 @@ def self_play_tree_gpu(model, num_games: int, mcts_simulations: int, temperature
     elapsed = max(1e-9, time.perf_counter() - started)
     if tail is not None:
         tail.check_overflow()
+    t_build = time.perf_counter()
     batch = buffer.build()
+    torch.cuda.synchronize(dev)
+    build_sec = time.perf_counter() - t_build
     o = outcome.tolist()
     hist = delta_hist.tolist() if delta_hist is not None else []
     keys = ("root_puct_ms", "pack_writeback_ms", "self_play_step_ms", "finalize_ms")
@@ -982,6 +1120,9 @@ def self_play_tree_gpu(model, num_games: int, mcts_simulations: int, temperature
         # the device-tail loop runs one fully masked ply per wave after the last game has ended (wave_tail.WaveTail.run)
         mcts_counters={"leaf_eval_count": int(mcts.leaf_evals) - (wasted_plies * wave * (int(mcts_simulations) + 1)
                                                                   if int(batch_k) <= 1 else 0),
-                       "masked_extra_plies": wasted_plies, "graph_retry_off": int(bool(mcts.graph_retry_off))},
+                       "masked_extra_plies": wasted_plies, "graph_retry_off": int(bool(mcts.graph_retry_off)),
+                       # where the wall time outside `elapsed_sec` (the plies) goes: engine construction or cache hit,
+                       # build() of the five tensors; graph capture happens inside the first plies
+                       "engine_cache_hit": int(cache_hit), "setup_ms": int(setup_sec * 1e3), "build_ms": int(build_sec * 1e3)},
         piece_delta_buckets={str(d - 18): int(v) for d, v in enumerate(hist)}, device=str(dev))
     return batch, stats

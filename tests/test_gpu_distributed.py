@@ -139,3 +139,55 @@ def test_bench_two_ranks_with_gather_in_the_timed_region():
     g = out["gather"]
     assert g["rows_on_rank0"] == 2 * 256 * 4 and g["record_bytes"] == 360 and g["bytes_received"] == 256 * 4 * 360
     assert "gathered to rank 0" in out["config"]["workload"] and out["config"]["workload"].startswith("C4")
+
+
+def _staged_loop(world, overlap, iterations=3, games=48, plies=6, extra=()):
+    """scripts/staged_loop.py with `world` ranks on cuda:0 (gloo group, records / checkpoint staged through host memory):
+    ranks 0..world-2 play, rank world-1 trains and does not play."""
+    import json
+    import subprocess
+    import sys
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    env.update(LZ_DIST_BACKEND="gloo", LZ_SHARE_GPU="1", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(root, "scripts", "staged_loop.py"), "--iterations", str(iterations), "--games-per-gpu", str(games),
+           "--sims", "8", "--max-game-plies", str(plies), "--batch-size", "128", "--overlap", str(overlap), *extra]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                     # one JSON line, from the trainer rank
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("world,overlap", [(2, 0), (3, 0), (3, 1)])
+def test_staged_loop_multi_rank_trainer_does_not_play(world, overlap):
+    """C5's world > 1 branches: the trainer rank joins the gather with an empty batch and is its destination, every player
+    re-packs the broadcast checkpoint into its live FusedNet buffers.  A game cannot end within 6 plies (placement
+    phase), so every player contributes exactly games x plies rows per iteration."""
+    games, plies, its = 48, 6, 3
+    out = _staged_loop(world, overlap, iterations=its, games=games, plies=plies)
+    assert out["world_size"] == world and out["trainer_rank"] == world - 1 and out["backend"] == "gloo"
+    assert out["player_ranks"] == list(range(world - 1)) and out["overlap"] == overlap
+    log = out["iterations"]
+    assert len(log) == its
+    for e in log:
+        assert e["positions"] == (world - 1) * games * plies
+        assert e["weights_equal_on_all_ranks"] is True           # players' packed device weights == the trainer's model
+    digests = [e["weights_digest"] for e in log]
+    if overlap:
+        # lag-1: iteration 1 has nothing to train on yet (hand-off of the initial weights), then generation i-1 each time
+        assert log[0]["train_samples"] == 0 and all(e["train_samples"] == (world - 1) * games * plies for e in log[1:])
+        assert len(set(digests[1:])) == its - 1 and digests[1] != digests[0]
+        assert out["tail"]["train_samples"] == (world - 1) * games * plies and out["tail"]["avg_loss"] is not None
+    else:
+        assert all(e["train_samples"] == (world - 1) * games * plies for e in log)
+        assert len(set(digests)) == its                           # the checkpoint changes every iteration
+        assert out["tail"] is None
+    assert all(e["avg_loss"] is not None for e in log if e["train_samples"])
+    assert out["steady_state_positions_per_sec"] > 0

@@ -221,8 +221,8 @@ def test_mcts_core_root_noise_is_fresh_for_every_root():
     assert priors[0] != priors[1] and priors[1] != priors[2] and priors[0] != priors[2]
     # a large simulation budget is refused with a clear message instead of an arena error deep inside the engine
     big = v0_core.MCTSConfig()
-    big.device, big.num_simulations = DEV, 5000
+    big.device, big.num_simulations = DEV, 20000
     core2 = v0_core.MCTSCore(big)
     core2.set_forward_callback(forward)
-    with pytest.raises(ValueError, match="16384"):
+    with pytest.raises(ValueError, match="65536"):
         core2.set_root_state(_state_like(st, 10))

@@ -244,6 +244,38 @@ def test_root_puct_visit_counts_bit_exact(v0):
     assert np.array_equal(v.cpu().numpy(), z["visits_64_c25"])
 
 
+@pytest.mark.parametrize("A,sims", [(36, 1024), (72, 8192), (130, 3000), (25, 65536)])
+def test_root_puct_table_kernel_equals_division_kernel(v0, A, sims, monkeypatch):
+    """The table-driven pulls (sqrt table, x / integer as a double product: csrc/lz_ops.hip::puct_pulls) against the plain
+    IEEE-division kernel (LZ_ROOT_PUCT_DIV=1), bit for bit on visits AND value sums, over ordinary rows and rows built to
+    hurt: equal scores, zero / negative / huge / NaN / -inf entries, and magnitudes below 2^-100 (those rows must take
+    the division branch of the new kernel)."""
+    rng = np.random.default_rng(1000 + A)
+    R = 96 if sims > 10000 else 384
+    valid = rng.random((R, A)) < 0.6
+    valid[:, rng.integers(0, A)] = True
+    pri = (rng.random((R, A)) ** 3 * valid).astype(np.float32)
+    pri /= np.maximum(pri.sum(1, keepdims=True), 1e-8)
+    leaf = ((rng.random((R, A)) * 2 - 1) * valid).astype(np.float32)
+    pri[0] = 1.0 / A; leaf[0] = 0.25; valid[0] = True                       # every score ties at every pull
+    leaf[1] = 0.0; pri[2] = 0.0                                              # q == 0 everywhere / u == 0 everywhere
+    leaf[3, :3] = [-1.0, 1.0, -0.0]; pri[3, :3] = [0.5, 1e-30, 0.25]
+    pri[4, 0] = np.float32(1e-40); leaf[4, 1] = np.float32(3e-39)           # denormal inputs: division branch
+    pri[5, 0] = np.float32(2.0 ** -110); leaf[5, 2] = np.float32(-2.0 ** -120)
+    pri[6, 0] = np.nan; pri[6, 1] = np.inf; leaf[7, 0] = -np.inf; leaf[8, 0] = np.nan
+    pri[9] = 3e38; leaf[10] = -3e38
+    valid[4:11, :3] = True
+    args = [torch.from_numpy(x).to(DEV) for x in (pri, leaf, valid)]
+    monkeypatch.delenv("LZ_ROOT_PUCT_DIV", raising=False)
+    v_t, vs_t, rv_t = (t.cpu().numpy() for t in v0.root_puct_allocate_visits(*args, sims, 1.5))
+    monkeypatch.setenv("LZ_ROOT_PUCT_DIV", "1")
+    v_d, vs_d, rv_d = (t.cpu().numpy() for t in v0.root_puct_allocate_visits(*args, sims, 1.5))
+    assert np.array_equal(v_t, v_d)
+    assert vs_t.tobytes() == vs_d.tobytes() and rv_t.tobytes() == rv_d.tobytes()
+    live = np.isfinite(v_t).all(1)
+    assert (v_t[live].sum(1) <= sims).all() and (v_t[0].sum() == sims)
+
+
 @pytest.mark.parametrize("A", [5, 64, 72, 130])
 def test_root_puct_random_vs_oracle(v0, A):
     rng = np.random.default_rng(A)

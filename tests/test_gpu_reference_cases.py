@@ -31,10 +31,15 @@ def _engine_with_root_edges(actions, visits, q_root_side, priors):
     edges["W"] = -np.asarray(q_root_side, np.float64) * np.asarray(visits, np.float64)
     edges["child"] = -1
     node = eng.buf["nodes"].view(1, eng.node_cap, 6)[0, :1].cpu().numpy().view(NODE_DT).copy()
+    # the root's run at the start of chunk 0 of the edge pool, booked as the game's first chunk
     node["edge_begin"], node["nedges"], node["parent"] = 0, n, -1
     eng.buf["nodes"].view(1, eng.node_cap, 6)[0, :1] = torch.from_numpy(node.view(np.int64).reshape(1, 6)).to(DEV)
-    eng.buf["edges"].view(1, eng.edge_cap, 4)[0, :n] = torch.from_numpy(edges.view(np.int64).reshape(n, 4)).to(DEV)
+    eng.buf["edges"][:n] = torch.from_numpy(edges.view(np.int64).reshape(n, 4)).to(DEV)
     eng.buf["n_edges"].fill_(n)
+    eng.buf["chunk_list"][0] = 0
+    eng.buf["n_chunks"].fill_(1)
+    eng.buf["free_chunks"].copy_(torch.roll(torch.arange(eng.pool_chunks, dtype=torch.int32, device=DEV), -1))
+    eng.buf["pool_top"].fill_(eng.pool_chunks - 1)
     eng.buf["root_visits"].fill_(int(np.sum(visits)))
     eng.buf["root_w"].fill_(float(np.sum(np.asarray(q_root_side) * np.asarray(visits))))
     eng.buf["root_terminal"].zero_()

@@ -121,6 +121,48 @@ def test_tree_self_play_runner_dual_stream_matches_contract():
         assert stats.mcts_counters["leaf_eval_count"] == 120 * 9 * 24      # 72 plies x all 40 slots x (8 sims + root)
 
 
+def test_tree_runner_engine_cache_gives_identical_games_and_follows_refreshed_weights():
+    """self_play_tree_gpu keeps its engine + captured graphs between calls with the same network buffers and shape (the
+    worker calls it per chunk, the staged loop per iteration): a second call is a cache hit and plays bit-identical games
+    for the same seed, other games for another seed; `FusedNet.refresh` writes a new checkpoint into the same buffers, so
+    the cached graph searches with the NEW weights; another shape or LZ_ENGINE_CACHE=0 builds a fresh engine."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from liuzhou_amd import tree_engine as TE
+    from liuzhou_amd.net import ChessNet, MODEL_CONFIGS
+    from liuzhou_amd.net_hip import FusedNet
+    TE.clear_engine_cache()
+    torch.manual_seed(3)
+    model = ChessNet(**MODEL_CONFIGS["b6c64"]).eval().to("cuda:0")
+    net = FusedNet(model)
+    kw = dict(num_games=48, mcts_simulations=10, temperature_init=1.0, temperature_final=0.1, temperature_threshold=10,
+              exploration_weight=1.0, device="cuda:0", max_game_plies=12, concurrent_games=32)
+    fields = ("state_tensors", "legal_masks", "policy_targets", "value_targets", "soft_value_targets")
+    same = lambda a, b: all(torch.equal(getattr(a, f), getattr(b, f)) for f in fields)
+    b1, s1 = TE.self_play_tree_gpu(net, seed=77, **kw)
+    b2, s2 = TE.self_play_tree_gpu(net, seed=77, **kw)
+    b3, s3 = TE.self_play_tree_gpu(net, seed=78, **kw)
+    assert (s1.mcts_counters["engine_cache_hit"], s2.mcts_counters["engine_cache_hit"], s3.mcts_counters["engine_cache_hit"]) == (0, 1, 1)
+    assert b1.num_samples == b2.num_samples == 48 * 12 and same(b1, b2) and not same(b1, b3)
+    assert s2.mcts_counters["leaf_eval_count"] == s1.mcts_counters["leaf_eval_count"]
+    engine = next(iter(TE._ENGINE_CACHE.values()))
+    assert engine.engine.pool_status()["refused_expansions"] == 0
+    # new weights into the same device buffers: the cached engine must play what a fresh engine plays with them
+    torch.manual_seed(4)
+    model2 = ChessNet(**MODEL_CONFIGS["b6c64"]).eval().to("cuda:0")
+    net.refresh(model2)
+    b4, s4 = TE.self_play_tree_gpu(net, seed=77, **kw)
+    assert s4.mcts_counters["engine_cache_hit"] == 1 and not same(b1, b4)
+    TE.clear_engine_cache()
+    b5, s5 = TE.self_play_tree_gpu(FusedNet(model2), seed=77, **kw)
+    assert s5.mcts_counters["engine_cache_hit"] == 0 and same(b4, b5)
+    # another shape evicts (limit 1), the old shape then misses
+    TE.self_play_tree_gpu(net, seed=77, **{**kw, "concurrent_games": 16})
+    assert len(TE._ENGINE_CACHE) == 1
+    TE.clear_engine_cache()
+    assert len(TE._ENGINE_CACHE) == 0
+
+
 @pytest.mark.parametrize("sims,use_graph", [(1, False), (64, False), (200, True)])
 def test_fused_root_search_equals_operator_chain(sims, use_graph):
     """FusedRootSearch (two fixed-shape kernels around the network launches, no host sync) == V1RootMCTS.search_batch

@@ -204,15 +204,17 @@ def test_advance_prunes_a_subtree_that_does_not_fit_instead_of_dropping_it():
     adds exactly `sims` visits."""
     _need_gpu()
     from liuzhou_amd.tree_engine import TreeEngine
-    from tests.tree_parity import hash_evaluator, unpack_packed, EDGE_DT, NODE_DT
+    from tests.tree_parity import hash_evaluator, unpack_packed, game_tree
     from oracle import lz_oracle as O
     z = load("g1_rules.npz")
     st = states(z, "s")
     idx = np.random.default_rng(11).integers(0, st["board"].shape[0], 24)
     cur = {f: np.ascontiguousarray(np.asarray(st[f])[idx]) for f in FIELDS}
     B, sims = 24, 320
-    eng = TreeEngine(B, sims, DEV, 1.0, reuse_factor=0.3)         # room for 96 kept nodes: most kept subtrees are larger
-    node_budget, edge_budget = eng.node_cap - (sims + 1), eng.edge_cap - (sims + 1) * 72
+    # room for 96 kept nodes: most kept subtrees are larger; chunks of 128 edges, so that every few expansions take a
+    # new chunk from the pool and the compaction of a kept subtree crosses many chunk boundaries
+    eng = TreeEngine(B, sims, DEV, 1.0, reuse_factor=0.3, edge_chunk=128)
+    node_budget = eng.node_cap - (sims + 1)
 
     def search(first):
         for s in range(sims + 1):
@@ -224,10 +226,24 @@ def test_advance_prunes_a_subtree_that_does_not_fit_instead_of_dropping_it():
         eng.finish(torch.full((B,), 0.1, device=DEV), None)
 
     def arena(g):
-        nn, ne = int(eng.buf["n_nodes"][g]), int(eng.buf["n_edges"][g])
-        nodes = eng.buf["nodes"].view(B, eng.node_cap, 6)[g, :nn].contiguous().cpu().numpy().view(NODE_DT).reshape(nn)
-        edges = eng.buf["edges"].view(B, eng.edge_cap, 4)[g, :ne].contiguous().cpu().numpy().view(EDGE_DT).reshape(ne)
-        return nodes, edges
+        return game_tree(eng, g)
+
+    def chunks_consistent():
+        """Every chunk is either free or owned by exactly one game; every run lies inside one chunk its game owns."""
+        nc = eng.buf["n_chunks"].cpu().numpy()
+        lists = eng.buf["chunk_list"].view(B, eng.chunk_cap).cpu().numpy()
+        top = int(eng.buf["pool_top"].item())
+        free = eng.buf["free_chunks"].cpu().numpy()[:top].tolist()
+        owned = [c for g in range(B) for c in lists[g, :nc[g]].tolist()]
+        assert len(set(free)) == len(free) and len(set(owned)) == len(owned) and not (set(free) & set(owned))
+        assert len(free) + len(owned) == eng.pool_chunks
+        for g in range(B):
+            mine = set(lists[g, :nc[g]].tolist())
+            nodes, _runs = game_tree(eng, g)
+            for nd in nodes:
+                e0, n = int(nd["edge_begin"]), int(nd["nedges"])
+                if n > 0:
+                    assert e0 // eng.edge_chunk in mine and (e0 + n - 1) // eng.edge_chunk == e0 // eng.edge_chunk
 
     eng.set_roots(to_gpu_batch(cur, DEV)); eng.begin(); search(True)
     pruned_total = 0
@@ -241,30 +257,27 @@ def test_advance_prunes_a_subtree_that_does_not_fit_instead_of_dropping_it():
         eng.set_roots(to_gpu_batch(cur, DEV))
         eng.advance()
         kind = eng.buf["leaf_kind"].cpu().numpy()
+        chunks_consistent()
         for g in range(B):
-            nodes, edges = arena(g)
+            nodes, runs = arena(g)
             if kind[g] != 3:
                 continue
-            assert nodes.size <= node_budget and edges.size <= edge_budget
-            # structure: runs inside the arena, owners / parents / child links consistent, ids ascend from parent to child
+            assert nodes.size <= node_budget
+            # structure: parents / child links consistent, ids ascend from parent to child, child runs where the edge says
             for i, nd in enumerate(nodes):
-                e0, n = int(nd["edge_begin"]), int(nd["nedges"])
-                assert n >= 1 and e0 >= 0 and e0 + n <= edges.size
-                assert (edges["owner"][e0:e0 + n] == i).all()
+                n = int(nd["nedges"])
+                assert n >= 1 and len(runs[i]) == n
                 assert int(nd["parent"]) == (-1 if i == 0 else int(nd["parent"])) and int(nd["parent"]) < i
-                for e in edges[e0:e0 + n]:
+                for e in runs[i]:
                     c = int(e["child"])
                     if c >= 0:
                         assert i < c < nodes.size and int(nodes[c]["parent"]) == i
                         assert int(e["cbegin"]) == int(nodes[c]["edge_begin"]) and int(e["cn"]) == int(nodes[c]["nedges"])
             # the new root's own statistics are the played child's, bit for bit (action, N | info, W, P)
-            onodes, oedges = before[g]
-            r0 = onodes[0]
-            run = oedges[int(r0["edge_begin"]):int(r0["edge_begin"]) + int(r0["nedges"])]
-            ce = run[run["act"] == chosen[g]][0]
-            oc = onodes[int(ce["child"])]
-            want = oedges[int(oc["edge_begin"]):int(oc["edge_begin"]) + int(oc["nedges"])]
-            got = edges[int(nodes[0]["edge_begin"]):int(nodes[0]["edge_begin"]) + int(nodes[0]["nedges"])]
+            onodes, oruns = before[g]
+            ce = oruns[0][oruns[0]["act"] == chosen[g]][0]
+            want = oruns[int(ce["child"])]
+            got = runs[0]
             for f in ("act", "n_info", "W", "P"):
                 assert got[f].tobytes() == want[f].tobytes(), (move, g, f)
             assert int(eng.buf["root_visits"][g]) == int(ce["n_info"] & 0xFFFFFF)
@@ -419,7 +432,7 @@ def test_tree_engine_degenerate_sizes():
     d.num_games = 0
     z = torch.zeros(8, device=DEV)
     assert L.lib().lz_tree_begin(C.byref(d), None) == 0 and L.lib().lz_tree_select(C.byref(d), None) == 0
-    assert L.lib().lz_tree_advance(C.byref(d), None, None, L.i64(4), None, None) == 0
+    assert L.lib().lz_tree_advance(C.byref(d), None, None, L.i64(4), None, None, None) == 0
     assert L.lib().lz_tree_expand(C.byref(d), C.c_int(1), None, None, None, L.ptr(z), L.ptr(z), None, L.i64(0), C.c_float(0.25), None) == 0
     # invalid descriptors are refused, not launched
     d.num_games = 1
@@ -427,21 +440,63 @@ def test_tree_engine_degenerate_sizes():
     assert L.lib().lz_tree_begin(C.byref(d), None) == -1
     d.nodes = eng.desc.nodes
     d.node_cap = 70000
-    assert L.lib().lz_tree_advance(C.byref(d), None, None, L.i64(4), None, None) == -2      # > 16384 nodes: unsupported
+    assert L.lib().lz_tree_advance(C.byref(d), None, None, L.i64(4), None, None, None) == -2      # > 65536 nodes: unsupported
+    d.node_cap = eng.desc.node_cap
+    d.edge_chunk = 100                                           # not a power of two
+    assert L.lib().lz_tree_begin(C.byref(d), None) == -1
+    d.edge_chunk = eng.desc.edge_chunk
+    eng2 = TreeEngine(1, 40, DEV)                                # 42 nodes x 72 children > one chunk of 1024 edges
+    C.memmove(C.byref(d), C.byref(eng2.desc), C.sizeof(LzTreeDesc))
+    d.chunk_cap = 1                                              # a chunk list that cannot hold the node arena's worst case
+    assert L.lib().lz_tree_advance(C.byref(d), None, None, L.i64(4), None, None, None) == -1
 
 
-def test_auto_reuse_factor_is_bounded_by_memory_and_node_limit():
+def test_auto_sizing_node_arena_and_edge_pool():
     _need_gpu()
-    from liuzhou_amd.tree_engine import TreeEngine, auto_reuse_factor
-    f_small = auto_reuse_factor(256, 200, DEV)
-    assert f_small == 16.0                                        # plenty of memory: the cap
-    assert auto_reuse_factor(256, 2000, DEV) <= (16384 - 2002) / 2000 + 1e-9     # 16 384 nodes per game at most
+    from liuzhou_amd.tree_engine import TreeEngine, auto_pool_chunks, auto_reuse_factor, chunk_cap_for, REUSE_FACTOR_CAP
+    assert auto_reuse_factor(256, 200, DEV) == REUSE_FACTOR_CAP   # plenty of memory: the cap
+    assert auto_reuse_factor(256, 4000, DEV) <= (65536 - 4002) / 4000 + 1e-9     # 65 536 nodes per game at most
     free, _ = torch.cuda.mem_get_info(torch.device(DEV))
-    games = int(free // (3 * 1024 * 1024))                        # ~3 MB of free memory per game
-    f_tight = auto_reuse_factor(games, 800, DEV)
-    assert 1.0 <= f_tight < 16.0
+    games = int(free // (3 * 1024 * 1024))                        # ~3 MB of free memory per game, a tenth of it for nodes
+    assert 1.0 <= auto_reuse_factor(games, 800, DEV) < REUSE_FACTOR_CAP
     eng = TreeEngine(64, 50, DEV, reuse_factor=-1.0)
-    assert eng.reuse_factor == 16.0 and eng.node_cap == 50 + 2 + 16 * 50
+    assert eng.reuse_factor == REUSE_FACTOR_CAP and eng.node_cap == 50 + 2 + int(REUSE_FACTOR_CAP) * 50
+    # <= 64 games: the pool holds the worst case (72 children everywhere), an allocation cannot fail
+    assert eng.pool_chunks == 64 * chunk_cap_for(eng.node_cap, eng.edge_chunk)
+    assert eng.chunk_cap * (eng.edge_chunk - 71) >= eng.node_cap * 72
+    # C3's shape: the mean case with head-room, within the 2^31 pool indices (64 GB) -- not 16 384 worst cases
+    n = auto_pool_chunks(16384, 800, 32802, 1024, DEV)
+    assert n * 1024 * 32 <= 64 * 2**30 and n < 16384 * chunk_cap_for(32802, 1024) // 4
+    st = eng.pool_status()
+    assert st["free"] == st["chunks"] == st["fewest_free"] and st["refused_expansions"] == 0
+
+
+def test_edge_pool_exhaustion_is_counted_not_a_fault():
+    """A pool that is too small: the expansions that find no chunk are refused and counted, the search goes on (the leaf
+    stays unexpanded, its value is backed up), every root still gets `sims` visits and nothing is written out of bounds."""
+    _need_gpu()
+    from liuzhou_amd.tree_engine import TreeEngine
+    from tests.tree_parity import hash_evaluator, unpack_packed
+    from oracle import lz_oracle as O
+    B, sims = 8, 60
+    eng = TreeEngine(B, sims, DEV, 1.0, edge_chunk=128, pool_chunks=B * 3)      # ~10 expansions per game, 61 wanted
+    guard = eng.buf["edges"].clone()
+    eng.set_roots(to_gpu_batch(O.initial_states(B), DEV))
+    eng.begin()
+    for s in range(sims + 1):
+        if s:
+            eng.select()
+        leaf = unpack_packed(eng.buf["leaf_state"].cpu().numpy())
+        pri, val = hash_evaluator(leaf)
+        eng.expand(is_root=(s == 0), values=torch.from_numpy(val).to(DEV), priors220=torch.from_numpy(pri).to(DEV))
+    eng.finish(torch.ones(B, device=DEV), None, sample_moves=False)
+    st = eng.pool_status()
+    assert st["refused_expansions"] > 0 and st["free"] == 0 and st["fewest_free"] == 0
+    assert (eng.buf["root_visits"].cpu().numpy() == sims).all()
+    assert (eng.child_visits.sum(1).cpu().numpy() == sims).all() and bool(eng.chosen_valid.all())
+    assert int(eng.buf["n_chunks"].sum()) == eng.pool_chunks and guard.shape == eng.buf["edges"].shape
+    eng.begin()                                                   # a fresh search gives every chunk back
+    assert eng.pool_status()["free"] == eng.pool_chunks
 
 
 @pytest.mark.parametrize("batch_k,sims", [(16, 50), (4, 30), (16, 200)])
@@ -542,7 +597,7 @@ def test_persistent_search_kernel_replayed_in_oracle_and_equal_to_the_launch_pai
     not a multiple of the 8 games per workgroup -- and bit-identical root edge records to the per-simulation launch pairs
     (the same device functions run the network pass and the tree steps in both)."""
     _need_gpu()
-    from tests.tree_parity import run_production_parity, root_edges
+    from tests.tree_parity import run_production_parity, root_edges, EDGE_LOGICAL
     ref, _ = run_production_parity(DEV, "b6c64", num_games=77, sims=96, moves=3, seed=31)
     assert not ref.engine.persistent
     monkeypatch.setenv("LZ_TREE_PERSISTENT", "1")
@@ -550,7 +605,7 @@ def test_persistent_search_kernel_replayed_in_oracle_and_equal_to_the_launch_pai
     assert got.engine.persistent and got.engine.persistent_ok(got.net) and got.use_graph and not got.graph_retry_off
     assert tot["kept"] > 0
     for x, y in zip(root_edges(got.engine), root_edges(ref.engine)):
-        assert x.tobytes() == y.tobytes()
+        assert all(x[f].tobytes() == y[f].tobytes() for f in EDGE_LOGICAL) and ((x["child"] >= 0) == (y["child"] >= 0)).all()
     assert torch.equal(got.engine.chosen_index, ref.engine.chosen_index)
     # the 128-channel net and the fp32 parity mode are refused by the entry point and stay on the launch pairs
     from liuzhou_amd.net import ChessNet, MODEL_CONFIGS
@@ -575,24 +630,24 @@ def test_production_search_path_c3_arithmetic():
 def test_production_search_direct_launches_equal_graph_replay():
     """The same search with direct launches (LZ_TREE_GRAPH=off path) and as a replayed hipGraph: identical trees."""
     _need_gpu()
-    from tests.tree_parity import run_production_parity, root_edges
+    from tests.tree_parity import run_production_parity, root_edges, EDGE_LOGICAL
     a, _ = run_production_parity(DEV, "b6c64", num_games=48, sims=64, moves=2, seed=23, use_graph=True)
     b, _ = run_production_parity(DEV, "b6c64", num_games=48, sims=64, moves=2, seed=23, use_graph=False)
     for x, y in zip(root_edges(a.engine), root_edges(b.engine)):
-        assert x.tobytes() == y.tobytes()
+        assert all(x[f].tobytes() == y[f].tobytes() for f in EDGE_LOGICAL) and ((x["child"] >= 0) == (y["child"] >= 0)).all()
 
 
 def test_graph_capture_failure_falls_back_to_direct_launches(monkeypatch):
     """A failed capture (the reference retries a failed finalize-graph capture with the graph off,
     v1/python/self_play_worker.py:434-442) must not lose the move: same result as the direct path, flag recorded."""
     _need_gpu()
-    from tests.tree_parity import run_production_parity, root_edges
+    from tests.tree_parity import run_production_parity, root_edges, EDGE_LOGICAL
     ref, _ = run_production_parity(DEV, "b6c64", num_games=32, sims=32, moves=2, seed=24, use_graph=False)
     monkeypatch.setenv("LZ_TREE_GRAPH_FAULT", "capture")
     got, _ = run_production_parity(DEV, "b6c64", num_games=32, sims=32, moves=2, seed=24, use_graph=True)
     assert got.graph_retry_off and not got.use_graph
     for x, y in zip(root_edges(got.engine), root_edges(ref.engine)):
-        assert x.tobytes() == y.tobytes()
+        assert all(x[f].tobytes() == y[f].tobytes() for f in EDGE_LOGICAL) and ((x["child"] >= 0) == (y["child"] >= 0)).all()
 
 
 def test_device_rng_equals_oracle_and_is_independent_of_the_batch_split():

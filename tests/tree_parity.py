@@ -339,22 +339,37 @@ def run_injected_wave_parity(device, num_games=48, sims=50, batch_k=16, moves=3,
 # Philox root noise and pick uniforms) replayed in the oracle from the trace the expand kernel leaves (LzTreeDesc.trace_*).
 # ---------------------------------------------------------------------------------------------------------------------
 EDGE_DT = np.dtype([("W", "<f8"), ("P", "<f4"), ("n_info", "<u4"), ("child", "<i4"), ("cbegin", "<i4"), ("act", "u1"),
-                    ("cn", "u1"), ("owner", "<u2"), ("pad", "V4")])
-NODE_DT = np.dtype([("state", "<i8", (4,)), ("edge_begin", "<i4"), ("nedges", "<i4"), ("parent", "<i4"), ("pad", "<i4")])
+                    ("cn", "u1"), ("pad", "V6")])
+NODE_DT = np.dtype([("state", "<i8", (4,)), ("edge_begin", "<i4"), ("nedges", "<i4"), ("parent", "<i4"), ("old_begin", "<i4")])
+# what a root edge record says about the search (everything but the place of the child's run in the engine's edge pool,
+# which depends on the order in which the games' waves took their chunks)
+EDGE_LOGICAL = ("W", "P", "n_info", "act", "cn")
+
+
+def game_tree(engine, g):
+    """(nodes, runs): game g's node records and, per node, its edge run read from the engine's pool."""
+    nn = int(engine.buf["n_nodes"][g])
+    nodes = engine.buf["nodes"].view(engine.B, engine.node_cap, 6)[g, :nn].contiguous().cpu().numpy().view(NODE_DT).reshape(nn)
+    pool = engine.buf["edges"]
+    runs = []
+    for nd in nodes:
+        e0, n = int(nd["edge_begin"]), int(nd["nedges"])
+        runs.append(pool[e0:e0 + n].contiguous().cpu().numpy().view(EDGE_DT).reshape(n) if n > 0 else np.zeros(0, EDGE_DT))
+    return nodes, runs
 
 
 def root_edges(engine):
-    """Root edge records of every game, read straight from the arena: list of structured arrays (EDGE_DT)."""
+    """Root edge records of every game, read straight from the pool: list of structured arrays (EDGE_DT)."""
     B = engine.B
     nodes = engine.buf["nodes"].view(B, engine.node_cap, 6)[:, 0].contiguous().cpu().numpy().view(NODE_DT).reshape(B)
-    e_dev = engine.buf["edges"].view(B, engine.edge_cap, 4)
+    pool = engine.buf["edges"]
     out = []
     for g in range(B):
         ne, e0 = int(nodes["nedges"][g]), int(nodes["edge_begin"][g])
         if ne <= 0:
             out.append(np.zeros(0, EDGE_DT))
             continue
-        out.append(e_dev[g, e0:e0 + ne].contiguous().cpu().numpy().view(EDGE_DT).reshape(ne))
+        out.append(pool[e0:e0 + ne].contiguous().cpu().numpy().view(EDGE_DT).reshape(ne))
     return out
 
 
