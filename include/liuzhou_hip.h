@@ -481,6 +481,10 @@ LZ_API int lz_root_collect(const void* root_states, const void* child_states, co
  * re-evaluated, they only get a fresh noise mix (portable_mcts.py:617-621). */
 LZ_API int lz_tree_advance(const LzTreeDesc* tree, const int32_t* played_action, const uint8_t* reset,
                            int64_t next_sims, int32_t* dropped, int32_t* pruned, void* stream);
+/* measurement aid (scripts/exp_advance_phases.py): when set, every later lz_tree_advance writes per game int64[8] =
+ * 100 MHz ticks at its start / after the marks / after the nodes / after the edge runs, nodes before, nodes kept, 0, 0
+ * (games that start a fresh tree only write the first and the fifth).  NULL (the default) switches it off. */
+LZ_API int lz_debug_advance_ticks(int64_t* ticks);
 /* lz_tree_search without the begin: searches the trees prepared by lz_tree_advance. */
 LZ_API int lz_tree_search_continue(const LzTreeDesc* tree, const LzNetDesc* net, int64_t sims, float* planes,
                                    float* log_p1, float* log_p2, float* log_pmc, float* values, const float* noise,

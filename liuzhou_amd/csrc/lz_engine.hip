@@ -377,13 +377,15 @@ __global__ __launch_bounds__(kBlock) void tree_expand_wave_kernel(Tree t, WaveAr
 // expansion order, which is closed under "parent of" and holds the root's and the upper levels' statistics --
 // survives; edges whose child fell past the cut keep their visit count and value sum and point to no node again (the
 // next visit expands that position afresh).  `pruned` counts pruned games, `dropped` the (only defensive) whole-subtree
-// drops.  Dynamic LDS: per wave ceil(node_cap / 64) mark words + as many prefix counts.
+// drops.  Dynamic LDS: per wave ceil(node_cap / 64) mark words + as many prefix counts + 3 x 64 ints of batch offsets.
 constexpr int kMarkWordsMax = 1024;        // subtree reuse supports node_cap <= 65536
 
 __global__ __launch_bounds__(kBlock) void tree_advance_kernel(Tree t, const int* __restrict__ played_action,
                                                               const uint8_t* __restrict__ reset, int reserve_nodes,
                                                               int mark_words, int* __restrict__ dropped,
-                                                              int* __restrict__ pruned) {
+                                                              int* __restrict__ pruned, long long* __restrict__ ticks) {
+    // `ticks` (measurement aid, NULL in production): per game 100 MHz ticks at the start / after the marks / after the
+    // nodes / after the edge runs, and the numbers of nodes before and kept (lz_debug_advance_ticks)
     extern __shared__ uint64_t s_adv[];
     const int lane = lane_id();
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -423,6 +425,7 @@ __global__ __launch_bounds__(kBlock) void tree_advance_kernel(Tree t, const int*
     const int nn = t.n_nodes[g];
     const int words = (nn + 63) >> 6;
     int kept_nodes = 0;
+    if (ticks != nullptr && lane == 0) { ticks[(size_t)g * 8] = (long long)wall_clock64(); ticks[(size_t)g * 8 + 4] = nn; }
     if (c > 0 && words > mark_words) {                          // more nodes than the mark words cover: fresh root
         c = -1;                                                 // (cannot happen: mark_words covers node_cap)
         if (lane == 0 && dropped != nullptr) atomicAdd(dropped, 1);
@@ -431,31 +434,44 @@ __global__ __launch_bounds__(kBlock) void tree_advance_kernel(Tree t, const int*
         // ---- pass 1: marks + per-word prefix counts ----
         const int node_budget = t.node_cap - reserve_nodes;
         bool cut = false;
-        for (int w = 0; w < words; ++w) {
-            const int id = w * kWave + lane;
-            const bool valid = id < nn;
-            int parent = -1;
-            if (valid) parent = nodes[id].parent;
-            const bool cand = valid && id > c && parent >= c;   // descendants have larger ids than their ancestors
-            bool kept = valid && id == c;
-            if (cand && parent < w * kWave) kept = (mark[parent >> 6] >> (parent & 63)) & 1ull;
-            uint64_t bal = __ballot(kept);
-            for (;;) {                                           // parents inside this chunk
-                const bool nk = kept || (cand && parent >= w * kWave && ((bal >> (parent - w * kWave)) & 1ull));
-                const uint64_t nb = __ballot(nk);
-                kept = nk;
-                if (nb == bal) break;
-                bal = nb;
+        // (the kernel's time is its slowest wave's -- a game that keeps thousands of nodes -- and that wave is bound by
+        //  the latency of dependent loads: the parents of kAhead words are fetched together)
+        constexpr int kAhead = 4;
+        for (int w0 = 0; w0 < words && !cut; w0 += kAhead) {
+            int par[kAhead];
+#pragma unroll
+            for (int u = 0; u < kAhead; ++u) {
+                const int id = (w0 + u) * kWave + lane;
+                par[u] = id < nn ? nodes[id].parent : -1;
             }
-            const int chunk_nodes = __popcll(bal);
-            if (kept_nodes + chunk_nodes > node_budget) {
-                // no room for this chunk: the subtree is cut here (expansion order), the rest is forgotten
-                for (int r = w + lane; r < words; r += kWave) { mark[r] = 0ull; nprefix[r] = kept_nodes; }
-                cut = true;
-                break;
+#pragma unroll
+            for (int u = 0; u < kAhead; ++u) {
+                const int w = w0 + u;
+                if (w >= words || cut) break;
+                const int id = w * kWave + lane;
+                const bool valid = id < nn;
+                const int parent = par[u];
+                const bool cand = valid && id > c && parent >= c;   // descendants have larger ids than their ancestors
+                bool kept = valid && id == c;
+                if (cand && parent < w * kWave) kept = (mark[parent >> 6] >> (parent & 63)) & 1ull;
+                uint64_t bal = __ballot(kept);
+                for (;;) {                                           // parents inside this chunk
+                    const bool nk = kept || (cand && parent >= w * kWave && ((bal >> (parent - w * kWave)) & 1ull));
+                    const uint64_t nb = __ballot(nk);
+                    kept = nk;
+                    if (nb == bal) break;
+                    bal = nb;
+                }
+                const int chunk_nodes = __popcll(bal);
+                if (kept_nodes + chunk_nodes > node_budget) {
+                    // no room for this chunk: the subtree is cut here (expansion order), the rest is forgotten
+                    for (int r = w + lane; r < words; r += kWave) { mark[r] = 0ull; nprefix[r] = kept_nodes; }
+                    cut = true;
+                    break;
+                }
+                if (lane == 0) { mark[w] = bal; nprefix[w] = kept_nodes; }
+                kept_nodes += chunk_nodes;
             }
-            if (lane == 0) { mark[w] = bal; nprefix[w] = kept_nodes; }
-            kept_nodes += chunk_nodes;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -472,78 +488,137 @@ __global__ __launch_bounds__(kBlock) void tree_advance_kernel(Tree t, const int*
         if (lane == 0) begin_game(t, g, /*release=*/false);
         return;
     }
+    if (ticks != nullptr && lane == 0) { ticks[(size_t)g * 8 + 1] = (long long)wall_clock64(); ticks[(size_t)g * 8 + 5] = kept_nodes; }
     // ---- pass 2: nodes, and the new places of their edge runs ----
     const int* list = t.chunk_list + (size_t)g * t.chunk_cap;
     const int n_chunks = t.n_chunks[g];
     const int CH = t.chunk;
     int ci = 0, off = 0;                                         // chunk being filled (index into the list), its fill
-    int cbase = list[0] * CH;
-    for (int w = 0; w < words; ++w) {
-        const uint64_t m = mark[w];
-        if (!m) continue;
-        const int id = w * kWave + lane;
-        const bool kept = (m >> lane) & 1ull;
-        Node rec;
-        int cnt = 0;
-        if (kept) { rec = nodes[id]; cnt = rec.nedges > 0 ? rec.nedges : 0; }
-        int begin = 0, start = 0;
-        for (;;) {
-            const int c2 = lane >= start ? cnt : 0;
-            int incl = c2;
+    int list_reg = lane < n_chunks ? list[lane] : 0;             // list[64 * (ci / 64) + lane]: no load on a chunk change
+    int cbase = lzw::lane_bcast(list_reg, 0) * CH;
+    // (the records of two words are fetched together: a word's stores land below its own ids, never on the next word's)
+    for (int w0 = 0; w0 < words; w0 += 2) {
+        // a node record as three 16-byte parts: the packed state (2 parts), then {edge_begin, nedges, parent, old_begin}
+        u32x4 na[2], nb2[2], nc2[2];
+        uint64_t ms[2];
 #pragma unroll
-            for (int o = 1; o < kWave; o <<= 1) { const int up = __shfl_up(incl, o); if (lane >= o) incl += up; }
-            const uint64_t over = __ballot(c2 > 0 && off + incl > CH);
-            const int first = over ? __ffsll((unsigned long long)over) - 1 : kWave;   // first run that does not fit
-            if (lane >= start && lane < first) begin = cbase + off + incl - c2;
-            const int placed = first == kWave ? __shfl(incl, kWave - 1) : (__shfl(incl, first) - __shfl(c2, first));
-            off += placed;
-            if (!over) break;
-            ci = ci + 1 < n_chunks ? ci + 1 : ci;               // (always within the list: see the header comment)
-            cbase = list[ci] * CH;
-            off = 0;
-            start = first;
+        for (int u = 0; u < 2; ++u) {
+            const int w = w0 + u;
+            ms[u] = w < words ? mark[w] : 0ull;
+            na[u] = nb2[u] = nc2[u] = (u32x4){0u, 0u, 0u, 0u};
+            if ((ms[u] >> lane) & 1ull) {
+                const u32x4* q = reinterpret_cast<const u32x4*>(&nodes[w * kWave + lane]);
+                na[u] = q[0]; nb2[u] = q[1]; nc2[u] = q[2];
+            }
         }
-        if (kept) {
-            rec.old_begin = rec.edge_begin;
-            rec.edge_begin = begin;
-            rec.parent = id == c ? -1 : rank_of(rec.parent);
-            nodes[nprefix[w] + __popcll(m & lt)] = rec;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int w = w0 + u;
+            const uint64_t m = ms[u];
+            if (!m) continue;
+            const int id = w * kWave + lane;
+            const bool kept = (m >> lane) & 1ull;
+            u32x4 meta = nc2[u];
+            const int cnt = kept ? ((int)meta.y > 0 ? (int)meta.y : 0) : 0;
+            int begin = 0, start = 0;
+            for (;;) {
+                const int c2 = lane >= start ? cnt : 0;
+                const int incl = lzw::wave_incl_scan(c2);
+                const uint64_t over = __ballot(c2 > 0 && off + incl > CH);
+                const int first = over ? __ffsll((unsigned long long)over) - 1 : kWave;   // first run that does not fit
+                if (lane >= start && lane < first) begin = cbase + off + incl - c2;
+                const int placed = first == kWave ? lzw::lane_bcast(incl, kWave - 1)
+                                                  : (lzw::lane_bcast(incl, first) - lzw::lane_bcast(c2, first));
+                off += placed;
+                if (!over) break;
+                ci = ci + 1 < n_chunks ? ci + 1 : ci;           // (always within the list: see the header comment)
+                if ((ci & 63) == 0) list_reg = ci + lane < n_chunks ? list[ci + lane] : 0;
+                cbase = lzw::lane_bcast(list_reg, ci & 63) * CH;
+                off = 0;
+                start = first;
+            }
+            if (kept) {
+                meta.w = meta.x;                                 // old_begin = edge_begin
+                meta.x = (uint32_t)begin;
+                meta.z = id == c ? 0xFFFFFFFFu : (uint32_t)rank_of((int)meta.z);
+                u32x4* q = reinterpret_cast<u32x4*>(&nodes[nprefix[w] + __popcll(m & lt)]);
+                q[0] = na[u]; q[1] = nb2[u]; q[2] = meta;
+            }
         }
     }
     __threadfence_block();
-    // ---- pass 3: edge runs, node by node in the new order ----
+    if (ticks != nullptr && lane == 0) ticks[(size_t)g * 8 + 2] = (long long)wall_clock64();
+    // ---- pass 3: edge runs, FLAT over the kept edges of 64 nodes at a time.  The kernel's time is its slowest wave's --
+    // a game that keeps well over a thousand nodes (a run of forced moves keeps the whole tree) -- and that wave is bound
+    // by memory round trips, not by bytes: so a round moves kFlat x 64 records (about 48 nodes' runs) with ALL their loads
+    // in flight, then all child-link lookups in flight, then the stores.  Lane l of slice r owns flat record
+    // f = f0 + 64 r + l of the batch: its node is found by a 6-step binary search over the batch's run offsets (LDS).
+    // Safe in place: a run's new place ends no later than its old place does, and old places ascend with the node, so
+    // nothing a round stores lies in what a later round loads ----
+    constexpr int kFlat = 12;
+    int* bat = reinterpret_cast<int*>(s_adv + (size_t)kWavesPerBlock * mark_words) + (size_t)kWavesPerBlock * mark_words +
+               (size_t)wv * (3 * kWave);
+    int* bP = bat; int* bOb = bat + kWave; int* bNb = bat + 2 * kWave;
     for (int base = 0; base < kept_nodes; base += kWave) {
         const int id = base + lane;
         int ob = 0, nb = 0, cnt = 0;
-        if (id < kept_nodes) { const Node nr = nodes[id]; ob = nr.old_begin; nb = nr.edge_begin; cnt = nr.nedges; }
-        const int lim = kept_nodes - base < kWave ? kept_nodes - base : kWave;
-        for (int j = 0; j < lim; ++j) {
-            const int n_j = lzw::lane_bcast(cnt, j), ob_j = lzw::lane_bcast(ob, j), nb_j = lzw::lane_bcast(nb, j);
-            Edge rec[2];
-            bool has[2];
+        if (id < kept_nodes) {
+            const u32x4 meta = reinterpret_cast<const u32x4*>(&nodes[id])[2];
+            nb = (int)meta.x; cnt = (int)meta.y > 0 ? (int)meta.y : 0; ob = (int)meta.w;
+        }
+        const int incl = lzw::wave_incl_scan(cnt);
+        const int T = lzw::lane_bcast(incl, kWave - 1);          // records of this batch
+        bP[lane] = incl - cnt; bOb[lane] = ob; bNb[lane] = nb;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int f0 = 0; f0 < T; f0 += kFlat * kWave) {
+            u32x4 lo[kFlat], hi[kFlat];
+            int dst[kFlat];
 #pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                const int k = r * kWave + lane;
-                has[r] = k < n_j;
-                if (r == 1 && n_j <= kWave) { has[r] = false; continue; }
-                if (has[r]) {
-                    rec[r] = edges[(size_t)(ob_j + k)];
-                    if (rec[r].child >= 0) {
-                        if ((mark[rec[r].child >> 6] >> (rec[r].child & 63)) & 1ull) {
-                            const int nc = rank_of(rec[r].child);
-                            rec[r].child = nc;
-                            rec[r].cbegin = nodes[nc].edge_begin;
-                        } else {                                 // the child fell past the cut of a pruned subtree
-                            rec[r].child = -1; rec[r].cbegin = 0; rec[r].cn = 0;
-                        }
+            for (int r = 0; r < kFlat; ++r) {
+                const int f = f0 + r * kWave + lane;
+                dst[r] = -1;
+                lo[r] = (u32x4){0u, 0u, 0u, 0u}; hi[r] = (u32x4){0xFFFFFFFFu, 0u, 0u, 0u};
+                if (f0 + r * kWave < T) {                        // wave-uniform: slices past the batch issue nothing
+                    int j = 0;
+#pragma unroll
+                    for (int st = 32; st > 0; st >>= 1) j += bP[j + st] <= f ? st : 0;
+                    if (f < T) {
+                        const int k = f - bP[j];
+                        dst[r] = bNb[j] + k;
+                        const u32x4* q = reinterpret_cast<const u32x4*>(&edges[(size_t)(bOb[j] + k)]);
+                        lo[r] = q[0]; hi[r] = q[1];
                     }
                 }
             }
+            // child links: every lookup is issued unconditionally (node 0 where there is no kept child)
+            int ncs[kFlat], ebs[kFlat];
+            bool kc[kFlat];
 #pragma unroll
-            for (int r = 0; r < 2; ++r)
-                if (has[r]) edges[(size_t)(nb_j + r * kWave + lane)] = rec[r];
+            for (int r = 0; r < kFlat; ++r) {
+                const int ch = (int)hi[r].x;
+                const int chc = ch >= 0 ? ch : 0;
+                kc[r] = ch >= 0 && ((mark[chc >> 6] >> (chc & 63)) & 1ull);
+                ncs[r] = kc[r] ? rank_of(chc) : 0;
+            }
+#pragma unroll
+            for (int r = 0; r < kFlat; ++r)
+                ebs[r] = (f0 + r * kWave < T) ? nodes[ncs[r]].edge_begin : 0;
+#pragma unroll
+            for (int r = 0; r < kFlat; ++r) {
+                if (dst[r] < 0) continue;
+                if ((int)hi[r].x >= 0) {
+                    if (kc[r]) { hi[r].x = (uint32_t)ncs[r]; hi[r].y = (uint32_t)ebs[r]; }
+                    else { hi[r].x = 0xFFFFFFFFu; hi[r].y = 0u; hi[r].z &= ~0xFF00u; }   // past the cut: child -1, cbegin 0, cn 0
+                }
+                u32x4* q = reinterpret_cast<u32x4*>(&edges[(size_t)dst[r]]);
+                q[0] = lo[r]; q[1] = hi[r];
+            }
         }
+        __builtin_amdgcn_wave_barrier();                          // the batch arrays are rewritten by the next batch
     }
+    if (ticks != nullptr && lane == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); ticks[(size_t)g * 8 + 3] = (long long)wall_clock64(); }
     release_chunks_wave(t, g, ci + 1, lane);
     if (lane == 0) {
         t.n_nodes[g] = kept_nodes;
@@ -969,6 +1044,9 @@ int lz_tree_finish(const LzTreeDesc* d, const float* temperatures, const float* 
     return st();
 }
 
+static long long* g_advance_ticks = nullptr;
+int lz_debug_advance_ticks(int64_t* ticks) { g_advance_ticks = reinterpret_cast<long long*>(ticks); return LZ_OK; }
+
 int lz_tree_advance(const LzTreeDesc* d, const int32_t* played_action, const uint8_t* reset, int64_t next_sims,
                     int32_t* dropped, int32_t* pruned, void* stream) {
     if (!tree_ok(d) || next_sims < 0) return LZ_ERR_ARG;
@@ -980,9 +1058,9 @@ int lz_tree_advance(const LzTreeDesc* d, const int32_t* played_action, const uin
     // a game's chunk list must be able to hold the worst case of its node arena (72 children everywhere), so that the
     // node budget is the only thing that can cut a kept subtree
     if ((int64_t)d->chunk_cap * (d->edge_chunk - (kMaxChildren - 1)) < (int64_t)d->node_cap * kMaxChildren) return LZ_ERR_ARG;
-    const size_t lds = (size_t)kWavesPerBlock * words * (sizeof(uint64_t) + sizeof(int));
+    const size_t lds = (size_t)kWavesPerBlock * (words * (sizeof(uint64_t) + sizeof(int)) + 3 * kWave * sizeof(int));
     hipLaunchKernelGGL(tree_advance_kernel, dim3(gw(d->num_games)), dim3(kBlock), lds, as_stream(stream), make_tree(d),
-                       played_action, reset, (int)rn, words, dropped, pruned);
+                       played_action, reset, (int)rn, words, dropped, pruned, g_advance_ticks);
     return st();
 }
 

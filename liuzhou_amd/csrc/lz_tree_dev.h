@@ -194,6 +194,8 @@ __device__ __forceinline__ void tree_select(const Tree& t, int g, int lane, cons
     float term_value = 0.f;
     int leaf_action = 0, leaf_edge = -1;
     while (ne > 0) {
+        // the node's run: a wave-uniform base (scalar 64-bit arithmetic) + a 32-bit lane offset per load
+        const Edge* run = edges + (size_t)__builtin_amdgcn_readfirstlane(e0);
         const double sq = sqrt((double)(parent_n > 1 ? parent_n : 1));
         double best = -INFINITY;
         int best_k = -1;
@@ -206,7 +208,7 @@ __device__ __forceinline__ void tree_select(const Tree& t, int g, int lane, cons
             if (r == 1 && ne <= kWave) break;
             const int k = r * kWave + lane;
             if (k < ne) {
-                mine[r] = load_edge(&edges[(size_t)(e0 + k)]);
+                mine[r] = load_edge(&run[k]);
                 const int n = edge_n(mine[r].n_info);
                 double q = 0.0;
                 if (n > 0) {
@@ -482,6 +484,7 @@ __device__ __forceinline__ void tree_expand(const Tree& t, int g, int lane, cons
             // stays unexpanded -- its value is still backed up, the next visit evaluates and tries again
             const int n_write = e0 >= 0 ? n : 0;
             // Phase B: one pass (two only when a movement position has more than 64 legal moves)
+            Edge* new_run = edges + (size_t)(e0 >= 0 ? e0 : 0);      // wave-uniform base + 32-bit lane offset
             for (int r = 0; r < (n_write > kWave ? 2 : 1); ++r) {
                 const int k = r * kWave + lane;
                 if (k >= n_write) continue;
@@ -504,7 +507,7 @@ __device__ __forceinline__ void tree_expand(const Tree& t, int g, int lane, cons
                 rec.act = (uint8_t)a;
                 rec.cn = 0;
                 rec.pad[0] = rec.pad[1] = rec.pad[2] = rec.pad[3] = rec.pad[4] = rec.pad[5] = 0;
-                edges[(size_t)(e0 + k)] = rec;
+                new_run[k] = rec;
             }
             backup_value = (double)value_ld;
         }

@@ -68,6 +68,18 @@ __device__ __forceinline__ float wave_max_nonan(float v) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
+// inclusive prefix sum over the wave on DPP (row_shr 1/2/4/8 inside the rows of 16, then the row totals with
+// row_bcast 15 / 31): 6 VALU steps, no LDS round trips (a __shfl_up ladder is 6 ds_bpermute)
+__device__ __forceinline__ int wave_incl_scan(int v) {
+    v += dpp_i32<0x111, 0xf>(0, v);
+    v += dpp_i32<0x112, 0xf>(0, v);
+    v += dpp_i32<0x114, 0xf>(0, v);
+    v += dpp_i32<0x118, 0xf>(0, v);
+    v += dpp_i32<0x142, 0xa>(0, v);
+    v += dpp_i32<0x143, 0xc>(0, v);
+    return v;
+}
+
 // value of `v` in lane `src` (src must be wave-uniform): v_readlane, no LDS
 __device__ __forceinline__ int lane_bcast(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
 __device__ __forceinline__ float lane_bcast(float v, int src) {

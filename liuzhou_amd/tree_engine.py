@@ -55,8 +55,11 @@ class LzTreeWaveDesc(C.Structure):
 
 WAVE_PATH_CAP = 64             # entries per leaf path of a wave (the kernel follows descents up to 48 levels)
 EDGE_CHUNK = 1024              # edges per chunk of the engine's edge pool (32 KB); a run of <= 72 edges never straddles chunks
-POOL_EDGES_PER_NODE = 40       # pool sizing: mean fan-out is ~25 (placement <= 36, movement ~20-30), 40 leaves 60 % head-room
-POOL_NODES_PER_SIM = 4         # pool sizing: a game's tree (kept subtree + new search) averages < 2 x sims nodes
+# pool sizing: 3 x sims nodes of 32 edges per game.  Measured peak use (bench.py `reuse.edge_pool.peak_use_frac`, round 4):
+# 15 edges per simulation of the budget at C3 (16 384 x 800) and 17 at C2 -- a steady-state population is mostly in the
+# movement phase with 10-20 legal moves, and a kept subtree rarely exceeds the new search -- so 96 is 6 x head-room
+POOL_EDGES_PER_NODE = 32
+POOL_NODES_PER_SIM = 3
 MAX_NODE_CAP = 65536           # lz_tree_advance marks a game's nodes in LDS: 1024 words of 64
 PATH_CAP = 192                 # a game lasts <= 144 plies (game_state.py:87-89), so no descent is deeper than that
 REUSE_FACTOR_CAP = 40.0
