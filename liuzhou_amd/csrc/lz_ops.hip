@@ -674,6 +674,53 @@ __device__ __forceinline__ void puct_pulls(int sims, int lane, int live, const f
     }
 }
 
+// Two roots in one wave: root A on lanes 0-31, root B on lanes 32-63, when every valid action of both sits below index
+// 32 (the fused root search packs its rows to the left; most positions have fewer than 32 legal moves).  The same
+// arithmetic per lane as puct_pulls; the maximum is taken per half (the row_bcast:31 step of the reduction is left out,
+// lanes 31 / 63 hold the halves' maxima), one ballot serves both halves.  A pull costs the same instructions as for one
+// root, so a packed pair takes half the issue slots.
+__device__ __forceinline__ void half_max2(float v, float& lo, float& hi) {
+    asm volatile("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                 "s_nop 1"
+                 : "+v"(v));
+    lo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 31));
+    hi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+template <bool EXACT_DIV>
+__device__ __forceinline__ void puct_pulls_pair(int sims, int lane, float cp, float lv, float& vis, float& vs) {
+    float q = 0.f;
+    double rd_u = 1.0, rd_next = 0.5;
+    int nv = 0;
+    const bool upper = lane >= 32;
+    for (int sim = 0; sim < sims; ++sim) {
+        const float sqrt_total = g_puct_sqrt[sim];
+        const float x = cp * sqrt_total;
+        const float u = EXACT_DIV ? x / (1.0f + vis) : div_by_int(x, rd_u);
+        const float sc = q + u;                                  // NaN on lanes without a valid action
+        const float best = sc > -INFINITY ? sc : -INFINITY;
+        float m_lo, m_hi;
+        half_max2(best, m_lo, m_hi);
+        const unsigned long long hit = __ballot(sc == (upper ? m_hi : m_lo));
+        const uint32_t hit_lo = (uint32_t)hit, hit_hi = (uint32_t)(hit >> 32);
+        if ((hit_lo | hit_hi) == 0u) break;                      // neither root has a candidate: none later either
+        const int ca = hit_lo ? __builtin_ctz(hit_lo) : -1, cb = hit_hi ? 32 + __builtin_ctz(hit_hi) : -1;
+        if (lane == ca || lane == cb) {
+            nv += 1;
+            vis += 1.0f;
+            vs += lv;
+            const double rd_q = rd_u;
+            rd_u = rd_next;
+            if (!EXACT_DIV) rd_next = g_puct_recip[nv + 2];
+            q = EXACT_DIV ? vs / vis : div_by_int(vs, rd_q);
+        }
+    }
+}
+
 template <int SLOTS>
 __global__ __launch_bounds__(kBlock) void root_puct_fast_kernel(const float* __restrict__ priors,
                                                                 const float* __restrict__ leaf,
@@ -685,6 +732,37 @@ __global__ __launch_bounds__(kBlock) void root_puct_fast_kernel(const float* __r
     const int lane = lane_id();
     const int64_t root = wave_item();
     if (root >= R) return;
+    // ---- two roots per wave where both fit 32 lanes: the even wave of a pair works for both, the odd one leaves ----
+    {
+        const int64_t ra = root & ~(int64_t)1, rb = ra + 1;
+        bool wide = false;                                        // a valid action at index >= 32 in either row
+        if (rb < R) {
+            for (int a = 32 + lane; a < A; a += kWave) wide = wide || valid[ra * A + a] != 0 || valid[rb * A + a] != 0;
+        }
+        if (rb < R && __ballot(wide) == 0ull) {
+            if (root != ra) return;
+            const int a = lane & 31;
+            const int64_t r = lane < 32 ? ra : rb;
+            const bool ok = a < A && valid[r * A + (a < A ? a : 0)] != 0;
+            const float cp1 = ok ? c * priors[r * A + a] : __builtin_nanf("");
+            const float lv1 = a < A ? leaf[r * A + a] : 0.f;
+            float vis1 = 0.f, vs1 = 0.f;
+            const float acp = fabsf(cp1), alv = fabsf(lv1);
+            const bool tiny1 = ok && ((acp != 0.f && acp < 0x1p-100f) || (alv != 0.f && alv < 0x1p-100f));
+            if (__ballot(tiny1) != 0ull) puct_pulls_pair<true>(sims, lane, cp1, lv1, vis1, vs1);
+            else puct_pulls_pair<false>(sims, lane, cp1, lv1, vis1, vs1);
+            if (a < A) { visits[r * A + a] = vis1; value_sum[r * A + a] = vs1; }
+            for (int a2 = 32 + lane; a2 < A; a2 += kWave) {       // the rest of both rows: never visited
+                visits[ra * A + a2] = 0.f; value_sum[ra * A + a2] = 0.f;
+                visits[rb * A + a2] = 0.f; value_sum[rb * A + a2] = 0.f;
+            }
+            float sv1 = vis1, sw1 = vs1;                          // per-half butterfly: the same additions as wave_sum
+#pragma unroll                                                    // performs for a root alone in a wave (x + 0 == x)
+            for (int o = 16; o > 0; o >>= 1) { sv1 += __shfl_xor(sv1, o); sw1 += __shfl_xor(sw1, o); }
+            if ((lane & 31) == 0) root_values[r] = sw1 / fmaxf(sv1, 1.0f);
+            return;
+        }
+    }
     float cp[SLOTS], lv[SLOTS], vis[SLOTS], vs[SLOTS];
     int live = 0;
     bool tiny = false;

@@ -583,9 +583,12 @@ class PortableTreeMCTS:
         g = self._graphs.get(key)
         if g is None:
             if not continue_trees:
-                # warm-up launch outside capture (a fresh search starts by resetting the trees, so running it twice
-                # is harmless); a continued search must run exactly once and is only reached after a fresh one
-                e.search(self.net, self.sims, noise, self.eps, False)
+                # warm-up launch outside capture: every kernel of the search must be loaded before a stream capture
+                # starts.  Two simulations reach all of them (root expand + select, expand + select, last expand), and a
+                # fresh search starts by resetting the trees, so what the warm-up leaves behind does not matter -- a full
+                # search here cost 1.6 s per engine at C3.  A continued search must run exactly once and is only reached
+                # after a fresh one
+                e.search(self.net, min(self.sims, 2), noise, self.eps, False)
             torch.cuda.synchronize(e.device)
             try:
                 g = torch.cuda.CUDAGraph()

@@ -219,4 +219,7 @@ def test_fused_fp16_kernel_against_autocast_and_its_effect_on_the_search():
     l1 = np.abs(p16 - p32).sum(1)
     print(f"fp16 vs fp32 search, {int(live.sum())} roots x 128 sims: identical visit counts {same:.3f}, identical most-visited "
           f"{arg:.3f}, policy L1 max {l1.max():.4f} mean {l1.mean():.5f}")
-    assert same >= 0.9 and arg >= 0.95 and l1.mean() <= 0.02
+    # observed on MI355X (rounds 3 and 4): every root identical.  The bound allows ONE root of the 96 to differ (a near-tie
+    # between two children decided by the last bits of a prior is legitimate; more than that would be a defect)
+    n_live = int(live.sum())
+    assert same >= 1.0 - 1.0 / n_live - 1e-9 and arg >= 1.0 - 1.0 / n_live - 1e-9 and l1.mean() <= 2.0 / (128 * n_live) + 1e-9

@@ -274,6 +274,29 @@ def test_root_puct_table_kernel_equals_division_kernel(v0, A, sims, monkeypatch)
     assert vs_t.tobytes() == vs_d.tobytes() and rv_t.tobytes() == rv_d.tobytes()
     live = np.isfinite(v_t).all(1)
     assert (v_t[live].sum(1) <= sims).all() and (v_t[0].sum() == sims)
+    # rows packed to the left, as the fused root search builds them: two roots share a wave when both have <= 32 actions
+    # (pairs of small rows, mixed pairs, an odd last row, rows with no action at all)
+    R2 = 95
+    n = rng.integers(0, min(A, 44) + 1, R2)
+    n[:8] = [1, 32, 32, 33, 0, 5, 31, 0]
+    valid2 = np.arange(A)[None, :] < n[:, None]
+    pri2 = (rng.random((R2, A)) ** 2 * valid2).astype(np.float32)
+    pri2 /= np.maximum(pri2.sum(1, keepdims=True), 1e-8)
+    leaf2 = ((rng.random((R2, A)) * 2 - 1) * valid2).astype(np.float32)
+    leaf2[10, :2] = [np.float32(2.0 ** -120), 0.5]                          # a pair that must take the division branch
+    args2 = [torch.from_numpy(x).to(DEV) for x in (pri2, leaf2, valid2)]
+    s2 = min(sims, 4096)
+    monkeypatch.delenv("LZ_ROOT_PUCT_DIV", raising=False)
+    a_t = [t.cpu().numpy() for t in v0.root_puct_allocate_visits(*args2, s2, 1.25)]
+    monkeypatch.setenv("LZ_ROOT_PUCT_DIV", "1")
+    a_d = [t.cpu().numpy() for t in v0.root_puct_allocate_visits(*args2, s2, 1.25)]
+    for x, y in zip(a_t, a_d):
+        assert x.tobytes() == y.tobytes()
+    assert (a_t[0].sum(1) == np.where(n > 0, s2, 0)).all() and (a_t[0][~valid2] == 0).all()
+    want_v, _, _ = O.root_puct(pri2, leaf2, valid2, min(s2, 300), 1.25)     # and against the oracle at a budget it can follow
+    monkeypatch.delenv("LZ_ROOT_PUCT_DIV", raising=False)
+    got_v = v0.root_puct_allocate_visits(*args2, min(s2, 300), 1.25)[0].cpu().numpy()
+    assert np.array_equal(got_v, want_v)
 
 
 @pytest.mark.parametrize("A", [5, 64, 72, 130])
