@@ -285,6 +285,34 @@ struct GemmSteps<C, S, TAPS9, STEM, CTN, NSTEPS, NSTEPS, NW> {
                                                const int (&)[3], int, const unsigned char*, int (&)[9], int) {}
 };
 
+// The same with the weight fragments fetched TWO K steps ahead (three register sets in rotation).  A K step of two waves
+// per SIMD lasts ~290 ns, an L2 hit 300 - 500 ns: one step ahead leaves part of every load's latency on the critical
+// path (scripts/micro/wfrag_ring.hip, profiles/r04_micro_wfrag_ring.json: the K loop of this kernel with loads one step
+// ahead runs 67 % over its no-weight-traffic bound, two steps ahead AT the bound).
+template <int C, int S, bool TAPS9, bool STEM, int CTN, int STEP, int NSTEPS, int NW>
+struct GemmSteps2 {
+    static __device__ __forceinline__ void run(AccT<NW>& acc, h8 (&A0)[NW], h8 (&A1)[NW], h8 (&A2)[NW], h8 (&B)[9],
+                                               __amdgpu_buffer_rsrc_t rw, const int (&wrow)[3], int lane16,
+                                               const unsigned char* lds, int (&base)[9], int row_step) {
+        using T = Steps<C, S, TAPS9, STEM>;
+        if (STEP + 2 < NSTEPS) {
+            constexpr int nx = STEP + 2 < NSTEPS ? STEP + 2 : STEP;
+#pragma unroll
+            for (int j = 0; j < NW; ++j) A2[j] = load_wfrag(rw, lane16, wrow[T::row(nx)] + T::w_imm(nx, CTN) + j * 1024);
+        }
+        gemm_step<C, S, TAPS9, STEM, STEP, NW>(acc, A0, B, lds, base, row_step);
+        GemmSteps2<C, S, TAPS9, STEM, CTN, STEP + 1, NSTEPS, NW>::run(acc, A1, A2, A0, B, rw, wrow, lane16, lds, base, row_step);
+    }
+};
+template <int C, int S, bool TAPS9, bool STEM, int CTN, int NSTEPS, int NW>
+struct GemmSteps2<C, S, TAPS9, STEM, CTN, NSTEPS, NSTEPS, NW> {
+    static __device__ __forceinline__ void run(AccT<NW>&, h8 (&)[NW], h8 (&)[NW], h8 (&)[NW], h8 (&)[9], __amdgpu_buffer_rsrc_t,
+                                               const int (&)[3], int, const unsigned char*, int (&)[9], int) {}
+};
+#ifndef LZ_NET_APF
+#define LZ_NET_APF 1            /* weight fragments fetched this many K steps ahead (1 or 2) */
+#endif
+
 // Fully unrolled over the K steps (9 taps x C/32 blocks): every LDS read offset is an immediate and every
 // weight address is {descriptor, scalar offset, lane offset}, so a step is <= 9 ds_read + 2 buffer_load +
 // <= 18 MFMA and (on the two row changes and at the end) 9 address adds.
@@ -312,10 +340,21 @@ __device__ __forceinline__ void conv_gemm(AccT<NW>& acc, __amdgpu_buffer_rsrc_t 
                          wbyte + (mirror ? 0 : 2) * T::w_row_bytes(CTN)};
     const int lane16 = lane * 16;
     h8 A1[NW], B[9];
+#if LZ_NET_APF == 2
+    h8 A2[NW];
+    if (T::N > 1) {
+#pragma unroll
+        for (int j = 0; j < NW; ++j) A1[j] = load_wfrag(rw, lane16, wrow[T::row(1)] + T::w_imm(1, CTN) + j * 1024);
+    }
+#endif
 #pragma unroll
     for (int i = 0; i < 9; ++i)
         if (T::live(i, 0)) B[i] = *reinterpret_cast<const h8*>(lds + base[i] + T::lds_imm(0));
+#if LZ_NET_APF == 2
+    GemmSteps2<C, S, TAPS9, STEM, CTN, 0, T::N, NW>::run(acc, A0, A1, A2, B, rw, wrow, lane16, lds, base, row_step);
+#else
     GemmSteps<C, S, TAPS9, STEM, CTN, 0, T::N, NW>::run(acc, A0, A1, B, rw, wrow, lane16, lds, base, row_step);
+#endif
 }
 
 // workgroup barrier that only orders LDS traffic: prefetched global loads stay in flight across it

@@ -16,8 +16,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(ROOT, "liuzhou_amd", "csrc", "lz_net.hip")
 with tempfile.TemporaryDirectory() as tmp:
     out = os.path.join(tmp, "lz_net.s")
+    defs = os.environ.get("LZ_ISA_DEFS", "").split()          # e.g. LZ_ISA_DEFS="-DLZ_NET_APF=1" for an experiment build
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
-                           "-S", "--cuda-device-only", src, "-o", out], stderr=subprocess.DEVNULL)
+                           *defs, "-S", "--cuda-device-only", src, "-o", out], stderr=subprocess.DEVNULL)
     text = open(out).read().splitlines()
 
 starts = [(i, l.split(":")[0]) for i, l in enumerate(text) if l.startswith("_ZN") and "net_forward_kernel" in l.split(":")[0]]
