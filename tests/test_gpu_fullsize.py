@@ -111,6 +111,22 @@ def _dropped(pop):
     return [sum(int(e.reuse_dropped[k].item()) for e in _engines(pop)) for k in (0, 1)]
 
 
+def _pool_ok(pop, max_tree_gbytes):
+    """The engines' edge pools: no expansion was refused, the peak use leaves head-room, every chunk is either free or on
+    exactly one game's list, and the tree memory is what DESIGN.md section 4 says."""
+    total = 0
+    for e in _engines(pop):
+        st = e.pool_status()
+        assert st["refused_expansions"] == 0, st
+        assert st["fewest_free"] > 0.4 * st["chunks"], f"edge pool nearly exhausted: {st}"
+        owned = int(e.buf["n_chunks"].sum(dtype=torch.int64).item())
+        assert owned + st["free"] == st["chunks"], "a chunk was lost or handed out twice"
+        assert int(e.buf["n_chunks"].max().item()) <= e.chunk_cap
+        total += e.hbm_bytes()
+    assert total <= max_tree_gbytes * 2**30, f"tree memory {total / 2**30:.1f} GiB"
+    return total / 2**30
+
+
 def test_c2_full_size_three_moves_and_same_seed_same_games():
     """C2 = 4 096 concurrent games, 200 simulations per move, 6x64 net, two streams: three consecutive moves with kept
     subtrees, checked move by move; a second population with the same seed plays bit-identical moves."""
@@ -123,7 +139,8 @@ def test_c2_full_size_three_moves_and_same_seed_same_games():
         steps = [_checked_step(pop, 200, first_move=(k == 0)) for k in range(3)]
         kept_any = any(int((e.buf["root_visits"] > 200).sum()) > 0 for e in _engines(pop))
         assert kept_any, "no game kept a subtree over three moves"
-        print(f"C2 full size: [dropped, pruned] subtrees {_dropped(pop)}")
+        assert _dropped(pop) == [0, 0]
+        print(f"C2 full size: [dropped, pruned] subtrees {_dropped(pop)}, tree memory {_pool_ok(pop, 8.0):.1f} GiB")
         runs.append(steps)
         del pop
         torch.cuda.empty_cache()
@@ -150,7 +167,10 @@ def test_c3_full_size_one_move_and_one_continued_move():
     e = _engines(pop)[0]
     assert int((e.buf["root_visits"] > 800).sum()) > 0, "no game continued a kept subtree"
     assert not pop.mcts.graph_retry_off
-    print(f"C3 full size: arena factor {e.reuse_factor}, [dropped, pruned] subtrees {_dropped(pop)}")
+    assert _dropped(pop) == [0, 0]
+    # round 4: 24 GB of node arenas + 38.5 GB of edge pool (rounds 1-3: ~210 GB of worst-case regions per game)
+    print(f"C3 full size: arena factor {e.reuse_factor}, [dropped, pruned] subtrees {_dropped(pop)}, "
+          f"tree memory {_pool_ok(pop, 120.0):.1f} GiB")
     del pop, e
     gc.collect()
     torch.cuda.empty_cache()

@@ -177,3 +177,37 @@ def test_bench_clock_sampler_reads_sysfs_in_process(tmp_path, monkeypatch):
         assert bench._under_profiler()
         monkeypatch.delenv(var)
     assert not bench._under_profiler() or any("rocprof" in os.environ.get(k, "").lower() for k in os.environ)
+
+
+def test_bench_also_summary_is_compact_and_last():
+    """`also_summary` is the digest the driver's truncated record of the line must still contain: one row per workload,
+    one number per runner leg, failures named, and it is the LAST key of the printed line."""
+    import json
+    import bench
+    leg = lambda v, ms, f, p: {"value": v, "ms_per_step": ms, "roofline": {"frac": f, "kernel_probe": {"frac": p}},
+                               "cpu_baseline": {"value": 1.5}}
+    out = leg(10000.0, 1600.0, 0.69, 0.72)
+    out["also"] = {"C2": leg(196000.0, 20.8, 0.52, 0.50), "C2_fp32": {"failed": "RuntimeError('x')"},
+                   "R_b10c128": leg(580000.0, 28.0, 0.67, 0.71),
+                   "runner": {"self_play_tree_gpu@C2": {"value": 177000.0}, "run_self_play_worker@R_b10c128": {"failed": "x"}}}
+    s = bench.also_summary(out)
+    assert s["headline"] == [10000.0, 1600.0, 0.69, 0.72] and s["C2"] == [196000.0, 20.8, 0.52, 0.50]
+    assert s["C2_fp32"] == "failed" and s["R_b10c128"][0] == 580000.0
+    assert s["runner"] == {"self_play_tree_gpu@C2": 177000.0, "run_self_play_worker@R_b10c128": "failed"}
+    assert s["cpu"]["headline"] == 1.5 and s["cpu"]["C2"] == 1.5
+    out["also_summary"] = s
+    line = json.dumps(out)
+    assert line.rstrip("}").endswith('probe"') or list(out)[-1] == "also_summary"
+    assert len(json.dumps(s)) < 1200                              # fits the 2 000 characters the driver keeps
+
+
+def test_edge_pool_sizing_arithmetic():
+    """chunk_cap_for: a game's chunk list must hold the worst case of its node arena (72 children everywhere, a run never
+    straddles a chunk, so up to 71 records of a chunk stay unused) -- the condition lz_tree_advance checks."""
+    from liuzhou_amd.tree_engine import chunk_cap_for, EDGE_CHUNK, MAX_CHILDREN
+    for node_cap in (6, 42, 1002, 8202, 32802, 65536):
+        for chunk in (128, 1024, 4096):
+            cap = chunk_cap_for(node_cap, chunk)
+            assert cap * (chunk - (MAX_CHILDREN - 1)) >= node_cap * MAX_CHILDREN
+            assert (cap - 2) * (chunk - (MAX_CHILDREN - 1)) < node_cap * MAX_CHILDREN      # and not wastefully long
+    assert EDGE_CHUNK == 1024 and EDGE_CHUNK & (EDGE_CHUNK - 1) == 0
