@@ -1117,6 +1117,16 @@ def self_play_tree_gpu(model, num_games: int, mcts_simulations: int, temperature
             timing["timing_calls"][k] = timing["timing_calls"].get(k, 0) + v["calls"]
     t_ms = {k: float(timing["timing_ms"].get(k, 0.0)) for k in keys}
     t_total = sum(t_ms.values())
+    # what the bounded arenas did to this run (the reference's tree is unbounded): must all be 0 for results that equal an
+    # unbounded tree's; a refused expansion means the edge pool was sized too small for this workload -- say so loudly
+    engines = [p.engine for p in getattr(mcts, "parts", [])] or [mcts.engine]
+    refused = sum(e.pool_status()["refused_expansions"] for e in engines)
+    dropped = sum(int(e.reuse_dropped[0].item()) for e in engines)
+    pruned = sum(int(e.reuse_dropped[1].item()) for e in engines)
+    if refused:
+        print(f"[liuzhou_amd] WARNING: {refused} tree expansions found no free edge chunk (pool of "
+              f"{sum(e.pool_chunks for e in engines)} chunks); those leaves stayed unexpanded for a visit.  Pass a larger "
+              "`pool_chunks` to TreeEngine or lower `concurrent_games`.", flush=True)
     stats = SelfPlayV1Stats(
         num_games=num_games, num_positions=batch.num_samples, black_wins=int(o[0]), white_wins=int(o[1]), draws=int(o[2]),
         avg_game_length=float(lengths.to(torch.float32).mean().item()), elapsed_sec=elapsed,
@@ -1129,6 +1139,7 @@ def self_play_tree_gpu(model, num_games: int, mcts_simulations: int, temperature
                        "masked_extra_plies": wasted_plies, "graph_retry_off": int(bool(mcts.graph_retry_off)),
                        # where the wall time outside `elapsed_sec` (the plies) goes: engine construction or cache hit,
                        # build() of the five tensors; graph capture happens inside the first plies
-                       "engine_cache_hit": int(cache_hit), "setup_ms": int(setup_sec * 1e3), "build_ms": int(build_sec * 1e3)},
+                       "engine_cache_hit": int(cache_hit), "setup_ms": int(setup_sec * 1e3), "build_ms": int(build_sec * 1e3),
+                       "reuse_pruned": pruned, "reuse_dropped": dropped, "edge_pool_refused": refused},
         piece_delta_buckets={str(d - 18): int(v) for d, v in enumerate(hist)}, device=str(dev))
     return batch, stats

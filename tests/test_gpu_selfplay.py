@@ -145,6 +145,8 @@ def test_tree_runner_engine_cache_gives_identical_games_and_follows_refreshed_we
     assert (s1.mcts_counters["engine_cache_hit"], s2.mcts_counters["engine_cache_hit"], s3.mcts_counters["engine_cache_hit"]) == (0, 1, 1)
     assert b1.num_samples == b2.num_samples == 48 * 12 and same(b1, b2) and not same(b1, b3)
     assert s2.mcts_counters["leaf_eval_count"] == s1.mcts_counters["leaf_eval_count"]
+    for st in (s1, s2, s3):                                      # nothing the bounded arenas did to these runs
+        assert (st.mcts_counters["edge_pool_refused"], st.mcts_counters["reuse_dropped"], st.mcts_counters["reuse_pruned"]) == (0, 0, 0)
     engine = next(iter(TE._ENGINE_CACHE.values()))
     assert engine.engine.pool_status()["refused_expansions"] == 0
     # new weights into the same device buffers: the cached engine must play what a fresh engine plays with them
