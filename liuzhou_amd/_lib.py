@@ -116,7 +116,7 @@ def host_lib() -> C.CDLL:
     global _host
     if _host is None:
         from .build import HOST_LIB, build_host
-        path = HOST_LIB if os.path.exists(HOST_LIB) else build_host()
+        path = os.environ.get("LZ_HOST_LIB") or (HOST_LIB if os.path.exists(HOST_LIB) else build_host())   # LZ_HOST_LIB: a sanitizer build
         H = C.CDLL(path)
         for name in HOST_SYMBOLS:
             fn = getattr(H, name)
