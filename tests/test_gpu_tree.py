@@ -134,13 +134,21 @@ def test_fused_search_runs_and_conserves_visits():
     assert bool(picked.all())
 
 
-@pytest.mark.parametrize("sims,games,moves,noise", [(48, 48, 4, True), (200, 24, 3, False)])
-def test_tree_reuse_bit_exact_vs_oracle_over_consecutive_moves(sims, games, moves, noise):
-    """a21 (advance_root): the played child's subtree is kept, compacted in place, re-noised and searched on."""
+@pytest.mark.parametrize("sims,games,moves,noise,chunk", [(48, 48, 4, True, None), (200, 24, 3, False, None),
+                                                           (160, 32, 5, True, 128), (96, 40, 4, True, 256)])
+def test_tree_reuse_bit_exact_vs_oracle_over_consecutive_moves(sims, games, moves, noise, chunk):
+    """a21 (advance_root): the played child's subtree is kept, compacted in place, re-noised and searched on.  With chunks
+    of 128 / 256 records the edge pool hands out a new chunk every few expansions and every compaction re-packs the kept runs
+    across many chunk boundaries: still the oracle's visit counts bit for bit, and no chunk is lost."""
     _need_gpu()
     from tests.tree_parity import run_injected_reuse_parity
-    eng, kept = run_injected_reuse_parity(DEV, num_games=games, sims=sims, moves=moves, seed=sims, with_noise=noise)
+    eng, kept = run_injected_reuse_parity(DEV, num_games=games, sims=sims, moves=moves, seed=sims, with_noise=noise,
+                                          edge_chunk=chunk)
     assert kept > 0, "no game ever kept a subtree -- the test did not exercise the reuse path"
+    st = eng.pool_status()
+    assert st["refused_expansions"] == 0 and int(eng.buf["n_chunks"].sum()) + st["free"] == st["chunks"]
+    if chunk is not None:
+        assert int(eng.buf["n_chunks"].max()) >= 4, "the small-chunk case did not cross chunk boundaries"
 
 
 def test_tree_reuse_falls_back_to_fresh_roots():

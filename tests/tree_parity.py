@@ -148,7 +148,7 @@ def run_injected_parity(device, num_games=64, sims=64, seed=0, states=None, c=1.
 
 
 def run_injected_reuse_parity(device, num_games=48, sims=48, moves=4, seed=3, c=1.0, with_noise=True, eps=0.25,
-                              reuse_factor=4.0):
+                              reuse_factor=4.0, edge_chunk=None):
     """Tree reuse (a21): `moves` consecutive searches per game; after each one the deterministic pick is played on
     both sides, the oracle promotes the child with `advance` (portable_mcts.py:74-87) and the GPU engine with
     lz_tree_advance.  Bit-exact visit counts / priors after every move, including the re-noised kept roots."""
@@ -160,7 +160,9 @@ def run_injected_reuse_parity(device, num_games=48, sims=48, moves=4, seed=3, c=
     idx0 = rng.integers(0, st_all["board"].shape[0], num_games)
     states = {f: np.ascontiguousarray(np.asarray(st_all[f])[idx0]) for f in FIELDS}
     B = num_games
-    eng = TreeEngine(B, sims, device, c, reuse_factor=reuse_factor)
+    # `edge_chunk`: small chunks of the edge pool (128 records) make every few expansions take a new chunk and every
+    # compaction of a kept subtree re-pack its runs across many chunk boundaries
+    eng = TreeEngine(B, sims, device, c, reuse_factor=reuse_factor, **({} if edge_chunk is None else {"edge_chunk": edge_chunk}))
     cur = [O.state_from_batch(states, i) for i in range(B)]
     trees = [O.OracleTree(cur[i], c) for i in range(B)]
     kept_total = 0
