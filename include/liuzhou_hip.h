@@ -204,7 +204,9 @@ LZ_API int lz_finalize_trajectory_inplace(float* value_targets, float* soft_valu
  * float32[11*36], legal mask uint8[T], policy float32[T] are copied into the arena row, value / soft targets are set
  * to NaN, sign = (current_player >= 0 ? 1 : -1); step_index[g, step_counts[g]++] = row; rows[g] = row (-1 for
  * finished slots); *cursor += live count.  A row >= capacity or a full step_index row drops the sample and bumps
- * *overflow (the host sizes both so that this never happens). */
+ * *overflow (the host sizes both so that this never happens).
+ * cursor == NULL and step_index_matrix == NULL select the SLOT-MAJOR arena of the finished-row log
+ * (lz_wave_log_finished): the row of slot g's step n is g * max_steps + n, capacity >= num_slots * max_steps. */
 LZ_API int lz_wave_record(const uint8_t* done, int64_t num_slots, int64_t* cursor, int64_t capacity,
                           int64_t max_steps, int64_t* step_index_matrix, int64_t* step_counts, int64_t* rows,
                           int32_t* overflow, const float* model_input, const uint8_t* legal_mask,
@@ -217,7 +219,8 @@ LZ_API int lz_wave_record(const uint8_t* done, int64_t num_slots, int64_t* curso
  * (module.cpp:547-630), outcome int64[3] += [black wins, white wins, draws] (games with >= 1 recorded step),
  * delta_hist int64[37] (optional) += final black-white piece difference clamped to [-18,18], lengths[slot_game ?
  * slot_game[g] : g] (optional) = recorded steps, *finished (optional) += 1.  reseat == 0: done[g] = 1.  reseat != 0: the slot restarts from the empty
- * board (plies, step_counts = 0, reseated[g] = 1 if given) -- the steady-state population of bench.py. */
+ * board (plies, step_counts = 0, reseated[g] = 1 if given) -- the steady-state population of bench.py.
+ * step_index_matrix == NULL: slot-major arena, the rows of slot g are g * max_steps + [0, step_counts[g]). */
 LZ_API int lz_wave_step_finish(const LzStateSoA* states, int64_t num_slots, int64_t* plies, uint8_t* done,
                                const int32_t* chosen_action_codes, const uint8_t* terminal_mask,
                                const uint8_t* chosen_valid_mask, int64_t max_game_plies, float soft_value_k,
@@ -229,10 +232,29 @@ LZ_API int lz_wave_step_finish(const LzStateSoA* states, int64_t num_slots, int6
 /* lz_wave_reseat: the wave loop of self_play_gpu_runner.py:84-90 starts the next `concurrent_games` games only when the
  * whole wave has finished; here finished slots (done[g] != 0, ascending g) restart from the empty board at once while
  * *budget (games not yet started) lasts: slot_game[g] = (*next_game)++, plies / step_counts = 0, done[g] = 0,
- * reseated[g] = 1 (optional); *budget is decremented.  Deterministic (one workgroup, ordered scan). */
+ * reseated[g] = 1 (optional); *budget is decremented.  Deterministic (one workgroup, ordered scan).
+ * logged_only != 0: a finished slot that still holds rows (step_counts[g] > 0, not yet taken by
+ * lz_wave_log_finished) is not re-seated. */
 LZ_API int lz_wave_reseat(const LzStateSoA* states, int64_t num_slots, uint8_t* done, int64_t* plies,
                           int64_t* step_counts, int64_t* budget, int64_t* next_game, int64_t* slot_game,
-                          uint8_t* reseated, void* stream);
+                          uint8_t* reseated, int logged_only, void* stream);
+
+/* lz_wave_log_finished: finished-row log of the streaming worker.  The reference worker sees the rows of a wave only
+ * after the whole wave has drained and copies them to the host with the GPU idle
+ * (v1/python/self_play_worker.py:430-546: `_run_once` -> `chunk_batch.to("cpu")` -> `save_self_play_payload`); here
+ * the rows of a game leave the slot-major live arena (lz_wave_record with cursor == NULL) for a game-major log the
+ * moment the game has ended, so finished samples can be copied out while the wave goes on playing.
+ * For every slot with done[g] != 0 and step_counts[g] > 0, in ascending slot order: its step_counts[g] rows (state
+ * float32[396], legal uint8[action_dim], policy float32[action_dim], value, soft value) are appended to the log at
+ * log_state[0] while they fit log_capacity, and step_counts[g] = 0; slots that do not fit wait (lz_wave_reseat with
+ * logged_only does not re-seat them).  log_state int64[4] = {rows in the log, games in the log, games waiting, rows
+ * waiting}; log_base int64[num_slots] is scratch.  Deterministic (one-workgroup ordered scan, then one wave per slot). */
+LZ_API int lz_wave_log_finished(const uint8_t* done, int64_t* step_counts, int64_t num_slots, int64_t max_steps,
+                                int64_t action_dim, const float* arena_state, const uint8_t* arena_legal,
+                                const float* arena_policy, const float* arena_value, const float* arena_soft,
+                                float* log_state_rows, uint8_t* log_legal, float* log_policy, float* log_value,
+                                float* log_soft, int64_t log_capacity, int64_t* log_state, int64_t* log_base,
+                                void* stream);
 
 /* ---- network forward ------------------------------------------------------------------------- */
 

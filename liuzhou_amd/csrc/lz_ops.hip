@@ -10,6 +10,8 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <mutex>
+
 #include "lz_soa.h"
 #include "lz_wave.h"
 
@@ -1049,12 +1051,27 @@ __global__ __launch_bounds__(kRowsBlock) void wave_rows_kernel(
     if (tid == 0) *cursor += total;
 }
 
+// Slot-major live arena (the finished-row log, lz_wave_log_finished): the sample of slot g's step n lives in row
+// g * Tmax + n until the game ends, so there is nothing to scan and no step_index matrix.
+__global__ __launch_bounds__(kBlock) void wave_rows_slot_kernel(
+    const uint8_t* __restrict__ done, int64_t G, int64_t Tmax, int64_t* __restrict__ step_counts,
+    int64_t* __restrict__ rows, int32_t* __restrict__ overflow) {
+    const int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (g >= G) return;
+    if (done[g] != 0) { rows[g] = -1; return; }
+    const int64_t n = step_counts[g];
+    if (n >= Tmax) { rows[g] = -1; atomicAdd(overflow, 1); return; }
+    rows[g] = g * Tmax + n;
+    step_counts[g] = n + 1;
+}
+
 // Start the next games in finished slots, in ascending slot order while the budget lasts (deterministic): slot g
 // restarts from the empty board as game *next_game + rank(g).  One workgroup, same scan as wave_rows_kernel.
+// `logged_only`: a finished slot whose rows have not left for the finished-row log yet (step_counts > 0) waits.
 __global__ __launch_bounds__(kRowsBlock) void wave_reseat_kernel(
     LzStateSoA s, int64_t G, uint8_t* __restrict__ done, int64_t* __restrict__ plies,
     int64_t* __restrict__ step_counts, int64_t* __restrict__ budget, int64_t* __restrict__ next_game,
-    int64_t* __restrict__ slot_game, uint8_t* __restrict__ reseated) {
+    int64_t* __restrict__ slot_game, uint8_t* __restrict__ reseated, int logged_only) {
     __shared__ int wave_total[kRowsBlock / kWave];
     const int tid = threadIdx.x, lane = tid & (kWave - 1), w = tid / kWave;
     const int64_t left = *budget;
@@ -1062,7 +1079,7 @@ __global__ __launch_bounds__(kRowsBlock) void wave_reseat_kernel(
     const int64_t per = (G + kRowsBlock - 1) / kRowsBlock;
     const int64_t lo = tid * per, hi = (lo + per < G) ? lo + per : G;
     int cnt = 0;
-    for (int64_t j = lo; j < hi; ++j) cnt += done[j] != 0 ? 1 : 0;
+    for (int64_t j = lo; j < hi; ++j) cnt += (done[j] != 0 && !(logged_only && step_counts[j] > 0)) ? 1 : 0;
     int incl = cnt;
 #pragma unroll
     for (int d = 1; d < kWave; d <<= 1) {
@@ -1077,7 +1094,7 @@ __global__ __launch_bounds__(kRowsBlock) void wave_reseat_kernel(
     int64_t rank = before + incl - cnt;
     __syncthreads();                                    // every thread has read budget / next_game
     for (int64_t j = lo; j < hi; ++j) {
-        if (done[j] == 0) continue;
+        if (done[j] == 0 || (logged_only && step_counts[j] > 0)) continue;
         if (rank < left) {
             State fresh{};
             fresh.phase = kPlacement;
@@ -1166,7 +1183,7 @@ __global__ __launch_bounds__(kBlock) void wave_step_finish_kernel(
     int64_t n = step_counts[g];
     if (n > Tmax) n = Tmax;
     for (int64_t j = lane; j < n; j += kWave) {
-        const int64_t idx = step_index[g * Tmax + j];
+        const int64_t idx = step_index ? step_index[g * Tmax + j] : g * Tmax + j;
         const float sg = (float)signs[idx];
         value_t[idx] = sg * res;
         soft_t[idx] = sg * sft;
@@ -1190,6 +1207,102 @@ __global__ __launch_bounds__(kBlock) void wave_step_finish_kernel(
             done[g] = 1;
         }
     }
+}
+
+// ---- finished-row log: the rows of a game leave the slot-major live arena for a game-major log the moment the game
+// has ended, so that a consumer can take finished samples away WHILE the wave goes on playing (the worker streams
+// them to the host; v1/python/self_play_worker.py:430-546 only sees its rows after a whole wave has drained).
+// Plan (one workgroup, ordered scan -> deterministic log order): the finished slots that still hold rows, in
+// ascending slot order, get log rows [cursor + prefix, +n) while they fit `capacity`; the others wait (back-pressure:
+// wave_reseat_kernel does not re-seat them, the host switches to an empty log within a few plies).
+// log_state int64[4] = {rows in the log, games in the log, games waiting, rows waiting}.
+__global__ __launch_bounds__(kRowsBlock) void wave_log_plan_kernel(
+    const uint8_t* __restrict__ done, const int64_t* __restrict__ step_counts, int64_t G, int64_t capacity,
+    int64_t* __restrict__ log_state, int64_t* __restrict__ log_base) {
+    __shared__ long long wave_rows[kRowsBlock / kWave];
+    __shared__ int fit_games[kRowsBlock / kWave], wait_games[kRowsBlock / kWave];
+    __shared__ long long fit_rows[kRowsBlock / kWave], wait_rows[kRowsBlock / kWave];
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), w = tid / kWave;
+    const int64_t per = (G + kRowsBlock - 1) / kRowsBlock;
+    const int64_t lo = tid * per, hi = (lo + per < G) ? lo + per : G;
+    long long cnt = 0;
+    for (int64_t j = lo; j < hi; ++j) cnt += (done[j] != 0 && step_counts[j] > 0) ? step_counts[j] : 0;
+    long long incl = cnt;
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+        const long long v = __shfl_up(incl, d, kWave);
+        if (lane >= d) incl += v;
+    }
+    if (lane == kWave - 1) wave_rows[w] = incl;
+    __syncthreads();
+    long long before = 0;
+    for (int i = 0; i < w; ++i) before += wave_rows[i];
+    const long long cursor = log_state[0];
+    long long pre = before + incl - cnt;                // rows of the waiting slots below this thread's range
+    int fg = 0, wg = 0;
+    long long fr = 0, wr = 0;
+    for (int64_t j = lo; j < hi; ++j) {
+        const long long n = (done[j] != 0 && step_counts[j] > 0) ? step_counts[j] : 0;
+        if (n == 0) { log_base[j] = -1; continue; }
+        if (cursor + pre + n <= capacity) { log_base[j] = cursor + pre; ++fg; fr += n; }
+        else { log_base[j] = -1; ++wg; wr += n; }
+        pre += n;
+    }
+    // prefixes are monotone, so the slots that fit are a prefix of the waiting list: their rows are contiguous
+#pragma unroll
+    for (int d = kWave / 2; d > 0; d >>= 1) {
+        fg += __shfl_xor(fg, d, kWave); wg += __shfl_xor(wg, d, kWave);
+        fr += __shfl_xor(fr, d, kWave); wr += __shfl_xor(wr, d, kWave);
+    }
+    if (lane == 0) { fit_games[w] = fg; wait_games[w] = wg; fit_rows[w] = fr; wait_rows[w] = wr; }
+    __syncthreads();                                    // also: every thread has read the cursor
+    if (tid == 0) {
+        long long a = 0, b = 0, c = 0, d2 = 0;
+        for (int i = 0; i < kRowsBlock / kWave; ++i) { a += fit_rows[i]; b += fit_games[i]; c += wait_games[i]; d2 += wait_rows[i]; }
+        log_state[0] = cursor + a;
+        log_state[1] += b;
+        log_state[2] = c;
+        log_state[3] = d2;
+    }
+}
+
+// one wave per slot: the n rows of slot g (contiguous in the slot-major arena) -> log rows [log_base[g], +n)
+__global__ __launch_bounds__(kBlock) void wave_log_copy_kernel(
+    const int64_t* __restrict__ log_base, int64_t* __restrict__ step_counts, int64_t G, int64_t Tmax, int T,
+    const float* __restrict__ a_state, const uint8_t* __restrict__ a_legal, const float* __restrict__ a_policy,
+    const float* __restrict__ a_value, const float* __restrict__ a_soft, float* __restrict__ l_state,
+    uint8_t* __restrict__ l_legal, float* __restrict__ l_policy, float* __restrict__ l_value,
+    float* __restrict__ l_soft) {
+    const int lane = lane_id();
+    const int64_t g = wave_item();
+    if (g >= G) return;
+    const int64_t base = log_base[g];
+    if (base < 0) return;
+    const int64_t n = step_counts[g], src = g * Tmax;
+    constexpr int kIn = 11 * 36;                         // 1 584 B: float4 copies (row starts are 16-byte multiples)
+    {
+        const float4* in = reinterpret_cast<const float4*>(a_state + src * kIn);
+        float4* out = reinterpret_cast<float4*>(l_state + base * kIn);
+        for (int64_t j = lane; j < n * (kIn / 4); j += kWave) out[j] = in[j];
+    }
+    if ((T & 3) == 0) {
+        const float4* in = reinterpret_cast<const float4*>(a_policy + src * T);
+        float4* out = reinterpret_cast<float4*>(l_policy + base * T);
+        for (int64_t j = lane; j < n * (T / 4); j += kWave) out[j] = in[j];
+        const uint32_t* li = reinterpret_cast<const uint32_t*>(a_legal + src * T);
+        uint32_t* lo = reinterpret_cast<uint32_t*>(l_legal + base * T);
+        for (int64_t j = lane; j < n * (T / 4); j += kWave) lo[j] = li[j];
+    } else {
+        for (int64_t j = lane; j < n * T; j += kWave) {
+            l_policy[base * T + j] = a_policy[src * T + j];
+            l_legal[base * T + j] = a_legal[src * T + j];
+        }
+    }
+    for (int64_t j = lane; j < n; j += kWave) {
+        l_value[base + j] = a_value[src + j];
+        l_soft[base + j] = a_soft[src + j];
+    }
+    if (lane == 0) step_counts[g] = 0;                  // logged: the slot may start its next game
 }
 
 inline unsigned grid_waves(int64_t items) { return (unsigned)((items + kWavesPerBlock - 1) / kWavesPerBlock); }
@@ -1344,14 +1457,30 @@ int lz_root_puct_allocate_visits(const float* priors, const float* leaf, const u
     // table-driven pulls (bit-identical, about half the instructions) for budgets the tables cover;
     // LZ_ROOT_PUCT_DIV=1 forces the division kernel (tests compare the two)
     const char* force = getenv("LZ_ROOT_PUCT_DIV");
-    if (sims <= kPuctTable && !(force && force[0] == '1')) {
+    bool use_tables = sims <= kPuctTable && !(force && force[0] == '1');
+    if (use_tables) {
+        // The tables are filled ONCE per device, synchronously: the flag is only set after the fill has completed and
+        // been checked, so no launch on any stream can read a partial table.  A stream that is being
+        // captured cannot be synchronised: such a call takes the division kernel until an eager call has filled the
+        // tables (FusedRootSearch makes one before it captures).
+        static std::mutex tables_mu;
         static bool tables_ready[64] = {};
         int device = 0;
         if (hipGetDevice(&device) != hipSuccess || device < 0 || device >= 64) return LZ_ERR_LAUNCH;
-        if (!tables_ready[device]) {   // once per device; a capture in progress simply records the fill with the search
-            hipLaunchKernelGGL(puct_tables_kernel, dim3((kPuctTable + 3 + 255) / 256), dim3(256), 0, st);
-            tables_ready[device] = true;
+        std::lock_guard<std::mutex> lk(tables_mu);
+        if (!tables_ready[device]) {
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            if (hipStreamIsCapturing(st, &cs) != hipSuccess) return LZ_ERR_LAUNCH;
+            if (cs == hipStreamCaptureStatusNone) {
+                hipLaunchKernelGGL(puct_tables_kernel, dim3((kPuctTable + 3 + 255) / 256), dim3(256), 0, st);
+                if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return LZ_ERR_LAUNCH;
+                tables_ready[device] = true;
+            } else {
+                use_tables = false;
+            }
         }
+    }
+    if (use_tables) {
         if (A <= 64) hipLaunchKernelGGL(root_puct_fast_kernel<1>, grid, block, 0, st, priors, leaf, valid, R, (int)A, (int)sims, c, visits, value_sum, root_values);
         else if (A <= 128) hipLaunchKernelGGL(root_puct_fast_kernel<2>, grid, block, 0, st, priors, leaf, valid, R, (int)A, (int)sims, c, visits, value_sum, root_values);
         else hipLaunchKernelGGL(root_puct_fast_kernel<4>, grid, block, 0, st, priors, leaf, valid, R, (int)A, (int)sims, c, visits, value_sum, root_values);
@@ -1430,12 +1559,19 @@ int lz_wave_record(const uint8_t* done, int64_t G, int64_t* cursor, int64_t capa
                    void* stream) {
     if (G < 0 || capacity < 0 || Tmax <= 0 || T <= 0) return LZ_ERR_ARG;
     if (G == 0) return LZ_OK;
-    if (!done || !cursor || !step_index || !step_counts || !rows || !overflow || !model_input || !legal_mask || !policy ||
+    if (!done || !step_counts || !rows || !overflow || !model_input || !legal_mask || !policy ||
         !current_player || !a_state || !a_legal || !a_policy || !a_value || !a_soft || !a_sign)
         return LZ_ERR_ARG;
+    if ((cursor == nullptr) != (step_index == nullptr)) return LZ_ERR_ARG;
     hipStream_t st = as_stream(stream);
-    hipLaunchKernelGGL(wave_rows_kernel, dim3(1), dim3(kRowsBlock), 0, st, done, G, cursor, capacity, Tmax, step_index,
-                       step_counts, rows, overflow);
+    if (!cursor) {                                       // slot-major live arena: row = slot * Tmax + step
+        if (capacity < G * Tmax) return LZ_ERR_ARG;
+        hipLaunchKernelGGL(wave_rows_slot_kernel, dim3(grid_threads(G)), dim3(kBlock), 0, st, done, G, Tmax, step_counts,
+                           rows, overflow);
+    } else {
+        hipLaunchKernelGGL(wave_rows_kernel, dim3(1), dim3(kRowsBlock), 0, st, done, G, cursor, capacity, Tmax, step_index,
+                           step_counts, rows, overflow);
+    }
     hipLaunchKernelGGL(wave_record_kernel, dim3(grid_waves(G)), dim3(kBlock), 0, st, rows, G, model_input, legal_mask,
                        policy, current_player, (int)T, a_state, a_legal, a_policy, a_value, a_soft, a_sign);
     return launch_status();
@@ -1449,8 +1585,8 @@ int lz_wave_step_finish(const LzStateSoA* s, int64_t G, int64_t* plies, uint8_t*
     if (G < 0 || max_plies <= 0 || Tmax <= 0) return LZ_ERR_ARG;
     if (G == 0) return LZ_OK;
     if (!soa_ok(s) || !plies || !done || !codes || !terminal || !cvalid || !value_t || !soft_t || !signs ||
-        !step_index || !step_counts || !outcome)
-        return LZ_ERR_ARG;
+        !step_counts || !outcome)
+        return LZ_ERR_ARG;                                 // step_index == NULL: slot-major arena (row = g * Tmax + j)
     if (!soa_aligned(s) || !aligned(codes, 16)) return LZ_ERR_ALIGN;
     hipLaunchKernelGGL(wave_step_finish_kernel, dim3(grid_waves(G)), dim3(kBlock), 0, as_stream(stream), *s, G, plies,
                        done, reinterpret_cast<const int4*>(codes), terminal, cvalid, max_plies, k, value_t, soft_t,
@@ -1461,13 +1597,33 @@ int lz_wave_step_finish(const LzStateSoA* s, int64_t G, int64_t* plies, uint8_t*
 }
 
 int lz_wave_reseat(const LzStateSoA* s, int64_t G, uint8_t* done, int64_t* plies, int64_t* step_counts, int64_t* budget,
-                   int64_t* next_game, int64_t* slot_game, uint8_t* reseated, void* stream) {
+                   int64_t* next_game, int64_t* slot_game, uint8_t* reseated, int logged_only, void* stream) {
     if (G < 0) return LZ_ERR_ARG;
     if (G == 0) return LZ_OK;
     if (!soa_ok(s) || !done || !plies || !step_counts || !budget || !next_game || !slot_game) return LZ_ERR_ARG;
     if (!soa_aligned(s)) return LZ_ERR_ALIGN;
     hipLaunchKernelGGL(wave_reseat_kernel, dim3(1), dim3(kRowsBlock), 0, as_stream(stream), *s, G, done, plies,
-                       step_counts, budget, next_game, slot_game, reseated);
+                       step_counts, budget, next_game, slot_game, reseated, logged_only);
+    return launch_status();
+}
+
+int lz_wave_log_finished(const uint8_t* done, int64_t* step_counts, int64_t G, int64_t Tmax, int64_t T,
+                         const float* a_state, const uint8_t* a_legal, const float* a_policy, const float* a_value,
+                         const float* a_soft, float* l_state, uint8_t* l_legal, float* l_policy, float* l_value,
+                         float* l_soft, int64_t log_capacity, int64_t* log_state, int64_t* log_base, void* stream) {
+    if (G < 0 || Tmax <= 0 || T <= 0 || log_capacity < 0) return LZ_ERR_ARG;
+    if (G == 0) return LZ_OK;
+    if (!done || !step_counts || !a_state || !a_legal || !a_policy || !a_value || !a_soft || !l_state || !l_legal ||
+        !l_policy || !l_value || !l_soft || !log_state || !log_base)
+        return LZ_ERR_ARG;
+    if (!aligned(a_state, 16) || !aligned(l_state, 16) || !aligned(a_policy, 16) || !aligned(l_policy, 16) ||
+        !aligned(a_legal, 4) || !aligned(l_legal, 4))
+        return LZ_ERR_ALIGN;
+    hipStream_t st = as_stream(stream);
+    hipLaunchKernelGGL(wave_log_plan_kernel, dim3(1), dim3(kRowsBlock), 0, st, done, step_counts, G, log_capacity,
+                       log_state, log_base);
+    hipLaunchKernelGGL(wave_log_copy_kernel, dim3(grid_waves(G)), dim3(kBlock), 0, st, log_base, step_counts, G, Tmax,
+                       (int)T, a_state, a_legal, a_policy, a_value, a_soft, l_state, l_legal, l_policy, l_value, l_soft);
     return launch_status();
 }
 

@@ -21,6 +21,15 @@ _DELTA_MIN, _DELTA_MAX = -18, 18
 _TRACKED = ("root_puct_ms", "pack_writeback_ms", "self_play_step_ms", "finalize_ms")
 
 
+def streaming_supported(model, *, opening_random_moves: int = 0, child_eval_mode: str = "value_only", sparse_ply: int = 1,
+                        inference_engine=None, collect_step_timing: bool = False) -> bool:
+    """True when `self_play_v1_gpu` would take the fused search + device tail for these options, i.e. when it can feed a
+    finished-row log (`row_log`)."""
+    return (hasattr(model, "desc") and inference_engine is None and int(opening_random_moves) == 0 and
+            str(child_eval_mode) == "value_only" and int(sparse_ply) <= 1 and not collect_step_timing and
+            os.environ.get("LZ_WAVE_TAIL", "1") != "0")
+
+
 def self_play_v1_gpu(model, num_games: int, mcts_simulations: int, temperature_init: float,
                      temperature_final: float, temperature_threshold: int, exploration_weight: float, device: str,
                      add_dirichlet_noise: bool = True, dirichlet_alpha: float = 0.3, dirichlet_epsilon: float = 0.25,
@@ -28,8 +37,11 @@ def self_play_v1_gpu(model, num_games: int, mcts_simulations: int, temperature_i
                      sample_moves: bool = True, concurrent_games: int = 8, child_eval_mode: str = "value_only",
                      sparse_ply: int = 1, sparse_top_k: int = 8, inference_engine=None,
                      collect_step_timing: bool = False, verbose: bool = False,
-                     autocast_dtype: str = "float16", fused_search: bool = True, continuous_waves: bool = True
-                     ) -> Tuple[TensorSelfPlayBatch, SelfPlayV1Stats]:
+                     autocast_dtype: str = "float16", fused_search: bool = True, continuous_waves: bool = True,
+                     row_log=None) -> Tuple[TensorSelfPlayBatch, SelfPlayV1Stats]:
+    """`row_log` (finished_log.FinishedRowLog, the streaming worker): the rows of every game leave through the log when
+    the game ends and the returned batch is empty; needs the fused search with the device tail and continuous waves
+    (`streaming_supported`)."""
     if num_games <= 0:
         raise ValueError("num_games must be positive.")
     dev = torch.device(device)
@@ -63,8 +75,11 @@ def self_play_v1_gpu(model, num_games: int, mcts_simulations: int, temperature_i
     tail = None
     if fused is not None and os.environ.get("LZ_WAVE_TAIL", "1") != "0":   # device-side record / move / finalise (wave_tail.py)
         from .wave_tail import WaveTail
-        tail = WaveTail(buffer, wave, max_plies, dev, soft_value_k=float(soft_value_k))
+        tail = WaveTail(buffer, wave, max_plies, dev, soft_value_k=float(soft_value_k), row_log=row_log)
         outcome, delta_hist = tail.outcome, tail.delta_hist
+    if row_log is not None and not (tail is not None and bool(continuous_waves)):
+        raise RuntimeError("self_play_v1_gpu: a finished-row log needs the fused search, the device tail and continuous "
+                           "waves (fused network, value_only children, sparse_ply 1, no opening moves, no step timing)")
     lengths = torch.zeros((int(num_games),), dtype=torch.int64, device=dev)
     timing_ms: Dict[str, float] = {k: 0.0 for k in _TRACKED}
     timing_calls: Dict[str, int] = {k: 0 for k in _TRACKED}
@@ -90,7 +105,7 @@ def self_play_v1_gpu(model, num_games: int, mcts_simulations: int, temperature_i
     for base in range(0, wave if continuous else int(num_games), wave):
         g = min(wave, int(num_games) - base)
         states = GpuStateBatch.initial(dev, g)
-        step_index = torch.full((g, max_plies), -1, dtype=torch.int64, device=dev)
+        step_index = None if row_log is not None else torch.full((g, max_plies), -1, dtype=torch.int64, device=dev)
         step_counts = torch.zeros((g,), dtype=torch.int64, device=dev)
         plies = torch.zeros((g,), dtype=torch.int64, device=dev)
         done = torch.zeros((g,), dtype=torch.bool, device=dev)
@@ -152,6 +167,8 @@ def self_play_v1_gpu(model, num_games: int, mcts_simulations: int, temperature_i
         torch.cuda.synchronize(dev)
     if tail is not None:
         tail.check_overflow()
+    if row_log is not None:
+        row_log.close()                                      # the last segment leaves; the rows are the consumer's now
     elapsed = max(1e-9, time.perf_counter() - started)
     for name, s, e in events:
         timing_ms[name] += float(s.elapsed_time(e)); timing_calls[name] += 1
@@ -164,10 +181,11 @@ def self_play_v1_gpu(model, num_games: int, mcts_simulations: int, temperature_i
     total = sum(timing_ms[k] for k in _TRACKED)
     o = outcome.tolist()
     hist = delta_hist.tolist()
+    positions = int(lengths.sum().item()) if row_log is not None else batch.num_samples
     stats = SelfPlayV1Stats(
-        num_games=num_games, num_positions=batch.num_samples, black_wins=int(o[0]), white_wins=int(o[1]),
+        num_games=num_games, num_positions=positions, black_wins=int(o[0]), white_wins=int(o[1]),
         draws=int(o[2]), avg_game_length=float(lengths.to(torch.float32).mean().item()), elapsed_sec=elapsed,
-        positions_per_sec=float(batch.num_samples / elapsed), games_per_sec=float(num_games / elapsed),
+        positions_per_sec=float(positions / elapsed), games_per_sec=float(num_games / elapsed),
         step_timing_ms={k: float(timing_ms[k]) for k in _TRACKED},
         step_timing_ratio={k: (float(timing_ms[k]) / total if total > 0 else 0.0) for k in _TRACKED},
         step_timing_calls={k: int(timing_calls[k]) for k in _TRACKED},

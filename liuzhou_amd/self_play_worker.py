@@ -1,8 +1,15 @@
 """Per-device self-play worker (mirror of v1/python/self_play_worker.py:276-552).
 
-`run_self_play_worker(**kwargs)` takes the reference's 33 keyword arguments, runs the shard in chunks of
-`concurrent_games_per_device` games, writes chunk payloads (`payload_format: v1_sharded_shard`) plus a worker
-manifest (`payload_format: v1_worker_chunk_manifest`) and returns the same dict.  `search_backend`:
+`run_self_play_worker(**kwargs)` takes the reference's 33 keyword arguments, plays the shard on
+`concurrent_games_per_device` slots, writes chunk payloads (`payload_format: v1_sharded_shard`) plus a worker
+manifest (`payload_format: v1_worker_chunk_manifest`) and returns the same dict.
+
+Pipelined (round 5, `stream_worker_shard`): ONE wave plays the whole shard -- a finished slot starts the next game at
+once, across what the reference calls chunks -- and the rows of finished games stream out while it plays: device
+finished-row log (finished_log.py) -> pinned host staging on a side stream (copier thread) -> `torch.save` of the chunk
+payloads (writer thread).  The reference's loop (`write_worker_chunks`: play a chunk to the end, `.to("cpu")`, save, with
+the GPU idle; v1/python/self_play_worker.py:430-546) stays as the path for the options the device tail does not cover
+and behind `LZ_WORKER_STREAM=0`.  Same file names, payload keys, dtypes and manifest keys either way.  `search_backend`:
   "cuda_root" (reference default) -> root-PUCT over the HIP operators (self_play_v1_gpu)
   "portable" / "tree"            -> device-resident full-tree PUCT engine (self_play_tree_gpu)
 Networks with 64 / 128 trunk channels run on the fused fp16-MFMA kernel; anything else uses PyTorch.
@@ -10,15 +17,18 @@ Networks with 64 / 128 trunk channels run on the fused fp16-MFMA kernel; anythin
 from __future__ import annotations
 
 import os
+import queue
+import threading
 import time
 import traceback
-from typing import Any, Dict, List, Optional
+from typing import Any, Callable, Dict, List, Optional
 
 import torch
 
 from .net import ChessNet
 from .self_play_storage import estimate_bytes_per_sample, plan_sample_ranges, save_self_play_payload, slice_batch_cpu
 from .self_play_types import SelfPlayV1Stats
+from .trajectory_buffer import TensorSelfPlayBatch
 
 _SUMMARY_COUNTS = ("total", "finite_count", "nonfinite_count", "nonzero_count", "zero_count", "positive_count",
                    "negative_count", "near_zero_count", "ge_abs_0p05_count", "ge_abs_0p10_count", "ge_abs_0p20_count")
@@ -185,6 +195,208 @@ def write_worker_chunks(run_once, *, worker_idx: int, device: str, games: int, g
             "num_samples": int(sum(sizes)), "saved_chunks": len(files)}
 
 
+class ShardStreamer:
+    """Host half of the streaming worker: takes the segments the finished-row log cuts (`on_segment`, called on the playing
+    thread: a queue put), copies each to pinned staging on its own stream (copier thread; the log arena goes back to the
+    player as soon as the copy has landed) and writes the chunk payloads (writer thread; `torch.save` releases the GIL).
+    Two staging buffers: the copy of segment k+1 overlaps the write of segment k; a writer that cannot keep up holds the
+    staging buffers, then the log arenas, then -- through the kernels' back-pressure -- the slots of finished games."""
+
+    def __init__(self, device: torch.device, capacity_rows: int, action_dim: int, write_segment: Callable[..., None],
+                 staging_buffers: int = 2) -> None:
+        self.device, self.capacity, self.A = torch.device(device), int(capacity_rows), int(action_dim)
+        self.write_segment = write_segment
+        self.n_staging = max(1, int(staging_buffers))
+        self.segments: "queue.Queue" = queue.Queue()
+        self.copied: "queue.Queue" = queue.Queue()
+        self.free_staging: "queue.Queue" = queue.Queue()
+        self.error: Optional[BaseException] = None
+        self._closed = False
+        self.rows = self.games = 0
+        self.copy_ms = self.write_ms = 0.0
+        self._threads = [threading.Thread(target=self._guard, args=(self._copier,), name="lz-shard-copier", daemon=True),
+                         threading.Thread(target=self._guard, args=(self._writer,), name="lz-shard-writer", daemon=True)]
+        for t in self._threads:
+            t.start()
+
+    def on_segment(self, seg) -> None:
+        self.raise_if_failed()
+        self.segments.put(seg)
+
+    def raise_if_failed(self) -> None:
+        if self.error is not None:
+            raise RuntimeError("streaming shard writer failed") from self.error
+
+    def _guard(self, fn) -> None:
+        try:
+            fn()
+        except BaseException as exc:  # noqa: BLE001 -- handed to the playing thread (on_segment / on_blocked / finish)
+            if self.error is None:
+                self.error = exc
+
+    def _get(self, q: "queue.Queue"):
+        """Blocking get that gives up when the other thread (or the player) has failed."""
+        while True:
+            try:
+                return q.get(timeout=0.1)
+            except queue.Empty:
+                if self.error is not None or self._closed:
+                    raise RuntimeError("streaming shard writer: stopped") from self.error
+
+    def _copier(self) -> None:
+        torch.cuda.set_device(self.device)
+        side = torch.cuda.Stream(self.device)
+        cap, A = self.capacity, self.A
+        for _ in range(self.n_staging):                          # pinned once, while the first games are being played
+            self.free_staging.put((torch.empty((cap, 11, 6, 6), dtype=torch.float32).pin_memory(),
+                                   torch.empty((cap, A), dtype=torch.bool).pin_memory(),
+                                   torch.empty((cap, A), dtype=torch.float32).pin_memory(),
+                                   torch.empty((cap,), dtype=torch.float32).pin_memory(),
+                                   torch.empty((cap,), dtype=torch.float32).pin_memory()))
+        while True:
+            seg = self._get(self.segments)
+            staging = self._get(self.free_staging)
+            t0 = time.perf_counter()
+            with torch.cuda.stream(side):
+                side.wait_event(seg.ready)
+                rows, games = (int(x) for x in seg.arena.counters[:2].tolist())     # waits for `ready` only (side stream)
+                a = seg.arena
+                for dst, src in zip(staging, (a.state, a.legal, a.policy, a.value, a.soft)):
+                    dst[:rows].copy_(src[:rows], non_blocking=True)
+                side.synchronize()
+            seg.release()                                        # the player may fill this arena again
+            self.copy_ms += (time.perf_counter() - t0) * 1e3
+            self.copied.put((staging, rows, games, seg.number))
+            if seg.final:
+                break
+        self.copied.put(None)
+
+    def _writer(self) -> None:
+        while True:
+            item = self._get(self.copied)
+            if item is None:
+                break
+            staging, rows, games, number = item
+            t0 = time.perf_counter()
+            if rows > 0:
+                self.write_segment(staging, rows, games, number)
+            self.rows += rows
+            self.games += games
+            self.write_ms += (time.perf_counter() - t0) * 1e3
+            self.free_staging.put(staging)
+
+    def finish(self) -> None:
+        """Wait until every segment is on disk (call after the runner has closed the log)."""
+        for t in self._threads:
+            while t.is_alive() and self.error is None:
+                t.join(timeout=0.2)
+        self.abort()
+        self.raise_if_failed()
+
+    def abort(self) -> None:
+        """Stop the threads (they notice within 0.1 s) -- the player has failed, or everything is written."""
+        self._closed = True
+
+
+def _host_view(t: torch.Tensor, start: int, end: int) -> torch.Tensor:
+    """Rows [start, end) of a host tensor as a tensor whose storage is exactly those bytes (no copy): `torch.save` writes a
+    tensor's whole storage, and the staging buffers are as large as a log arena."""
+    return torch.from_numpy(t.numpy()[int(start):int(end)])
+
+
+def stream_worker_shard(play, *, device: torch.device, worker_idx: int, games: int, games_per_chunk: int,
+                        max_game_plies: int, soft_label_alpha: float, chunk_dir: str, chunk_prefix: str,
+                        chunk_file_ext: str, output_path: str, target_samples_per_shard: int, chunk_target_bytes: int,
+                        meta_common: Dict[str, Any], segment_games: Optional[int] = None,
+                        action_dim: int = 220) -> Dict[str, Any]:
+    """The pipelined worker: `play(row_log) -> SelfPlayV1Stats` runs the whole shard on `games_per_chunk` slots with the
+    finished-row log attached.  A payload file holds the games that ended in one segment of the log (`segment_games`,
+    default a quarter of `games_per_chunk`, so that what is left to write when the last game ends is small), cut further
+    by `chunk_target_bytes` / `target_samples_per_shard` exactly as the reference cuts a chunk (`plan_sample_ranges`)."""
+    from .finished_log import FinishedRowLog
+    alpha = float(max(0.0, min(1.0, soft_label_alpha)))
+    if segment_games is None:
+        env = str(os.environ.get("LZ_WORKER_SEGMENT_GAMES", "")).strip()
+        segment_games = int(env) if env else max(1, int(games_per_chunk) // 4)
+    val_s, soft_s, mix_s = [], [], []
+    files: List[str] = []
+    sizes: List[int] = []
+    bps = [0, 0]
+
+    def write_segment(staging, rows: int, seg_games: int, number: int) -> None:
+        state, legal, policy, value, soft = (t[:rows] for t in staging)
+        val_s.append(summarize_scalar_targets(value))
+        soft_s.append(summarize_scalar_targets(soft))
+        mix_s.append(summarize_scalar_targets(torch.clamp((1.0 - alpha) * value + alpha * soft, -1.0, 1.0)))
+        whole = TensorSelfPlayBatch(state, legal, policy, value, soft)
+        b = estimate_bytes_per_sample(whole)
+        bps[0] += b * max(1, rows)
+        bps[1] += max(1, rows)
+        for lo, hi in plan_sample_ranges(total_samples=rows, num_shards=1,
+                                         target_samples_per_shard=int(target_samples_per_shard),
+                                         chunk_target_bytes=int(chunk_target_bytes), bytes_per_sample=b):
+            name = f"{chunk_prefix}.chunk{len(files):05d}{chunk_file_ext}"
+            meta = {"payload_format": "v1_sharded_shard", "worker_idx": int(worker_idx), "device": str(device),
+                    "games": int(games), "games_per_chunk": int(games_per_chunk),
+                    "num_selfplay_batches": int(number) + 1, "saved_chunk_index": len(files)}
+            meta.update(meta_common)
+            meta["source_worker_manifest"] = os.path.basename(str(output_path))
+            save_self_play_payload(path=os.path.join(chunk_dir, name),
+                                   samples=TensorSelfPlayBatch(*(_host_view(t, lo, hi) for t in staging)),
+                                   stats_payload={}, metadata=meta)
+            files.append(name)
+            sizes.append(int(hi - lo))
+
+    wave = max(1, min(int(games), int(games_per_chunk)))
+    env_rows = str(os.environ.get("LZ_WORKER_LOG_ROWS", "")).strip()      # rows per log arena (tests: force back-pressure)
+    log = FinishedRowLog(device, segment_games=int(segment_games), num_slots=wave, max_steps=int(max_game_plies),
+                         action_dim=int(action_dim), capacity_rows=int(env_rows) if env_rows else None)
+    streamer = ShardStreamer(device, log.capacity, int(action_dim), write_segment)
+    log.on_segment = streamer.on_segment
+    log.on_blocked = streamer.raise_if_failed
+    started = time.perf_counter()
+    try:
+        st = play(log)
+    except BaseException:
+        streamer.abort()
+        raise
+    play_sec = time.perf_counter() - started
+    streamer.finish()
+    if int((st.mcts_counters or {}).get("graph_retry_off", 0)):
+        meta_common["graph_retry_off"] = True
+    if streamer.rows != int(st.num_positions):
+        raise RuntimeError(f"streaming worker: {streamer.rows} rows written, the runner recorded {int(st.num_positions)}")
+    stats = merge_self_play_stats([st], max(1e-9, time.perf_counter() - started))
+    stats.mcts_counters.update({"stream_segments": int(log.segments_cut), "stream_blocked_polls": int(log.blocked_polls),
+                                "stream_copy_ms": int(streamer.copy_ms), "stream_write_ms": int(streamer.write_ms),
+                                "stream_tail_ms": int((time.perf_counter() - started - play_sec) * 1e3)})
+    wmeta = {"worker_idx": int(worker_idx), "device": str(device), "games": int(games),
+             "games_per_chunk": int(games_per_chunk), "num_selfplay_batches": int(log.segments_cut),
+             "saved_chunks": len(files)}
+    wmeta.update(meta_common)
+    manifest = {
+        "payload_format": "v1_worker_chunk_manifest", "version": 1, "num_samples": int(sum(sizes)),
+        "num_shards": len(files), "shard_files": list(files), "shard_sizes": list(sizes),
+        "chunk_target_bytes": int(chunk_target_bytes), "avg_bytes_per_sample": int(bps[0] // max(1, bps[1])),
+        "stats": stats.to_dict(), "value_target_summary": merge_target_summaries(val_s),
+        "soft_value_target_summary": merge_target_summaries(soft_s),
+        "mixed_value_target_summary": merge_target_summaries(mix_s), "metadata": wmeta,
+    }
+    os.makedirs(os.path.dirname(str(output_path)) or ".", exist_ok=True)
+    torch.save(manifest, str(output_path))
+    return {"worker_idx": int(worker_idx), "device": str(device), "games": int(games), "output_path": str(output_path),
+            "num_samples": int(sum(sizes)), "saved_chunks": len(files)}
+
+
+def _drop_engines() -> None:
+    """The worker's network dies with the call, so the tree engines cached on it (tens of GB of arenas) go too."""
+    try:
+        from .tree_engine import clear_engine_cache
+        clear_engine_cache()
+    except Exception:
+        pass
+
+
 def run_self_play_worker(*, worker_idx: int, shard_device: str, shard_games: int, seed: int, model_state_path: str,
                          output_path: str, mcts_simulations: int, temperature_init: float, temperature_final: float,
                          temperature_threshold: int, exploration_weight: float, dirichlet_alpha: float,
@@ -228,8 +440,13 @@ def run_self_play_worker(*, worker_idx: int, shard_device: str, shard_games: int
                              "manifest output.")
 
         chunk_no = [0]
+        tree = backend in ("portable", "tree")
+        stream = os.environ.get("LZ_WORKER_STREAM", "1") != "0"
+        if stream and not tree:
+            from .self_play_gpu_runner import streaming_supported
+            stream = streaming_supported(evaluator, opening_random_moves=int(opening_random_moves), sparse_ply=int(sparse_ply))
 
-        def run_once(n: int):
+        def run_once(n: int, row_log=None):
             chunk_no[0] += 1                  # every chunk plays NEW games: its own RNG key (game ids restart per chunk)
             rng_seed = (int(seed) * 1000003 + chunk_no[0]) & 0x7FFFFFFFFFFFFFFF
             common = dict(num_games=n, mcts_simulations=int(mcts_simulations), temperature_init=float(temperature_init),
@@ -243,10 +460,10 @@ def run_self_play_worker(*, worker_idx: int, shard_device: str, shard_games: int
                 return self_play_tree_gpu(evaluator, opening_random_moves=int(opening_random_moves),
                                           policy_target_temperature=policy_target_temperature,
                                           policy_target_prior_pseudocount=float(policy_target_prior_pseudocount),
-                                          seed=rng_seed, collect_timing=True, **common)
+                                          seed=rng_seed, collect_timing=True, row_log=row_log, **common)
             from .self_play_gpu_runner import self_play_v1_gpu
             return self_play_v1_gpu(evaluator, opening_random_moves=int(opening_random_moves), sparse_ply=int(sparse_ply),
-                                    sparse_top_k=int(sparse_top_k), **common)
+                                    sparse_top_k=int(sparse_top_k), row_log=row_log, **common)
 
         meta_common = {"graph_retry_off": False, "memory_anchor_mb": int(anchor_mb),
                        "opening_random_moves": int(opening_random_moves), "search_backend": str(search_backend),
@@ -254,11 +471,20 @@ def run_self_play_worker(*, worker_idx: int, shard_device: str, shard_games: int
                        "portable_cpp_threads": int(portable_cpp_threads),
                        "policy_target_temperature": policy_target_temperature,
                        "policy_target_prior_pseudocount": float(policy_target_prior_pseudocount)}
+        if stream:
+            os.makedirs(chunk_dir, exist_ok=True)
+            return stream_worker_shard(lambda log: run_once(games, row_log=log)[1], device=dev, worker_idx=int(worker_idx),
+                                       games=games, games_per_chunk=concurrent, max_game_plies=int(max_game_plies),
+                                       soft_label_alpha=float(soft_label_alpha), chunk_dir=chunk_dir, chunk_prefix=prefix,
+                                       chunk_file_ext=str(chunk_file_ext), output_path=str(output_path),
+                                       target_samples_per_shard=int(target_samples_per_shard),
+                                       chunk_target_bytes=int(chunk_target_bytes), meta_common=meta_common)
         return write_worker_chunks(run_once, worker_idx=int(worker_idx), device=str(dev), games=games,
                                    games_per_chunk=concurrent, soft_label_alpha=float(soft_label_alpha),
                                    chunk_dir=chunk_dir, chunk_prefix=prefix, chunk_file_ext=str(chunk_file_ext),
                                    output_path=str(output_path), target_samples_per_shard=int(target_samples_per_shard),
                                    chunk_target_bytes=int(chunk_target_bytes), meta_common=meta_common)
     except Exception as exc:
+        _drop_engines()
         raise RuntimeError(f"v1 self-play process worker failed: worker={int(worker_idx)}, device={shard_device}, "
                            f"games={int(shard_games)}\n{traceback.format_exc()}") from exc

@@ -81,6 +81,15 @@ class TensorTrajectoryBuffer:
         self._device_dirty = True
         return self._cursor
 
+    def reserve_slot_major(self, num_slots: int, max_steps: int, shape: Tuple[int, int, int] = (11, 6, 6)) -> None:
+        """Slot-major live arena of the finished-row log (finished_log.py): row = slot * max_steps + step; the rows of a
+        game leave for the log when the game ends, so `build()` has nothing to return in this mode."""
+        need = int(num_slots) * int(max_steps)
+        if self._state is None or self._capacity < need:
+            if self._size or self._device_dirty:
+                raise RuntimeError("TensorTrajectoryBuffer: slot-major mode needs an empty buffer")
+            self._allocate(need, tuple(shape))
+
     def sync_cursor(self) -> int:
         """Read the device cursor back (one host synchronisation)."""
         if self._device_dirty:

@@ -670,6 +670,8 @@ class PortableTreeMCTS:
         self.extra_rounds = 0
         self.engine.eval_count.zero_()
         self.engine.reuse_dropped.zero_()
+        # refused expansions / fewest free chunks are per run too (a cached engine must not report an earlier run's)
+        self.engine.buf["pool_stats"].copy_(torch.tensor([0, self.engine.pool_chunks], dtype=torch.int32))
         self.get_timing(reset=True)
         if self.batch_k > 1:
             self.engine.wbuf["eval_total"].zero_(); self.engine.wbuf["eval_count"].zero_()
@@ -979,15 +981,19 @@ def self_play_tree_gpu(model, num_games: int, mcts_simulations: int, temperature
                        policy_target_prior_pseudocount: float = 0.0, reuse_tree: bool = True,
                        reuse_factor: float = -1.0, dual_stream: Optional[bool] = None, continuous_waves: bool = True,
                        device_tail: bool = True, batch_k: int = 1, evaluator: str = "auto", seed: int = 12345,
-                       collect_timing: bool = False) -> Tuple[TensorSelfPlayBatch, SelfPlayV1Stats]:
+                       collect_timing: bool = False, row_log=None) -> Tuple[TensorSelfPlayBatch, SelfPlayV1Stats]:
     """Tree-search twin of self_play_v1_gpu (same outputs); mirrors v1/python/portable_self_play.py:82-284,
     including the subtree reuse it performs on every move (:191, `reuse_tree`).
     `model` may also be a `PriorEvaluator` (states -> priors over the 220 actions + values, the reference's own
     split-phase hand-off).  `evaluator`: "fused" = the hand-written fp16 network kernel inside the captured search (6x64 / 10x128 nets);
     "module" = `model` itself as an external fp32 evaluator behind the split-phase protocol, whatever its size or
     device (what the reference's portable runner does with its `model`); "auto" = fused when the net has a fused
-    kernel.  `seed`: key of the per-game counter RNG (noise, sampled moves); game ids are the runner's game numbers."""
+    kernel.  `seed`: key of the per-game counter RNG (noise, sampled moves); game ids are the runner's game numbers.
+    `row_log` (finished_log.FinishedRowLog, the streaming worker): the rows of every game leave through the log when the
+    game ends and the returned batch is empty; needs `device_tail` and `continuous_waves`."""
     dev = torch.device(device)
+    if row_log is not None and not (device_tail and continuous_waves):
+        raise RuntimeError("self_play_tree_gpu: a finished-row log needs device_tail and continuous_waves")
     if evaluator not in ("auto", "fused", "module"):
         raise ValueError(f"evaluator must be auto / fused / module, got {evaluator!r}")
     if isinstance(model, FusedNet):
@@ -1016,8 +1022,11 @@ def self_play_tree_gpu(model, num_games: int, mcts_simulations: int, temperature
     # shape -- the worker calls this once per chunk and the staged loop once per iteration, and construction + capture
     # were 12.5 % of a C2 run.  `FusedNet.refresh()` writes new weights into the same buffers, so a
     # cached graph stays valid across checkpoints.  A PriorEvaluator / external module is never cached.
+    # Only a caller-owned FusedNet is a stable key: for a module a fresh FusedNet is packed per call, its engine could
+    # never be found again and would only pin its arenas.  Engines stay alive after the return -- call
+    # `clear_engine_cache()` before handing the GPU's memory to something else (training on the same device).
     key = None
-    if use_fused and _engine_cache_limit() > 0:
+    if use_fused and isinstance(model, FusedNet) and _engine_cache_limit() > 0:
         key = (cls.__name__, int(net.pack.wfrag.data_ptr()), int(net.pack.fparams.data_ptr()), int(net.desc.flags),
                str(dev), wave, int(mcts_simulations), tuple(sorted((k, repr(v)) for k, v in kw.items())),
                os.environ.get("LZ_TREE_GRAPH", "on"), os.environ.get("LZ_TREE_PERSISTENT", "0"))
@@ -1043,7 +1052,7 @@ def self_play_tree_gpu(model, num_games: int, mcts_simulations: int, temperature
     delta_hist = None
     if device_tail:
         from .wave_tail import WaveTail
-        tail = WaveTail(buffer, wave, int(max_game_plies), dev, soft_value_k=float(soft_value_k))
+        tail = WaveTail(buffer, wave, int(max_game_plies), dev, soft_value_k=float(soft_value_k), row_log=row_log)
         tail.collect_timing = bool(collect_timing)
         outcome, delta_hist = tail.outcome, tail.delta_hist
     continuous = tail is not None and bool(continuous_waves)
@@ -1052,7 +1061,7 @@ def self_play_tree_gpu(model, num_games: int, mcts_simulations: int, temperature
     for base in range(0, wave if continuous else int(num_games), wave):
         g = min(wave, int(num_games) - base)
         states = GpuStateBatch.initial(dev, wave)
-        step_index = torch.full((wave, max_game_plies), -1, dtype=torch.int64, device=dev)
+        step_index = None if row_log is not None else torch.full((wave, max_game_plies), -1, dtype=torch.int64, device=dev)
         step_counts = torch.zeros((wave,), dtype=torch.int64, device=dev)
         plies = torch.zeros((wave,), dtype=torch.int64, device=dev)
         done = torch.zeros((wave,), dtype=torch.bool, device=dev)
@@ -1103,10 +1112,13 @@ def self_play_tree_gpu(model, num_games: int, mcts_simulations: int, temperature
     elapsed = max(1e-9, time.perf_counter() - started)
     if tail is not None:
         tail.check_overflow()
+    if row_log is not None:
+        row_log.close()                                      # the last segment leaves; the rows are the consumer's now
     t_build = time.perf_counter()
     batch = buffer.build()
     torch.cuda.synchronize(dev)
     build_sec = time.perf_counter() - t_build
+    positions = int(lengths.sum().item()) if row_log is not None else batch.num_samples
     o = outcome.tolist()
     hist = delta_hist.tolist() if delta_hist is not None else []
     keys = ("root_puct_ms", "pack_writeback_ms", "self_play_step_ms", "finalize_ms")
@@ -1128,9 +1140,9 @@ def self_play_tree_gpu(model, num_games: int, mcts_simulations: int, temperature
               f"{sum(e.pool_chunks for e in engines)} chunks); those leaves stayed unexpanded for a visit.  Pass a larger "
               "`pool_chunks` to TreeEngine or lower `concurrent_games`.", flush=True)
     stats = SelfPlayV1Stats(
-        num_games=num_games, num_positions=batch.num_samples, black_wins=int(o[0]), white_wins=int(o[1]), draws=int(o[2]),
+        num_games=num_games, num_positions=positions, black_wins=int(o[0]), white_wins=int(o[1]), draws=int(o[2]),
         avg_game_length=float(lengths.to(torch.float32).mean().item()), elapsed_sec=elapsed,
-        positions_per_sec=float(batch.num_samples / elapsed), games_per_sec=float(num_games / elapsed),
+        positions_per_sec=float(positions / elapsed), games_per_sec=float(num_games / elapsed),
         step_timing_ms=t_ms, step_timing_ratio={k: (t_ms[k] / t_total if t_total > 0 else 0.0) for k in keys},
         step_timing_calls={k: int(timing["timing_calls"].get(k, 0)) for k in keys},
         # the device-tail loop runs one fully masked ply per wave after the last game has ended (wave_tail.WaveTail.run)

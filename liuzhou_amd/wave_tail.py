@@ -20,7 +20,7 @@ DELTA_BINS = 37
 
 class WaveTail:
     def __init__(self, buffer: TensorTrajectoryBuffer, num_slots: int, max_game_plies: int, device,
-                 soft_value_k: float = 2.0, reseat: bool = False) -> None:
+                 soft_value_k: float = 2.0, reseat: bool = False, row_log=None) -> None:
         dev = torch.device(device)
         if dev.type != "cuda":
             raise RuntimeError("WaveTail needs a HIP device (no CPU path)")
@@ -35,6 +35,14 @@ class WaveTail:
         self.slot_game = torch.arange(self.G, dtype=torch.int64, device=dev)   # game number played in each slot (run())
         self.collect_timing = False
         self._timing_events = []
+        # finished_log.FinishedRowLog: the live rows are slot-major (row = slot * max_plies + step, no step_index matrix)
+        # and the rows of a game move to the log when the game ends (the streaming worker)
+        self.row_log = row_log
+        if row_log is not None:
+            if reseat:
+                raise ValueError("WaveTail: the finished-row log needs run()'s re-seating (reseat=False)")
+            if int(row_log.G) != self.G or int(row_log.Tmax) != self.max_plies:
+                raise ValueError("WaveTail: the finished-row log was built for another wave shape")
 
     def _bracket(self, name: str):
         """HIP-event bracket + roctx range for one tail kernel sequence (bucket names of the reference's runner,
@@ -69,13 +77,18 @@ class WaveTail:
                search: RootSearchBatchOutput) -> None:
         """Append this ply's sample of every live slot to the trajectory arena."""
         G = self.G
-        cursor = self.buffer.reserve_rows(G, tuple(int(x) for x in search.model_input.shape[1:]))
+        shape = tuple(int(x) for x in search.model_input.shape[1:])
+        if self.row_log is not None:
+            cursor, steps = None, self.max_plies
+            self.buffer.reserve_slot_major(G, steps, shape)
+        else:
+            cursor, steps = self.buffer.reserve_rows(G, shape), int(step_index.shape[1])
         a_state, a_legal, a_policy, a_value, a_soft, a_sign = self.buffer.arena()
         mi, lm, pol = search.model_input.contiguous(), search.legal_mask.contiguous(), search.policy_dense.contiguous()
         T = int(pol.shape[1])
         with torch.cuda.device(self.device):
             L.check(L.lib().lz_wave_record(
-                L.ptr(done), L.i64(G), L.ptr(cursor), L.i64(self.buffer.capacity), L.i64(int(step_index.shape[1])),
+                L.ptr(done), L.i64(G), L.ptr(cursor), L.i64(self.buffer.capacity), L.i64(steps),
                 L.ptr(step_index), L.ptr(step_counts), L.ptr(self.rows), L.ptr(self.overflow), L.ptr(mi), L.ptr(lm),
                 L.ptr(pol), L.ptr(states.current_player), L.i64(T), L.ptr(a_state), L.ptr(a_legal), L.ptr(a_policy),
                 L.ptr(a_value), L.ptr(a_soft), L.ptr(a_sign), L.stream_ptr(self.device)), "wave_record")
@@ -95,7 +108,8 @@ class WaveTail:
             L.check(L.lib().lz_wave_step_finish(
                 C.byref(L.soa(ts)), L.i64(self.G), L.ptr(plies), L.ptr(done), L.ptr(codes), L.ptr(term), L.ptr(cvalid),
                 L.i64(self.max_plies), C.c_float(self.soft_k), L.ptr(a_value), L.ptr(a_soft), L.ptr(a_sign),
-                L.ptr(step_index), L.ptr(step_counts), L.i64(int(step_index.shape[1])), L.ptr(self.outcome),
+                L.ptr(step_index), L.ptr(step_counts),
+                L.i64(self.max_plies if step_index is None else int(step_index.shape[1])), L.ptr(self.outcome),
                 L.ptr(self.delta_hist), L.ptr(lengths), L.ptr(slot_game), L.ptr(self.finished), L.ptr(reseated),
                 C.c_int(1 if self.reseat else 0), L.stream_ptr(self.device)), "wave_step_finish")
 
@@ -106,7 +120,8 @@ class WaveTail:
         with torch.cuda.device(self.device):
             L.check(L.lib().lz_wave_reseat(C.byref(L.soa(states.tensors())), L.i64(self.G), L.ptr(done), L.ptr(plies),
                                            L.ptr(step_counts), L.ptr(budget), L.ptr(next_game), L.ptr(slot_game),
-                                           L.ptr(reseated), L.stream_ptr(self.device)), "wave_reseat")
+                                           L.ptr(reseated), C.c_int(1 if self.row_log is not None else 0),
+                                           L.stream_ptr(self.device)), "wave_reseat")
 
     def run(self, search_fn, states: GpuStateBatch, plies: torch.Tensor, done: torch.Tensor, step_index: torch.Tensor,
             step_counts: torch.Tensor, lengths: torch.Tensor, t_init: float, t_final: float, t_threshold: int,
@@ -117,8 +132,13 @@ class WaveTail:
         whose game has finished starts the next game at once (lz_wave_reseat) instead of idling until the whole wave
         is done; `lengths` is then indexed by game.  The loop ends on the `all done` flag of TWO plies ago (copied to
         pinned memory behind an event), so the host stays one ply ahead of the device; the price is exactly one
-        extra, fully masked ply at the end.  Returns the number of plies launched (including that one)."""
+        extra, fully masked ply at the end.  Returns the number of plies launched (including that one).
+        With a finished-row log (`row_log`) `step_index` is None, the rows of the games that have ended move to the log
+        after every ply, and the loop ends when every game has ended AND is in a log (which the caller then closes)."""
         dev, g = self.device, self.G
+        log = self.row_log
+        if (log is None) == (step_index is None):
+            raise ValueError("WaveTail.run: pass a step_index matrix, or build the tail with a finished-row log")
         flags = [torch.zeros((1,), dtype=torch.bool).pin_memory() for _ in range(2)]
         events = [torch.cuda.Event() for _ in range(2)]
         budget = torch.full((1,), int(games_to_start), dtype=torch.int64, device=dev)
@@ -133,6 +153,8 @@ class WaveTail:
                 events[k].synchronize()
                 if bool(flags[k].item()):
                     break
+                if log is not None:
+                    log.poll(k)                                   # may switch log arenas (a segment leaves)
             if games_to_start > 0 and ply > 0:
                 self.start_next_games(states, plies, done, step_counts, budget, next_game, slot_game, reseated)
             temps = torch.where(plies < int(t_threshold), float(t_init), float(t_final)).to(torch.float32)
@@ -143,7 +165,13 @@ class WaveTail:
             with self._bracket("self_play_step_ms"):
                 self.step_finish(states, plies, done, step_index, step_counts, search, lengths=lengths, slot_game=slot_game)
             # all finished and nothing left to start (a finished slot restarts at the top of the next ply otherwise)
-            flags[k].copy_((done.all() & (budget <= 0).all()).view(1), non_blocking=True)
+            if log is not None:
+                if ply == 0:
+                    log.bind(self.buffer.arena())
+                log.after_ply(done, step_counts, k)
+                flags[k].copy_((done.all() & (budget <= 0).all() & (log.waiting() == 0)).view(1), non_blocking=True)
+            else:
+                flags[k].copy_((done.all() & (budget <= 0).all()).view(1), non_blocking=True)
             events[k].record(torch.cuda.current_stream(dev))
             ply += 1
         return ply
