@@ -64,7 +64,8 @@ class FinishedRowLog:
         self.device, self.G, self.Tmax, self.A = dev, int(num_slots), int(max_steps), int(action_dim)
         self.segment_games = max(1, int(segment_games))
         # a segment of `segment_games` games of ~130 rows, plus the games that end while the host is two plies behind
-        cap = int(capacity_rows) if capacity_rows else self.segment_games * 192 + 4 * self.G
+        # (~G / 130 per ply); whatever does not fit waits a ply or two in its slot (back-pressure), nothing is lost
+        cap = int(capacity_rows) if capacity_rows else self.segment_games * 160 + 2 * self.G
         self.capacity = max(cap, 2 * self.Tmax)
         self.on_segment = on_segment
         self.on_blocked: Optional[Callable[[], None]] = None      # called when a cut finds no free arena (consumer health check)
@@ -114,7 +115,7 @@ class FinishedRowLog:
         if self._pinned_gen[k] != self.gen:
             return
         rows, games, waiting, _ = (int(x) for x in self._pinned[k].tolist())
-        if games >= self.segment_games or waiting > 0 or rows >= self.capacity - 2 * self.G:
+        if games >= self.segment_games or waiting > 0 or rows >= self.capacity - self.G:
             if not self._switch(final=False):
                 self.blocked_polls += 1
                 if self.on_blocked is not None:

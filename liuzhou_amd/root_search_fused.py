@@ -178,7 +178,8 @@ class DualStreamRootSearch:
         self.parts = [FusedRootSearch(net, b - a, num_simulations, dev, out={k: v[a:b] for k, v in self.out.items()},
                                       game_offset=a, game_stride=B, **kw)
                       for a, b in self.bounds]
-        self.streams = tuple(torch.cuda.Stream(dev) for _ in self.parts)
+        from .streams import overlapping_streams
+        self.streams = overlapping_streams(dev, len(self.parts))
         self.serialize = False        # measurement aid: run the halves one after the other on the caller's stream
 
     @property

@@ -190,7 +190,9 @@ def self_play_v1_gpu(model, num_games: int, mcts_simulations: int, temperature_i
         step_timing_ratio={k: (float(timing_ms[k]) / total if total > 0 else 0.0) for k in _TRACKED},
         step_timing_calls={k: int(timing_calls[k]) for k in _TRACKED},
         mcts_counters={**{k: int(v) for k, v in mt["counters"].items()},
-                       **({"leaf_eval_count": int(fused.leaf_evals), "fused_root_search": 1} if fused is not None else {})},
+                       **({"leaf_eval_count": int(fused.leaf_evals), "fused_root_search": 1} if fused is not None else {}),
+                       **({"loop_ms": int(tail.loop_ms), "host_wait_ms": int(tail.host_wait_ms),
+                           "plies_launched": int(tail.plies_launched)} if tail is not None else {})},
         piece_delta_buckets={str(d): int(hist[d - _DELTA_MIN]) for d in range(_DELTA_MIN, _DELTA_MAX + 1)},
         device=str(dev))
     return batch, stats

@@ -62,6 +62,28 @@ def summarize_scalar_targets(values: torch.Tensor) -> Dict[str, Any]:
     return _finish_summary(d)
 
 
+def summarize_scalar_targets_np(values) -> Dict[str, Any]:
+    """`summarize_scalar_targets` on a numpy view, single-threaded: the streaming writer runs beside the playing thread, and
+    a torch CPU operator there wakes the whole intra-op thread pool (one thread per core of the host) under the playing
+    thread's feet -- measured: the two halves of a C2 search stop overlapping and a run takes up to 1.5x as long."""
+    import numpy as np
+    d: Dict[str, Any] = {k: 0 for k in _SUMMARY_COUNTS}
+    d["sum_abs"] = 0.0
+    v = np.asarray(values).reshape(-1)
+    total = int(v.size)
+    if total > 0:
+        fv = v[np.isfinite(v)]
+        a = np.abs(fv)
+        d.update(total=total, finite_count=int(fv.size), nonfinite_count=total - int(fv.size),
+                 positive_count=int((fv > 0).sum()), negative_count=int((fv < 0).sum()),
+                 sum_abs=float(a.sum(dtype=np.float32)), near_zero_count=int((a <= 1e-6).sum()),
+                 ge_abs_0p05_count=int((a >= 0.05).sum()), ge_abs_0p10_count=int((a >= 0.10).sum()),
+                 ge_abs_0p20_count=int((a >= 0.20).sum()))
+        d["nonzero_count"] = d["positive_count"] + d["negative_count"]
+        d["zero_count"] = d["finite_count"] - d["nonzero_count"]
+    return _finish_summary(d)
+
+
 def merge_target_summaries(summaries: List[Dict[str, Any]]) -> Dict[str, Any]:
     d: Dict[str, Any] = {k: 0 for k in _SUMMARY_COUNTS}
     d["sum_abs"] = 0.0
@@ -199,14 +221,18 @@ class ShardStreamer:
     """Host half of the streaming worker: takes the segments the finished-row log cuts (`on_segment`, called on the playing
     thread: a queue put), copies each to pinned staging on its own stream (copier thread; the log arena goes back to the
     player as soon as the copy has landed) and writes the chunk payloads (writer thread; `torch.save` releases the GIL).
-    Two staging buffers: the copy of segment k+1 overlaps the write of segment k; a writer that cannot keep up holds the
-    staging buffers, then the log arenas, then -- through the kernels' back-pressure -- the slots of finished games."""
+    `plan_segment(rows, number)` runs on the copier thread, in segment order (file names are assigned there);
+    `write_segment(staging, rows, plan)` on one of `writers` threads (a `torch.save` is one core's memcpy + crc32, 2.6 - 4.4
+    GB/s on the GPU box: three writers keep up with the burst of games that end while the last wave drains).  One staging
+    buffer more than writers: the copy of the next segment overlaps the writes; writers that cannot keep up hold the staging
+    buffers, then the log arenas, then -- through the kernels' back-pressure -- the slots of finished games."""
 
-    def __init__(self, device: torch.device, capacity_rows: int, action_dim: int, write_segment: Callable[..., None],
-                 staging_buffers: int = 2) -> None:
+    def __init__(self, device: torch.device, capacity_rows: int, action_dim: int, plan_segment: Callable[..., Any],
+                 write_segment: Callable[..., None], writers: int = 3) -> None:
         self.device, self.capacity, self.A = torch.device(device), int(capacity_rows), int(action_dim)
-        self.write_segment = write_segment
-        self.n_staging = max(1, int(staging_buffers))
+        self.plan_segment, self.write_segment = plan_segment, write_segment
+        self.n_writers = max(1, int(writers))
+        self.n_staging = self.n_writers + 1
         self.segments: "queue.Queue" = queue.Queue()
         self.copied: "queue.Queue" = queue.Queue()
         self.free_staging: "queue.Queue" = queue.Queue()
@@ -214,8 +240,10 @@ class ShardStreamer:
         self._closed = False
         self.rows = self.games = 0
         self.copy_ms = self.write_ms = 0.0
-        self._threads = [threading.Thread(target=self._guard, args=(self._copier,), name="lz-shard-copier", daemon=True),
-                         threading.Thread(target=self._guard, args=(self._writer,), name="lz-shard-writer", daemon=True)]
+        self._lock = threading.Lock()
+        self._threads = [threading.Thread(target=self._guard, args=(self._copier,), name="lz-shard-copier", daemon=True)] + [
+            threading.Thread(target=self._guard, args=(self._writer,), name=f"lz-shard-writer{i}", daemon=True)
+            for i in range(self.n_writers)]
         for t in self._threads:
             t.start()
 
@@ -247,15 +275,23 @@ class ShardStreamer:
         torch.cuda.set_device(self.device)
         side = torch.cuda.Stream(self.device)
         cap, A = self.capacity, self.A
-        for _ in range(self.n_staging):                          # pinned once, while the first games are being played
-            self.free_staging.put((torch.empty((cap, 11, 6, 6), dtype=torch.float32).pin_memory(),
-                                   torch.empty((cap, A), dtype=torch.bool).pin_memory(),
-                                   torch.empty((cap, A), dtype=torch.float32).pin_memory(),
-                                   torch.empty((cap,), dtype=torch.float32).pin_memory(),
-                                   torch.empty((cap,), dtype=torch.float32).pin_memory()))
+        allocated = 0
         while True:
             seg = self._get(self.segments)
-            staging = self._get(self.free_staging)
+            # Staging buffers are pinned on demand, one tensor at a time: pinning blocks the other threads' HIP calls
+            # while it runs (~80 ms per GB measured), and the playing thread is only two plies ahead of the device
+            try:
+                staging = self.free_staging.get_nowait()
+            except queue.Empty:
+                if allocated < self.n_staging:
+                    staging = (torch.empty((cap, 11, 6, 6), dtype=torch.float32, pin_memory=True),
+                               torch.empty((cap, A), dtype=torch.bool, pin_memory=True),
+                               torch.empty((cap, A), dtype=torch.float32, pin_memory=True),
+                               torch.empty((cap,), dtype=torch.float32, pin_memory=True),
+                               torch.empty((cap,), dtype=torch.float32, pin_memory=True))
+                    allocated += 1
+                else:
+                    staging = self._get(self.free_staging)
             t0 = time.perf_counter()
             with torch.cuda.stream(side):
                 side.wait_event(seg.ready)
@@ -266,23 +302,25 @@ class ShardStreamer:
                 side.synchronize()
             seg.release()                                        # the player may fill this arena again
             self.copy_ms += (time.perf_counter() - t0) * 1e3
-            self.copied.put((staging, rows, games, seg.number))
+            self.copied.put((staging, rows, games, self.plan_segment(rows, seg.number) if rows > 0 else None))
             if seg.final:
                 break
-        self.copied.put(None)
+        for _ in range(self.n_writers):
+            self.copied.put(None)
 
     def _writer(self) -> None:
         while True:
             item = self._get(self.copied)
             if item is None:
                 break
-            staging, rows, games, number = item
+            staging, rows, games, plan = item
             t0 = time.perf_counter()
-            if rows > 0:
-                self.write_segment(staging, rows, games, number)
-            self.rows += rows
-            self.games += games
-            self.write_ms += (time.perf_counter() - t0) * 1e3
+            if rows > 0 and os.environ.get("LZ_WORKER_NOWRITE", "0") != "1":     # experiment switch: copy out, write nothing
+                self.write_segment(staging, rows, plan)
+            with self._lock:
+                self.rows += rows
+                self.games += games
+                self.write_ms += (time.perf_counter() - t0) * 1e3              # summed over the writers
             self.free_staging.put(staging)
 
     def finish(self) -> None:
@@ -298,6 +336,11 @@ class ShardStreamer:
         self._closed = True
 
 
+def _ROW_BYTES(action_dim: int) -> int:
+    """Bytes of one sample in the five payload tensors (estimate_bytes_per_sample of a full batch): 2 692 for 220 actions."""
+    return 11 * 36 * 4 + int(action_dim) * (1 + 4) + 4 + 4
+
+
 def _host_view(t: torch.Tensor, start: int, end: int) -> torch.Tensor:
     """Rows [start, end) of a host tensor as a tensor whose storage is exactly those bytes (no copy): `torch.save` writes a
     tensor's whole storage, and the staging buffers are as large as a log arena."""
@@ -308,53 +351,67 @@ def stream_worker_shard(play, *, device: torch.device, worker_idx: int, games: i
                         max_game_plies: int, soft_label_alpha: float, chunk_dir: str, chunk_prefix: str,
                         chunk_file_ext: str, output_path: str, target_samples_per_shard: int, chunk_target_bytes: int,
                         meta_common: Dict[str, Any], segment_games: Optional[int] = None,
-                        action_dim: int = 220) -> Dict[str, Any]:
+                        action_dim: int = 220, extra_counters: Optional[Dict[str, int]] = None) -> Dict[str, Any]:
     """The pipelined worker: `play(row_log) -> SelfPlayV1Stats` runs the whole shard on `games_per_chunk` slots with the
     finished-row log attached.  A payload file holds the games that ended in one segment of the log (`segment_games`,
-    default a quarter of `games_per_chunk`, so that what is left to write when the last game ends is small), cut further
+    default an eighth of `games_per_chunk`, so that what is left to write when the last game ends is small), cut further
     by `chunk_target_bytes` / `target_samples_per_shard` exactly as the reference cuts a chunk (`plan_sample_ranges`)."""
     from .finished_log import FinishedRowLog
     alpha = float(max(0.0, min(1.0, soft_label_alpha)))
     if segment_games is None:
         env = str(os.environ.get("LZ_WORKER_SEGMENT_GAMES", "")).strip()
-        segment_games = int(env) if env else max(1, int(games_per_chunk) // 4)
+        segment_games = int(env) if env else max(1, int(games_per_chunk) // 8)
     val_s, soft_s, mix_s = [], [], []
     files: List[str] = []
     sizes: List[int] = []
     bps = [0, 0]
+    summary_lock = threading.Lock()
 
-    def write_segment(staging, rows: int, seg_games: int, number: int) -> None:
-        state, legal, policy, value, soft = (t[:rows] for t in staging)
-        val_s.append(summarize_scalar_targets(value))
-        soft_s.append(summarize_scalar_targets(soft))
-        mix_s.append(summarize_scalar_targets(torch.clamp((1.0 - alpha) * value + alpha * soft, -1.0, 1.0)))
-        whole = TensorSelfPlayBatch(state, legal, policy, value, soft)
-        b = estimate_bytes_per_sample(whole)
-        bps[0] += b * max(1, rows)
-        bps[1] += max(1, rows)
+    def plan_segment(rows: int, number: int):
+        """File names and row ranges of one segment (copier thread, segment order)."""
+        plan = []
         for lo, hi in plan_sample_ranges(total_samples=rows, num_shards=1,
                                          target_samples_per_shard=int(target_samples_per_shard),
-                                         chunk_target_bytes=int(chunk_target_bytes), bytes_per_sample=b):
+                                         chunk_target_bytes=int(chunk_target_bytes), bytes_per_sample=_ROW_BYTES(action_dim)):
             name = f"{chunk_prefix}.chunk{len(files):05d}{chunk_file_ext}"
             meta = {"payload_format": "v1_sharded_shard", "worker_idx": int(worker_idx), "device": str(device),
                     "games": int(games), "games_per_chunk": int(games_per_chunk),
                     "num_selfplay_batches": int(number) + 1, "saved_chunk_index": len(files)}
             meta.update(meta_common)
             meta["source_worker_manifest"] = os.path.basename(str(output_path))
+            plan.append((name, lo, hi, meta))
+            files.append(name)
+            sizes.append(int(hi - lo))
+        return plan
+
+    def write_segment(staging, rows: int, plan) -> None:
+        import numpy as np
+        state, legal, policy, value, soft = (t[:rows] for t in staging)
+        v_np, s_np = value.numpy(), soft.numpy()                  # numpy, not torch: no intra-op thread pool (see above)
+        summaries = (summarize_scalar_targets_np(v_np), summarize_scalar_targets_np(s_np),
+                     summarize_scalar_targets_np(np.clip(np.float32(1.0 - alpha) * v_np + np.float32(alpha) * s_np,
+                                                         np.float32(-1.0), np.float32(1.0))))
+        b = estimate_bytes_per_sample(TensorSelfPlayBatch(state, legal, policy, value, soft))
+        with summary_lock:
+            val_s.append(summaries[0]); soft_s.append(summaries[1]); mix_s.append(summaries[2])
+            bps[0] += b * max(1, rows)
+            bps[1] += max(1, rows)
+        for name, lo, hi, meta in plan:
             save_self_play_payload(path=os.path.join(chunk_dir, name),
                                    samples=TensorSelfPlayBatch(*(_host_view(t, lo, hi) for t in staging)),
                                    stats_payload={}, metadata=meta)
-            files.append(name)
-            sizes.append(int(hi - lo))
 
+    t_stream = time.perf_counter()
     wave = max(1, min(int(games), int(games_per_chunk)))
     env_rows = str(os.environ.get("LZ_WORKER_LOG_ROWS", "")).strip()      # rows per log arena (tests: force back-pressure)
     log = FinishedRowLog(device, segment_games=int(segment_games), num_slots=wave, max_steps=int(max_game_plies),
                          action_dim=int(action_dim), capacity_rows=int(env_rows) if env_rows else None)
-    streamer = ShardStreamer(device, log.capacity, int(action_dim), write_segment)
+    streamer = ShardStreamer(device, log.capacity, int(action_dim), plan_segment, write_segment,
+                             writers=int(os.environ.get("LZ_WORKER_WRITERS", "3") or 3))
     log.on_segment = streamer.on_segment
     log.on_blocked = streamer.raise_if_failed
     started = time.perf_counter()
+    log_setup_ms = int((started - t_stream) * 1e3)
     try:
         st = play(log)
     except BaseException:
@@ -369,7 +426,9 @@ def stream_worker_shard(play, *, device: torch.device, worker_idx: int, games: i
     stats = merge_self_play_stats([st], max(1e-9, time.perf_counter() - started))
     stats.mcts_counters.update({"stream_segments": int(log.segments_cut), "stream_blocked_polls": int(log.blocked_polls),
                                 "stream_copy_ms": int(streamer.copy_ms), "stream_write_ms": int(streamer.write_ms),
-                                "stream_tail_ms": int((time.perf_counter() - started - play_sec) * 1e3)})
+                                "stream_tail_ms": int((time.perf_counter() - started - play_sec) * 1e3),
+                                "stream_setup_ms": log_setup_ms, "play_call_ms": int(play_sec * 1e3),
+                                **(extra_counters or {})})
     wmeta = {"worker_idx": int(worker_idx), "device": str(device), "games": int(games),
              "games_per_chunk": int(games_per_chunk), "num_selfplay_batches": int(log.segments_cut),
              "saved_chunks": len(files)}
@@ -409,6 +468,7 @@ def run_self_play_worker(*, worker_idx: int, shard_device: str, shard_games: int
                          portable_cpp_threads: int = 1, policy_target_temperature: Optional[float] = None,
                          policy_target_prior_pseudocount: float = 0.0) -> Dict[str, Any]:
     try:
+        t_worker = time.perf_counter()
         torch.manual_seed(int(seed))
         dev = torch.device(str(shard_device))
         if dev.type != "cuda":
@@ -460,11 +520,13 @@ def run_self_play_worker(*, worker_idx: int, shard_device: str, shard_games: int
                 return self_play_tree_gpu(evaluator, opening_random_moves=int(opening_random_moves),
                                           policy_target_temperature=policy_target_temperature,
                                           policy_target_prior_pseudocount=float(policy_target_prior_pseudocount),
-                                          seed=rng_seed, collect_timing=True, row_log=row_log, **common)
+                                          seed=rng_seed, collect_timing=os.environ.get("LZ_WORKER_TIMING", "1") != "0", row_log=row_log,
+                                          **common)
             from .self_play_gpu_runner import self_play_v1_gpu
             return self_play_v1_gpu(evaluator, opening_random_moves=int(opening_random_moves), sparse_ply=int(sparse_ply),
                                     sparse_top_k=int(sparse_top_k), row_log=row_log, **common)
 
+        setup_ms = int((time.perf_counter() - t_worker) * 1e3)     # checkpoint load, module, network packing
         meta_common = {"graph_retry_off": False, "memory_anchor_mb": int(anchor_mb),
                        "opening_random_moves": int(opening_random_moves), "search_backend": str(search_backend),
                        "portable_mcts_backend": str(portable_mcts_backend),
@@ -478,7 +540,8 @@ def run_self_play_worker(*, worker_idx: int, shard_device: str, shard_games: int
                                        soft_label_alpha=float(soft_label_alpha), chunk_dir=chunk_dir, chunk_prefix=prefix,
                                        chunk_file_ext=str(chunk_file_ext), output_path=str(output_path),
                                        target_samples_per_shard=int(target_samples_per_shard),
-                                       chunk_target_bytes=int(chunk_target_bytes), meta_common=meta_common)
+                                       chunk_target_bytes=int(chunk_target_bytes), meta_common=meta_common,
+                                       extra_counters={"worker_setup_ms": setup_ms})
         return write_worker_chunks(run_once, worker_idx=int(worker_idx), device=str(dev), games=games,
                                    games_per_chunk=concurrent, soft_label_alpha=float(soft_label_alpha),
                                    chunk_dir=chunk_dir, chunk_prefix=prefix, chunk_file_ext=str(chunk_file_ext),

@@ -1,0 +1,78 @@
+"""HIP streams that really run side by side.
+
+The runtime multiplexes streams onto a few hardware queues (4 by default) and picks the queue of a new stream from the
+pool's reference counts, so two streams created back to back CAN share a queue depending on what the process created and
+destroyed before -- their kernels then run strictly one after the other.  Measured in round 5
+(`scripts/micro/stream_queues.py`, `profiles/r05_experiments.md`): with one extra stream alive the next pair was
+serialised; inside a long-lived process (bench.py's later legs, a worker after an earlier engine) the two halves of a C2
+search then took 31 ms per ply instead of 20.5.  `overlapping_streams` therefore PROBES: two spin kernels of ~0.3 ms, one
+per stream, take ~0.3 ms together if the queues differ and ~0.6 ms if not; candidates that collide are held (so that
+the pool moves on) until a set that overlaps pairwise is found, then released."""
+from __future__ import annotations
+
+import time
+from typing import List, Tuple
+
+import torch
+
+_SPIN_CYCLES = [0]
+
+
+def _spin_cycles(dev: torch.device) -> int:
+    """Cycle count of `torch.cuda._sleep` worth ~0.3 ms on this device (calibrated once)."""
+    if _SPIN_CYCLES[0] <= 0:
+        n = 200_000
+        torch.cuda._sleep(n)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        torch.cuda._sleep(n)
+        torch.cuda.synchronize(dev)
+        dt = max(1e-6, time.perf_counter() - t0)
+        _SPIN_CYCLES[0] = max(10_000, min(50_000_000, int(n * 3e-4 / dt)))
+    return _SPIN_CYCLES[0]
+
+
+def _overlap(dev: torch.device, s1: torch.cuda.Stream, s2: torch.cuda.Stream) -> bool:
+    n = _spin_cycles(dev)
+    for s in (s1, s2):                                           # first use of a stream: set-up costs, not a sample
+        with torch.cuda.stream(s):
+            torch.cuda._sleep(n)
+    ratios = []
+    for _ in range(3):
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        with torch.cuda.stream(s1):
+            torch.cuda._sleep(n)
+        torch.cuda.synchronize(dev)
+        one = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        with torch.cuda.stream(s1):
+            torch.cuda._sleep(n)
+        with torch.cuda.stream(s2):
+            torch.cuda._sleep(n)
+        torch.cuda.synchronize(dev)
+        both = time.perf_counter() - t0
+        ratios.append(both / max(one, 1e-9))
+    return sorted(ratios)[1] < 1.5                               # median: ~1.05 on two queues, ~1.95 on one
+
+
+def overlapping_streams(device, k: int = 2, max_tries: int = 12) -> Tuple[torch.cuda.Stream, ...]:
+    """`k` streams on `device` whose kernels overlap pairwise (see the module docstring).  Falls back to the last
+    candidates after `max_tries` collisions (results never depend on the overlap, only the speed does)."""
+    dev = torch.device(device)
+    chosen: List[torch.cuda.Stream] = []
+    rejected: List[torch.cuda.Stream] = []
+    with torch.cuda.device(dev):
+        _spin_cycles(dev)
+        while len(chosen) < int(k):
+            cand = torch.cuda.Stream(dev)
+            if all(_overlap(dev, c, cand) for c in chosen) or len(rejected) >= int(max_tries):
+                chosen.append(cand)
+            else:
+                rejected.append(cand)                            # keep it alive: the next candidate gets another queue
+    overlapping_streams.last_rejected = len(rejected)
+    del rejected
+    return tuple(chosen)
+
+
+overlapping_streams.last_rejected = 0

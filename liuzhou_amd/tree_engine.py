@@ -788,7 +788,8 @@ class DualStreamTreeMCTS:
             self.bounds.append((start, start + n))
             start += n
         self.device = dev
-        self.streams = tuple(torch.cuda.Stream(dev) for _ in range(k))
+        from .streams import overlapping_streams
+        self.streams = overlapping_streams(dev, k)              # probed: two new streams CAN share a hardware queue
         self.parts = []
         base = model if isinstance(model, FusedNet) else FusedNet(model, dev)
         kw.pop("game_offset", None); kw.pop("game_stride", None)
@@ -1108,7 +1109,9 @@ def self_play_tree_gpu(model, num_games: int, mcts_simulations: int, temperature
                 if int(f_slots.numel()) > 0:
                     lengths.index_copy_(0, f_slots + base, f_len)
                 outcome.add_(f_out)
+    t_sync = time.perf_counter()
     torch.cuda.synchronize(dev)
+    sync_ms = (time.perf_counter() - t_sync) * 1e3
     elapsed = max(1e-9, time.perf_counter() - started)
     if tail is not None:
         tail.check_overflow()
@@ -1152,6 +1155,9 @@ def self_play_tree_gpu(model, num_games: int, mcts_simulations: int, temperature
                        # where the wall time outside `elapsed_sec` (the plies) goes: engine construction or cache hit,
                        # build() of the five tensors; graph capture happens inside the first plies
                        "engine_cache_hit": int(cache_hit), "setup_ms": int(setup_sec * 1e3), "build_ms": int(build_sec * 1e3),
-                       "reuse_pruned": pruned, "reuse_dropped": dropped, "edge_pool_refused": refused},
+                       "reuse_pruned": pruned, "reuse_dropped": dropped, "edge_pool_refused": refused,
+                       "final_sync_ms": int(sync_ms),
+                       **({"loop_ms": int(tail.loop_ms), "host_wait_ms": int(tail.host_wait_ms),
+                           "plies_launched": int(tail.plies_launched)} if tail is not None else {})},
         piece_delta_buckets={str(d - 18): int(v) for d, v in enumerate(hist)}, device=str(dev))
     return batch, stats

@@ -7,6 +7,7 @@ synchronisation per ply; finished slots stay in the batch and are masked by `don
 from __future__ import annotations
 
 import ctypes as C
+import time
 from typing import Optional
 
 import torch
@@ -35,6 +36,8 @@ class WaveTail:
         self.slot_game = torch.arange(self.G, dtype=torch.int64, device=dev)   # game number played in each slot (run())
         self.collect_timing = False
         self._timing_events = []
+        self.host_wait_ms = self.loop_ms = 0.0              # run(): time the host spent waiting for the device / in the loop
+        self.plies_launched = 0
         # finished_log.FinishedRowLog: the live rows are slot-major (row = slot * max_plies + step, no step_index matrix)
         # and the rows of a game move to the log when the game ends (the streaming worker)
         self.row_log = row_log
@@ -147,10 +150,13 @@ class WaveTail:
         slot_game.copy_(torch.arange(g, dtype=torch.int64, device=dev))
         reseated = torch.zeros((g,), dtype=torch.uint8, device=dev)
         ply = 0
+        t_run = time.perf_counter()
         while True:
             k = ply & 1
             if ply >= 2:
+                t_w = time.perf_counter()
                 events[k].synchronize()
+                self.host_wait_ms += (time.perf_counter() - t_w) * 1e3      # ~0 for a whole run: the HOST is the bottleneck
                 if bool(flags[k].item()):
                     break
                 if log is not None:
@@ -174,6 +180,8 @@ class WaveTail:
                 flags[k].copy_((done.all() & (budget <= 0).all()).view(1), non_blocking=True)
             events[k].record(torch.cuda.current_stream(dev))
             ply += 1
+        self.loop_ms += (time.perf_counter() - t_run) * 1e3
+        self.plies_launched += ply
         return ply
 
     def check_overflow(self) -> None:
