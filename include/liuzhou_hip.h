@@ -314,6 +314,9 @@ LZ_API int lz_prof_enable(int on);
 LZ_API int lz_prof_net_summary(double* total_ms, int64_t* launches, int64_t* evals);
 /* launches on several streams may overlap: time during which at least one bracketed launch was running */
 LZ_API int lz_prof_net_busy(double* busy_ms);
+/* the HBM-bound kernels of the tree search, bracketed the same way while lz_prof_enable(1): kind 0 = the fused
+ * expand + backup + select kernel of one simulation (units = games), kind 1 = lz_tree_advance (units = games) */
+LZ_API int lz_prof_aux_summary(int kind, double* total_ms, int64_t* launches, int64_t* units);
 
 /* ---- device-resident tree search (variant P) --------------------------------------------------- */
 

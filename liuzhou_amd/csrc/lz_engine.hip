@@ -1047,6 +1047,9 @@ int lz_tree_finish(const LzTreeDesc* d, const float* temperatures, const float* 
 static long long* g_advance_ticks = nullptr;
 int lz_debug_advance_ticks(int64_t* ticks) { g_advance_ticks = reinterpret_cast<long long*>(ticks); return LZ_OK; }
 
+int lz_prof_aux_begin(int kind, void* stream);                       // lz_net.hip (bench.py roofline.secondary)
+int lz_prof_aux_end(int kind, void* stream, int64_t units);
+
 int lz_tree_advance(const LzTreeDesc* d, const int32_t* played_action, const uint8_t* reset, int64_t next_sims,
                     int32_t* dropped, int32_t* pruned, void* stream) {
     if (!tree_ok(d) || next_sims < 0) return LZ_ERR_ARG;
@@ -1059,8 +1062,10 @@ int lz_tree_advance(const LzTreeDesc* d, const int32_t* played_action, const uin
     // node budget is the only thing that can cut a kept subtree
     if ((int64_t)d->chunk_cap * (d->edge_chunk - (kMaxChildren - 1)) < (int64_t)d->node_cap * kMaxChildren) return LZ_ERR_ARG;
     const size_t lds = (size_t)kWavesPerBlock * (words * (sizeof(uint64_t) + sizeof(int)) + 3 * kWave * sizeof(int));
+    (void)lz_prof_aux_begin(1, stream);
     hipLaunchKernelGGL(tree_advance_kernel, dim3(gw(d->num_games)), dim3(kBlock), lds, as_stream(stream), make_tree(d),
                        played_action, reset, (int)rn, words, dropped, pruned, g_advance_ticks);
+    (void)lz_prof_aux_end(1, stream, d->num_games);
     return st();
 }
 
@@ -1091,8 +1096,10 @@ static int tree_search_impl(const LzTreeDesc* d, const LzNetDesc* net, int64_t s
             hipLaunchKernelGGL(tree_expand_select_kernel<true>, dim3(gw(t.B)), dim3(kBlock), 0, as_stream(stream), t, lp1,
                                lp2, lpmc, values, noise, (int)noise_stride, epsilon, (int)s);
         } else {
+            (void)lz_prof_aux_begin(0, stream);                      // no-ops unless lz_prof_enable(1) (never in a capture)
             hipLaunchKernelGGL(tree_expand_select_kernel<false>, dim3(gw(t.B)), dim3(kBlock), 0, as_stream(stream), t, lp1,
                                lp2, lpmc, values, nullptr, 0, 0.f, (int)s);
+            (void)lz_prof_aux_end(0, stream, B);
         }
     }
     return st();

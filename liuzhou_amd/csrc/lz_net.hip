@@ -87,6 +87,8 @@ struct NetProf {
 } g_prof;
 }  // namespace
 
+extern "C" void lz_prof_aux_reset(void);
+
 extern "C" {
 
 int lz_prof_enable(int on) {
@@ -98,6 +100,7 @@ int lz_prof_enable(int on) {
     g_prof.on = on != 0;
     g_prof.used = 0;
     g_prof.evals = 0;
+    lz_prof_aux_reset();
     return LZ_OK;
 }
 
@@ -152,6 +155,54 @@ int lz_prof_mark_end(void* stream, int64_t evals) {
     if (!(g_prof.on && g_prof.used < NetProf::kMax)) return LZ_OK;
     (void)hipEventRecord(g_prof.ev[2 * g_prof.used + 1], reinterpret_cast<hipStream_t>(stream));
     g_prof.used += 1; g_prof.evals += evals;
+    return LZ_OK;
+}
+
+/* Secondary brackets for the HBM-bound kernels of the search (bench.py `roofline.secondary`): kind 0 = the fused
+ * expand + backup + select kernel of a simulation, kind 1 = the subtree compaction of a move.  Same mechanism as the
+ * network brackets (events on the launch stream, only while lz_prof_enable(1)); begin / end are internal. */
+namespace {
+struct AuxProf {
+    static constexpr int kKinds = 2, kMax = 4096;
+    hipEvent_t ev[kKinds][2 * kMax];
+    int used[kKinds] = {0, 0};
+    int64_t units[kKinds] = {0, 0};
+    bool created = false;
+} g_aux;
+}  // namespace
+
+void lz_prof_aux_reset(void) {
+    for (int k = 0; k < AuxProf::kKinds; ++k) { g_aux.used[k] = 0; g_aux.units[k] = 0; }
+}
+int lz_prof_aux_begin(int kind, void* stream) {
+    if (!g_prof.on || kind < 0 || kind >= AuxProf::kKinds) return LZ_OK;
+    if (!g_aux.created) {
+        for (int k = 0; k < AuxProf::kKinds; ++k)
+            for (int i = 0; i < 2 * AuxProf::kMax; ++i)
+                if (hipEventCreate(&g_aux.ev[k][i]) != hipSuccess) return LZ_ERR_LAUNCH;
+        g_aux.created = true;
+    }
+    if (g_aux.used[kind] >= AuxProf::kMax) return LZ_OK;
+    return hipEventRecord(g_aux.ev[kind][2 * g_aux.used[kind]], reinterpret_cast<hipStream_t>(stream)) == hipSuccess ? LZ_OK : LZ_ERR_LAUNCH;
+}
+int lz_prof_aux_end(int kind, void* stream, int64_t units) {
+    if (!g_prof.on || !g_aux.created || kind < 0 || kind >= AuxProf::kKinds || g_aux.used[kind] >= AuxProf::kMax) return LZ_OK;
+    (void)hipEventRecord(g_aux.ev[kind][2 * g_aux.used[kind] + 1], reinterpret_cast<hipStream_t>(stream));
+    g_aux.used[kind] += 1; g_aux.units[kind] += units;
+    return LZ_OK;
+}
+/* exported: call after synchronising; lz_prof_enable() resets the counts */
+int lz_prof_aux_summary(int kind, double* total_ms, int64_t* launches, int64_t* units) {
+    if (kind < 0 || kind >= AuxProf::kKinds) return LZ_ERR_ARG;
+    double t = 0.0;
+    for (int i = 0; i < g_aux.used[kind]; ++i) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, g_aux.ev[kind][2 * i], g_aux.ev[kind][2 * i + 1]) != hipSuccess) return LZ_ERR_LAUNCH;
+        t += ms;
+    }
+    if (total_ms) *total_ms = t;
+    if (launches) *launches = g_aux.used[kind];
+    if (units) *units = g_aux.units[kind];
     return LZ_OK;
 }
 

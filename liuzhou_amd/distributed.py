@@ -34,6 +34,15 @@ def worker_seed(iteration_seed: int, worker_idx: int) -> int:
     return int(iteration_seed) * 10007 + (int(worker_idx) + 1) * 9973
 
 
+def _free_device_bytes(dev: torch.device) -> int:
+    """Device memory an allocation could still get: free on the device + cached blocks torch can reuse; -1 = not a HIP
+    device (the gloo rehearsal with host tensors: no check)."""
+    if dev.type != "cuda":
+        return -1
+    free, _total = torch.cuda.mem_get_info(dev)
+    return int(free + torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev))
+
+
 def _gather_compact(batch: TensorSelfPlayBatch, dst: int, group) -> Optional[TensorSelfPlayBatch]:
     """HIP path: rows travel as exact 360-byte records (trajectory_codec.py), 7.5x less xGMI traffic than the five
     tensors, packed / unpacked by one kernel each side.  The row count and the number of rows the record format cannot
@@ -43,7 +52,11 @@ def _gather_compact(batch: TensorSelfPlayBatch, dst: int, group) -> Optional[Ten
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     dev = batch.state_tensors.device
     rec, bad = pack_batch(batch, return_bad=True)
-    mine = torch.stack([torch.tensor(batch.num_samples, dtype=torch.int64, device=dev), bad.to(torch.int64).view(())])
+    # the destination's free memory travels with the counts, so that EVERY rank can see that the expanded rows would
+    # not fit and raise before anything is sent (a check on `dst` alone would leave the senders waiting in the next
+    # collective until it times out -- ADVICE r04)
+    mine = torch.stack([torch.tensor(batch.num_samples, dtype=torch.int64, device=dev), bad.to(torch.int64).view(()),
+                        torch.tensor(_free_device_bytes(dev) if rank == dst else -1, dtype=torch.int64, device=dev)])
     if dist.get_backend(group) != "nccl":
         mine = mine.cpu()
     every = [torch.zeros_like(mine) for _ in range(world)]
@@ -55,6 +68,14 @@ def _gather_compact(batch: TensorSelfPlayBatch, dst: int, group) -> Optional[Ten
         raise RuntimeError(f"gather_trajectories: rows not representable as compact records on ranks "
                            f"{[r for r, b in enumerate(n_bad) if b]} (counts {n_bad}): planes not 0/1, policy mass off "
                            "the legal set, or more than 72 legal actions; every rank raises, nothing was sent")
+    # the destination expands every rank's records to the 2 692-byte five-tensor rows next to whatever else lives on
+    # its device (at C4 rank 0 still holds its own tree arenas): refuse -- on every rank -- before anything moves
+    need, free_dst = sum(counts) * (EXPANDED_ROW_BYTES + RECORD_BYTES), int(every[dst, 2])
+    if free_dst >= 0 and need > free_dst:
+        raise RuntimeError(f"gather_trajectories: rank {dst} needs {need / 2**30:.1f} GiB to receive and expand "
+                           f"{sum(counts)} rows but only {free_dst / 2**30:.1f} GiB of its device memory are free; release "
+                           "the search engines (arenas) first or gather in several pieces; every rank raises, nothing was "
+                           "sent")
     # RCCL moves device memory directly (peer writes over xGMI); any other backend (gloo in the tests) stages the
     # records through host memory -- same protocol, same kernels on both sides
     direct = dist.get_backend(group) == "nccl"
@@ -77,23 +98,16 @@ def _gather_compact(batch: TensorSelfPlayBatch, dst: int, group) -> Optional[Ten
         for req in dist.batch_isend_irecv(ops):
             req.wait()
     buf = buf.to(dev)
-    # the destination expands every rank's records to the 2 692-byte five-tensor rows next to whatever else lives on
-    # its device (at C4 rank 0 still holds its own tree arenas): refuse before allocating rather than fail half-way
-    need = int(buf.shape[0]) * EXPANDED_ROW_BYTES
-    free, _total = torch.cuda.mem_get_info(dev)
-    free += torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)     # cached blocks torch can reuse
-    if need > free:
-        raise RuntimeError(f"gather_trajectories: rank {dst} needs {need / 2**30:.1f} GiB to expand {int(buf.shape[0])} "
-                           f"rows but only {free / 2**30:.1f} GiB of device memory are free; release the search engines "
-                           "(arenas) first or gather in several pieces")
     return unpack_records(buf)
 
 
 def gather_trajectories(batch: TensorSelfPlayBatch, dst: int = 0, group=None,
-                        compact: Optional[bool] = None) -> Optional[TensorSelfPlayBatch]:
+                        compact: Optional[bool] = None, force: bool = False) -> Optional[TensorSelfPlayBatch]:
     """Concatenate every rank's samples on `dst` (rank order).  Returns None on the other ranks.
-    `compact` (default: on for HIP tensors) sends 360-byte records instead of the five tensors."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    `compact` (default: on for HIP tensors) sends 360-byte records instead of the five tensors.
+    `force`: run the protocol (counts all-gather, pack / unpack) even in a group of one -- what a 1-GPU box can execute
+    of the RCCL path (tests/test_gpu_distributed.py)."""
+    if not dist.is_initialized() or (dist.get_world_size(group) == 1 and not force):
         return batch
     if compact is None:
         compact = batch.state_tensors.is_cuda
@@ -141,11 +155,11 @@ def gather_trajectories(batch: TensorSelfPlayBatch, dst: int = 0, group=None,
     return None
 
 
-def broadcast_checkpoint(model: torch.nn.Module, src: int = 0, group=None) -> None:
+def broadcast_checkpoint(model: torch.nn.Module, src: int = 0, group=None, force: bool = False) -> None:
     """Rank `src`'s parameters and buffers -> every rank (checkpoint hand-off each iteration, v1/train.py:978 hands a
     `model_state_cpu.pt` file to the workers).  One flat buffer per dtype (fp32 weights + the int64 BatchNorm counters:
     12 MB for 10x128 in two collectives) instead of one tiny broadcast per tensor."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_initialized() or (dist.get_world_size(group) == 1 and not force):
         return
     by_dtype: Dict[torch.dtype, List[torch.Tensor]] = {}
     for t in list(model.parameters()) + list(model.buffers()):

@@ -139,6 +139,15 @@ def test_bench_two_ranks_with_gather_in_the_timed_region():
     g = out["gather"]
     assert g["rows_on_rank0"] == 2 * 256 * 4 and g["record_bytes"] == 360 and g["bytes_received"] == 256 * 4 * 360
     assert "gathered to rank 0" in out["config"]["workload"] and out["config"]["workload"].startswith("C4")
+    # per-rank rows (all-gathered): a SCALE run can attribute a loss to a straggler, the gather or a power-capped package
+    pr = out["per_rank"]
+    assert [d["rank"] for d in pr] == [0, 1] and out["backend"] == "gloo" and out["rccl_ranks"] == 2
+    for d in pr:
+        assert 0 < d["play_ms_per_step"] <= d["ms_per_step"] * 1.001 and d["leaf_evals"] > 0 and d["gather_ms"] > 0
+        assert d["pci"].count(":") == 2
+    assert out["distinct_devices"] == 1                             # both ranks share cuda:0 here; under RCCL bench.py raises
+    assert abs(max(d["ms_per_step"] for d in pr) - out["ms_per_step"]) < 0.01 * out["ms_per_step"] + 0.01
+    assert out["per_rank_summary"]["straggler_ratio"] >= 1.0
 
 
 def _staged_loop(world, overlap, iterations=3, games=48, plies=6, extra=()):
@@ -191,3 +200,27 @@ def test_staged_loop_multi_rank_trainer_does_not_play(world, overlap):
         assert out["tail"] is None
     assert all(e["avg_loss"] is not None for e in log if e["train_samples"])
     assert out["steady_state_positions_per_sec"] > 0
+
+
+def test_rccl_group_of_one_runs_the_device_tensor_collectives():
+    """Every multi-rank test above is gloo (two ranks cannot share a device under RCCL).  This one initialises a
+    world-size-1 `nccl` group -- RCCL library load, communicator creation -- and runs the device-tensor branch of
+    `gather_trajectories` (counts all-gather) and `broadcast_checkpoint` plus bench.py's all-reduce through it
+    (tests/nccl_world1.py, in a child process with a time limit: a hung collective must not hang the suite)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    try:
+        res = subprocess.run([sys.executable, os.path.join(root, "tests", "nccl_world1.py"), str(_free_port())],
+                             capture_output=True, text=True, timeout=240, env=env)
+    except subprocess.TimeoutExpired as exc:
+        pytest.fail(f"the world-size-1 RCCL job did not finish in 240 s: {exc.stdout} {exc.stderr}")
+    assert res.returncode == 0, res.stdout + res.stderr
+    out = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["backend"] == "nccl" and out["world"] == 1
+    assert out["gather_bit_exact"] is True and out["rows"] > 0
+    assert out["broadcast_keeps_weights"] is True and out["all_reduce_max"] == 3.25 and out["barrier"] is True
