@@ -89,6 +89,19 @@ class NetPack:
 
 
 def pack_model(model, fp32_fragments: bool = False) -> NetPack:
+    """Single-threaded wrapper of `_pack_model`: the packing is a few hundred small fp64 host operators, and torch's
+    intra-op pool (one thread per core: 128 on the GPU box) costs more to wake per operator than the operator takes --
+    measured 0.7 - 2.5 s with the pool, 0.09 s on one thread (`scripts/micro/worker_setup.py`); it was most of the
+    worker's set-up time."""
+    prev = torch.get_num_threads()
+    torch.set_num_threads(1)
+    try:
+        return _pack_model(model, fp32_fragments)
+    finally:
+        torch.set_num_threads(prev)
+
+
+def _pack_model(model, fp32_fragments: bool = False) -> NetPack:
     """`fp32_fragments`: also lay the (BN-folded) conv weights out as fp32 MFMA fragments for the parity-mode kernel.
     BN folding + MFMA fragment order, on a detached host copy: the caller's module keeps its device, its train /
     eval mode and its parameter storages (optimizer state, DDP buckets and captured graphs keep pointing at them)."""

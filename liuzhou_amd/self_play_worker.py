@@ -487,13 +487,14 @@ def run_self_play_worker(*, worker_idx: int, shard_device: str, shard_games: int
         concurrent = max(1, min(games, int(concurrent_games_per_device)))
         model = _infer_model(state)
         model.load_state_dict(state, strict=True)
-        model.to(dev).eval()
+        model.eval()
         backend = str(search_backend).strip().lower()
         evaluator: Any = model
         if int(model.stem_conv.weight.shape[0]) in (64, 128):
             from .net_hip import FusedNet
-            evaluator = FusedNet(model, dev)
-        # other widths: the module itself is the (external fp32) evaluator of the tree engine / the root search
+            evaluator = FusedNet(model, dev)                  # packed from the host copy: the module never visits the device
+        else:
+            model.to(dev)   # other widths: the module itself is the (external fp32) evaluator of the tree engine / root search
         chunk_dir, prefix = str(chunk_output_dir or "").strip(), str(chunk_file_prefix or "").strip()
         if not chunk_dir or not prefix:
             raise ValueError("run_self_play_worker requires chunk_output_dir and chunk_file_prefix to emit worker "
