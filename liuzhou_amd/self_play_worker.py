@@ -347,66 +347,110 @@ def _host_view(t: torch.Tensor, start: int, end: int) -> torch.Tensor:
     return torch.from_numpy(t.numpy()[int(start):int(end)])
 
 
+class StreamedShardFiles:
+    """Host-only half of the streamed shard: which rows go to which payload file (`plan_segment`, called in segment order),
+    the `torch.save` of a segment's files from host staging tensors (`write_segment`, any thread) and the worker manifest
+    (`finish`).  Same file names, payload keys and manifest keys as the reference's chunk loop
+    (v1/python/self_play_worker.py:430-546); a file holds the games that ended within one segment of the finished-row
+    log, cut further by `chunk_target_bytes` / `target_samples_per_shard` exactly as the reference cuts a chunk
+    (`plan_sample_ranges`).  No device in here: tests/test_self_play_stage.py drives it on the CPU and reads the result
+    back through the reference's own loader."""
+
+    def __init__(self, *, device, worker_idx: int, games: int, games_per_chunk: int, soft_label_alpha: float,
+                 chunk_dir: str, chunk_prefix: str, chunk_file_ext: str, output_path: str, target_samples_per_shard: int,
+                 chunk_target_bytes: int, meta_common: Dict[str, Any], action_dim: int = 220) -> None:
+        self.device, self.worker_idx, self.games, self.games_per_chunk = str(device), int(worker_idx), int(games), int(games_per_chunk)
+        self.alpha = float(max(0.0, min(1.0, soft_label_alpha)))
+        self.chunk_dir, self.prefix, self.ext, self.output_path = str(chunk_dir), str(chunk_prefix), str(chunk_file_ext), str(output_path)
+        self.target_samples, self.target_bytes = int(target_samples_per_shard), int(chunk_target_bytes)
+        self.meta_common, self.action_dim = meta_common, int(action_dim)
+        self.val_s: List[Dict[str, Any]] = []
+        self.soft_s: List[Dict[str, Any]] = []
+        self.mix_s: List[Dict[str, Any]] = []
+        self.files: List[str] = []
+        self.sizes: List[int] = []
+        self.bps = [0, 0]
+        self.lock = threading.Lock()
+        os.makedirs(self.chunk_dir or ".", exist_ok=True)
+
+    def plan_segment(self, rows: int, number: int):
+        """File names and row ranges of one segment (one thread, segment order)."""
+        plan = []
+        for lo, hi in plan_sample_ranges(total_samples=rows, num_shards=1, target_samples_per_shard=self.target_samples,
+                                         chunk_target_bytes=self.target_bytes, bytes_per_sample=_ROW_BYTES(self.action_dim)):
+            name = f"{self.prefix}.chunk{len(self.files):05d}{self.ext}"
+            meta = {"payload_format": "v1_sharded_shard", "worker_idx": self.worker_idx, "device": self.device,
+                    "games": self.games, "games_per_chunk": self.games_per_chunk,
+                    "num_selfplay_batches": int(number) + 1, "saved_chunk_index": len(self.files)}
+            meta.update(self.meta_common)
+            meta["source_worker_manifest"] = os.path.basename(self.output_path)
+            plan.append((name, lo, hi, meta))
+            self.files.append(name)
+            self.sizes.append(int(hi - lo))
+        return plan
+
+    def write_segment(self, staging, rows: int, plan) -> None:
+        import numpy as np
+        state, legal, policy, value, soft = (t[:rows] for t in staging)
+        v_np, s_np = value.numpy(), soft.numpy()                  # numpy, not torch: no intra-op thread pool (see above)
+        a = self.alpha
+        summaries = (summarize_scalar_targets_np(v_np), summarize_scalar_targets_np(s_np),
+                     summarize_scalar_targets_np(np.clip(np.float32(1.0 - a) * v_np + np.float32(a) * s_np,
+                                                         np.float32(-1.0), np.float32(1.0))))
+        b = estimate_bytes_per_sample(TensorSelfPlayBatch(state, legal, policy, value, soft))
+        with self.lock:
+            self.val_s.append(summaries[0]); self.soft_s.append(summaries[1]); self.mix_s.append(summaries[2])
+            self.bps[0] += b * max(1, rows)
+            self.bps[1] += max(1, rows)
+        for name, lo, hi, meta in plan:
+            save_self_play_payload(path=os.path.join(self.chunk_dir, name),
+                                   samples=TensorSelfPlayBatch(*(_host_view(t, lo, hi) for t in staging)),
+                                   stats_payload={}, metadata=meta)
+
+    def finish(self, stats: SelfPlayV1Stats, num_batches: int) -> Dict[str, Any]:
+        """Write the worker manifest (`v1_worker_chunk_manifest`) and return the worker's result row."""
+        wmeta = {"worker_idx": self.worker_idx, "device": self.device, "games": self.games,
+                 "games_per_chunk": self.games_per_chunk, "num_selfplay_batches": int(num_batches),
+                 "saved_chunks": len(self.files)}
+        wmeta.update(self.meta_common)
+        manifest = {
+            "payload_format": "v1_worker_chunk_manifest", "version": 1, "num_samples": int(sum(self.sizes)),
+            "num_shards": len(self.files), "shard_files": list(self.files), "shard_sizes": list(self.sizes),
+            "chunk_target_bytes": self.target_bytes, "avg_bytes_per_sample": int(self.bps[0] // max(1, self.bps[1])),
+            "stats": stats.to_dict(), "value_target_summary": merge_target_summaries(self.val_s),
+            "soft_value_target_summary": merge_target_summaries(self.soft_s),
+            "mixed_value_target_summary": merge_target_summaries(self.mix_s), "metadata": wmeta,
+        }
+        os.makedirs(os.path.dirname(self.output_path) or ".", exist_ok=True)
+        torch.save(manifest, self.output_path)
+        return {"worker_idx": self.worker_idx, "device": self.device, "games": self.games, "output_path": self.output_path,
+                "num_samples": int(sum(self.sizes)), "saved_chunks": len(self.files)}
+
+
 def stream_worker_shard(play, *, device: torch.device, worker_idx: int, games: int, games_per_chunk: int,
                         max_game_plies: int, soft_label_alpha: float, chunk_dir: str, chunk_prefix: str,
                         chunk_file_ext: str, output_path: str, target_samples_per_shard: int, chunk_target_bytes: int,
                         meta_common: Dict[str, Any], segment_games: Optional[int] = None,
                         action_dim: int = 220, extra_counters: Optional[Dict[str, int]] = None) -> Dict[str, Any]:
     """The pipelined worker: `play(row_log) -> SelfPlayV1Stats` runs the whole shard on `games_per_chunk` slots with the
-    finished-row log attached.  A payload file holds the games that ended in one segment of the log (`segment_games`,
-    default an eighth of `games_per_chunk`, so that what is left to write when the last game ends is small), cut further
-    by `chunk_target_bytes` / `target_samples_per_shard` exactly as the reference cuts a chunk (`plan_sample_ranges`)."""
+    finished-row log attached; `segment_games` (default an eighth of `games_per_chunk`, so that what is left to write when
+    the last game ends is small; env LZ_WORKER_SEGMENT_GAMES) finished games make a segment = one payload file unless
+    `chunk_target_bytes` / `target_samples_per_shard` cut it further (`StreamedShardFiles`)."""
     from .finished_log import FinishedRowLog
-    alpha = float(max(0.0, min(1.0, soft_label_alpha)))
     if segment_games is None:
         env = str(os.environ.get("LZ_WORKER_SEGMENT_GAMES", "")).strip()
         segment_games = int(env) if env else max(1, int(games_per_chunk) // 8)
-    val_s, soft_s, mix_s = [], [], []
-    files: List[str] = []
-    sizes: List[int] = []
-    bps = [0, 0]
-    summary_lock = threading.Lock()
-
-    def plan_segment(rows: int, number: int):
-        """File names and row ranges of one segment (copier thread, segment order)."""
-        plan = []
-        for lo, hi in plan_sample_ranges(total_samples=rows, num_shards=1,
-                                         target_samples_per_shard=int(target_samples_per_shard),
-                                         chunk_target_bytes=int(chunk_target_bytes), bytes_per_sample=_ROW_BYTES(action_dim)):
-            name = f"{chunk_prefix}.chunk{len(files):05d}{chunk_file_ext}"
-            meta = {"payload_format": "v1_sharded_shard", "worker_idx": int(worker_idx), "device": str(device),
-                    "games": int(games), "games_per_chunk": int(games_per_chunk),
-                    "num_selfplay_batches": int(number) + 1, "saved_chunk_index": len(files)}
-            meta.update(meta_common)
-            meta["source_worker_manifest"] = os.path.basename(str(output_path))
-            plan.append((name, lo, hi, meta))
-            files.append(name)
-            sizes.append(int(hi - lo))
-        return plan
-
-    def write_segment(staging, rows: int, plan) -> None:
-        import numpy as np
-        state, legal, policy, value, soft = (t[:rows] for t in staging)
-        v_np, s_np = value.numpy(), soft.numpy()                  # numpy, not torch: no intra-op thread pool (see above)
-        summaries = (summarize_scalar_targets_np(v_np), summarize_scalar_targets_np(s_np),
-                     summarize_scalar_targets_np(np.clip(np.float32(1.0 - alpha) * v_np + np.float32(alpha) * s_np,
-                                                         np.float32(-1.0), np.float32(1.0))))
-        b = estimate_bytes_per_sample(TensorSelfPlayBatch(state, legal, policy, value, soft))
-        with summary_lock:
-            val_s.append(summaries[0]); soft_s.append(summaries[1]); mix_s.append(summaries[2])
-            bps[0] += b * max(1, rows)
-            bps[1] += max(1, rows)
-        for name, lo, hi, meta in plan:
-            save_self_play_payload(path=os.path.join(chunk_dir, name),
-                                   samples=TensorSelfPlayBatch(*(_host_view(t, lo, hi) for t in staging)),
-                                   stats_payload={}, metadata=meta)
-
+    shard = StreamedShardFiles(device=device, worker_idx=worker_idx, games=games, games_per_chunk=games_per_chunk,
+                               soft_label_alpha=soft_label_alpha, chunk_dir=chunk_dir, chunk_prefix=chunk_prefix,
+                               chunk_file_ext=chunk_file_ext, output_path=output_path,
+                               target_samples_per_shard=target_samples_per_shard, chunk_target_bytes=chunk_target_bytes,
+                               meta_common=meta_common, action_dim=action_dim)
     t_stream = time.perf_counter()
     wave = max(1, min(int(games), int(games_per_chunk)))
     env_rows = str(os.environ.get("LZ_WORKER_LOG_ROWS", "")).strip()      # rows per log arena (tests: force back-pressure)
     log = FinishedRowLog(device, segment_games=int(segment_games), num_slots=wave, max_steps=int(max_game_plies),
                          action_dim=int(action_dim), capacity_rows=int(env_rows) if env_rows else None)
-    streamer = ShardStreamer(device, log.capacity, int(action_dim), plan_segment, write_segment,
+    streamer = ShardStreamer(device, log.capacity, int(action_dim), shard.plan_segment, shard.write_segment,
                              writers=int(os.environ.get("LZ_WORKER_WRITERS", "3") or 3))
     log.on_segment = streamer.on_segment
     log.on_blocked = streamer.raise_if_failed
@@ -429,22 +473,7 @@ def stream_worker_shard(play, *, device: torch.device, worker_idx: int, games: i
                                 "stream_tail_ms": int((time.perf_counter() - started - play_sec) * 1e3),
                                 "stream_setup_ms": log_setup_ms, "play_call_ms": int(play_sec * 1e3),
                                 **(extra_counters or {})})
-    wmeta = {"worker_idx": int(worker_idx), "device": str(device), "games": int(games),
-             "games_per_chunk": int(games_per_chunk), "num_selfplay_batches": int(log.segments_cut),
-             "saved_chunks": len(files)}
-    wmeta.update(meta_common)
-    manifest = {
-        "payload_format": "v1_worker_chunk_manifest", "version": 1, "num_samples": int(sum(sizes)),
-        "num_shards": len(files), "shard_files": list(files), "shard_sizes": list(sizes),
-        "chunk_target_bytes": int(chunk_target_bytes), "avg_bytes_per_sample": int(bps[0] // max(1, bps[1])),
-        "stats": stats.to_dict(), "value_target_summary": merge_target_summaries(val_s),
-        "soft_value_target_summary": merge_target_summaries(soft_s),
-        "mixed_value_target_summary": merge_target_summaries(mix_s), "metadata": wmeta,
-    }
-    os.makedirs(os.path.dirname(str(output_path)) or ".", exist_ok=True)
-    torch.save(manifest, str(output_path))
-    return {"worker_idx": int(worker_idx), "device": str(device), "games": int(games), "output_path": str(output_path),
-            "num_samples": int(sum(sizes)), "saved_chunks": len(files)}
+    return shard.finish(stats, int(log.segments_cut))
 
 
 def _drop_engines() -> None:

@@ -8,16 +8,16 @@ import torch
 
 from liuzhou_amd import self_play_stage as S
 from liuzhou_amd.distributed import split_games, worker_seed
-from tests.stage_stub import random_batch, stub_worker
+from tests.stage_stub import random_batch, stub_stream_worker, stub_worker
 
 REF = "/root/reference"
 
 
-def _run(tmp_path, in_process, games=23, devices=("cuda:0", "cuda:1", "cuda:2")):
-    out = str(tmp_path / "selfplay_iter_001.pt")
+def _run(tmp_path, in_process, games=23, devices=("cuda:0", "cuda:1", "cuda:2"), worker_fn=stub_worker, name="selfplay_iter_001.pt"):
+    out = str(tmp_path / name)
     stats, manifest = S.run_self_play_stage(
         model_state={"w": torch.zeros(3)}, num_games=games, devices=list(devices), output_path=out, iteration_seed=1,
-        mcts_simulations=8, concurrent_games_per_device=5, target_samples_per_shard=20, worker_fn=stub_worker,
+        mcts_simulations=8, concurrent_games_per_device=5, target_samples_per_shard=20, worker_fn=worker_fn,
         in_process=in_process, metadata_base={"iteration": 1})
     return out, stats, manifest
 
@@ -50,6 +50,74 @@ def test_stage_writes_chunks_and_manifest(tmp_path, in_process):
     # DDP dealing: shards round-robin over ranks, every sample exactly once
     parts = [S.load_self_play_payload(out, ddp_rank=r, ddp_world_size=2)[0].num_samples for r in range(2)]
     assert sum(parts) == 23 * 7
+
+
+def _sorted_rows(batch):
+    import numpy as np
+    n = batch.num_samples
+    flat = np.concatenate([getattr(batch, k).reshape(n, -1).to(torch.float32).numpy() for k in S.TENSOR_KEYS], axis=1)
+    return flat[np.lexsort(flat.T[::-1])]
+
+
+def test_streamed_shard_files_equal_the_chunk_loop_and_read_back_through_the_reference(tmp_path):
+    """The pipelined worker's file side (`StreamedShardFiles`: segments of uneven size, written out of order by two threads
+    from staging tensors larger than a segment) against the reference-style chunk loop on the same rows: same manifest
+    keys / metadata keys / payload keys / dtypes, every file owns exactly its rows, the same multiset of samples, the same
+    target summaries -- and the reference's own loader and streaming index read it (container only)."""
+    import numpy as np
+    a_out, a_stats, a_man = _run(tmp_path / "classic", True, worker_fn=stub_worker)
+    b_out, b_stats, b_man = _run(tmp_path / "streamed", True, worker_fn=stub_stream_worker)
+    assert set(a_man) == set(b_man) and set(a_man["metadata"]) == set(b_man["metadata"])
+    assert a_man["num_samples"] == b_man["num_samples"] == 23 * 7 == sum(b_man["shard_sizes"])
+    assert b_stats.num_games == a_stats.num_games == 23 and b_stats.num_positions == a_stats.num_positions
+    for k in ("value_target_summary", "soft_value_target_summary", "mixed_value_target_summary"):
+        for kk, v in a_man["metadata"][k].items():
+            w = b_man["metadata"][k][kk]
+            assert (abs(v - w) < 1e-4) if isinstance(v, float) else v == w, (k, kk, v, w)
+    # the worker manifests themselves (the stage deletes its workspace, so one worker of each kind is run directly)
+    wms = []
+    for fn, d in ((stub_worker, "wm_classic"), (stub_stream_worker, "wm_streamed")):
+        os.makedirs(tmp_path / d)
+        row = fn(worker_idx=2, shard_device="cuda:2", shard_games=11, seed=5, concurrent_games_per_device=4,
+                 soft_label_alpha=0.3, chunk_output_dir=str(tmp_path / d), chunk_file_prefix="it.w02", chunk_file_ext=".pt",
+                 output_path=str(tmp_path / d / "worker.pt"), target_samples_per_shard=0, chunk_target_bytes=0,
+                 search_backend="cuda_root", opening_random_moves=0)
+        assert set(row) == {"worker_idx", "device", "games", "output_path", "num_samples", "saved_chunks"} and row["num_samples"] == 77
+        wms.append(torch.load(tmp_path / d / "worker.pt", weights_only=False))
+    wm_a, wm_b = wms
+    assert set(wm_a) == set(wm_b) and set(wm_a["metadata"]) == set(wm_b["metadata"]) and set(wm_a["stats"]) == set(wm_b["stats"])
+    assert wm_b["payload_format"] == "v1_worker_chunk_manifest" and wm_b["avg_bytes_per_sample"] == wm_a["avg_bytes_per_sample"] == 2692
+    assert wm_b["shard_files"][0] == "it.w02.chunk00000.pt" and wm_b["num_shards"] == len(wm_b["shard_files"]) == wm_b["metadata"]["saved_chunks"]
+    for k in ("value_target_summary", "soft_value_target_summary", "mixed_value_target_summary"):
+        assert set(wm_a[k]) == set(wm_b[k]) and wm_a[k]["total"] == wm_b[k]["total"] == 77
+        assert abs(wm_a[k]["abs_mean"] - wm_b[k]["abs_mean"]) < 1e-5                # alpha = 0.3: the mixed targets differ from both
+    for f, size in zip(b_man["shard_files"], b_man["shard_sizes"]):
+        shard = torch.load(tmp_path / "streamed" / f, weights_only=False)
+        ref = torch.load(tmp_path / "classic" / a_man["shard_files"][0], weights_only=False)
+        assert set(shard) == set(ref) and set(shard["metadata"]) == set(ref["metadata"])
+        for k in S.TENSOR_KEYS:
+            assert shard[k].dtype == ref[k].dtype and shard[k].shape[1:] == ref[k].shape[1:] and shard[k].shape[0] == size
+            assert shard[k].untyped_storage().nbytes() == shard[k].numel() * shard[k].element_size()
+    a_batch, _, _ = S.load_self_play_payload(a_out)
+    b_batch, _, _ = S.load_self_play_payload(b_out)
+    assert np.array_equal(_sorted_rows(a_batch), _sorted_rows(b_batch))
+    if os.path.isdir(os.path.join(REF, "v1")):
+        sys.path.insert(0, REF)
+        sys.dont_write_bytecode = True
+        try:
+            import v1.train as T
+            from v1.python.streaming_dataset import resolve_shard_specs as ref_specs
+        except Exception as exc:   # pragma: no cover
+            pytest.skip(f"reference not importable here: {exc!r}")
+        finally:
+            sys.path.remove(REF)
+        theirs, st, meta = T._load_self_play_payload(b_out)
+        for k in S.TENSOR_KEYS:
+            assert torch.equal(getattr(theirs, k), getattr(b_batch, k)), k
+        assert int(st["num_positions"]) == 23 * 7 and meta["manifest_num_shards"] == b_man["num_shards"]
+        rs, rtotal = ref_specs(b_out, [], 0)
+        ms, mtotal = S.resolve_shard_specs(b_out, [], 0)
+        assert rtotal == mtotal == 23 * 7 and [(s.path, s.num_samples) for s in rs] == [(s.path, s.num_samples) for s in ms]
 
 
 def test_shard_specs_and_replay_budget(tmp_path):
