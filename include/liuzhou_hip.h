@@ -383,6 +383,17 @@ typedef struct LzTreeDesc {
     int32_t* pool_top;             /* [1] */
     int32_t* pool_stats;           /* [2] */
     int64_t  pool_chunks;
+    /* optional compact evaluation list of lz_tree_search / lz_tree_search_continue (all three set, live_count_cap >= sims + 2):
+     * every simulation's leaves that NEED the network (live game, leaf to expand -- not a terminal leaf, not a kept
+     * root) are appended to live_state (<= num_games records) and evaluated with lz_net_forward_packed_counted_f16, so a
+     * launch runs ceil(live / samples-per-pass) network passes instead of one per slot: the cost of a wave that is
+     * draining follows its live games (the reference's PortableMCTS.evaluate_states gets exactly the pending leaves,
+     * v1/python/portable_mcts.py:337-378).  live_row[g] = row of game g's leaf in the list; live_count[s] = number
+     * of leaves of simulation s.  Results are bit-identical to the dense launch. */
+    void*    live_state;           /* [num_games] 32-byte packed states */
+    int32_t* live_row;             /* [num_games] */
+    int64_t* live_count;           /* [live_count_cap] */
+    int64_t  live_count_cap;
 } LzTreeDesc;
 
 /* SoA batch -> packed records; packed records -> float32[B,11,6,6] model input (src/neural_network.py:15-65) */

@@ -80,7 +80,9 @@ __global__ __launch_bounds__(kBlock) void tree_select_kernel(Tree t) {
 }
 
 
-template <bool IS_ROOT>
+// COMPACT: the evaluator rows are those of the compact list (Tree::live_row); tree_expand indexes its inputs with g, so
+// the base pointers are shifted by row - g (rows of leaves that needed no evaluation are never read for their content)
+template <bool IS_ROOT, bool COMPACT = false>
 __global__ __launch_bounds__(kBlock) void tree_expand_kernel(Tree t, const float* __restrict__ lp1,
                                                              const float* __restrict__ lp2,
                                                              const float* __restrict__ lpm,
@@ -91,13 +93,32 @@ __global__ __launch_bounds__(kBlock) void tree_expand_kernel(Tree t, const float
     LZ_EXPAND_SCRATCH(sc);
     const int g = wave_game();
     if (g >= t.B) return;
-    tree_expand<IS_ROOT>(t, g, lane_id(), lp1, lp2, lpm, priors220, values, noise, noise_stride, epsilon, sc, nullptr, step);
+    ptrdiff_t o = 0;
+    if (COMPACT) o = (ptrdiff_t)(t.leaf_kind[g] == kLeafExpand ? t.live_row[g] : 0) - g;
+    tree_expand<IS_ROOT>(t, g, lane_id(), lp1 ? lp1 + o * 36 : nullptr, lp2 ? lp2 + o * 36 : nullptr,
+                         lpm ? lpm + o * 36 : nullptr, priors220 ? priors220 + o * 220 : nullptr, values + o, noise,
+                         noise_stride, epsilon, sc, nullptr, step);
+}
+
+// the roots that need an evaluation (fresh trees: all live games; after lz_tree_advance: the games that did not keep a
+// subtree) -> the compact list of simulation 0
+__global__ __launch_bounds__(kBlock) void tree_live_roots_kernel(Tree t) {
+    const int g = blockIdx.x * kBlock + threadIdx.x;
+    if (g >= t.B) return;
+    if (t.leaf_kind[g] != kLeafExpand) return;
+    const int row = (int)atomicAdd(t.live_count, 1ull);
+    t.live_state[row] = t.leaf_state[g];
+    t.live_row[g] = row;
+}
+__global__ __launch_bounds__(kBlock) void zero_counts_kernel(unsigned long long* p, int n) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) p[i] = 0ull;
 }
 
 // expand + backup of simulation s fused with the selection of simulation s+1 (same wave, same game: the edge
 // records it just touched are still in L1/L2) -- one launch per simulation besides the network kernel.
 // (forcing 8 waves / SIMD -- <= 96 SGPRs, 126 scalar spills -- was measured: no gain at 16 384 games, 1 % slower at C2)
-template <bool IS_ROOT>
+template <bool IS_ROOT, bool COMPACT = false>
 __global__ __launch_bounds__(kBlock) void tree_expand_select_kernel(Tree t, const float* __restrict__ lp1,
                                                                     const float* __restrict__ lp2,
                                                                     const float* __restrict__ lpm,
@@ -115,10 +136,13 @@ __global__ __launch_bounds__(kBlock) void tree_expand_select_kernel(Tree t, cons
     if (g >= t.B) return;
     const int lane = lane_id();
     RootInfo root;
-    tree_expand<IS_ROOT>(t, g, lane, lp1, lp2, lpm, nullptr, values, noise, noise_stride, epsilon, sc, &root, step);
+    ptrdiff_t o = 0;
+    if (COMPACT) o = (ptrdiff_t)(t.leaf_kind[g] == kLeafExpand ? t.live_row[g] : 0) - g;
+    tree_expand<IS_ROOT>(t, g, lane, lp1 + o * 36, lp2 + o * 36, lpm + o * 36, nullptr, values + o, noise, noise_stride,
+                         epsilon, sc, &root, step);
     __threadfence_block();
     if (IS_ROOT) root = load_root_info(t, g);                  // the root record itself was just written
-    tree_select(t, g, lane, root);
+    tree_select(t, g, lane, root, COMPACT ? t.live_count + (step + 1) : nullptr);     // the leaves of simulation step + 1
 }
 
 // ---- wave-batched leaves: the legacy search of src/mcts.py (batch_K leaves per tree and wave, no virtual loss) ------
@@ -1082,6 +1106,35 @@ static int tree_search_impl(const LzTreeDesc* d, const LzNetDesc* net, int64_t s
     if (rc) return rc;
     (void)planes;   // the network kernel stages its input straight from the 32-byte packed leaf states
     const Tree t = make_tree(d);
+    if (t.live_count != nullptr) {
+        // compact evaluation lists: simulation s evaluates live_count[s] leaves (see LzTreeDesc.live_*)
+        if (d->live_count_cap < sims + 2) return LZ_ERR_ARG;
+        hipLaunchKernelGGL(zero_counts_kernel, dim3(gt(sims + 2)), dim3(kBlock), 0, as_stream(stream), t.live_count,
+                           (int)(sims + 2));
+        hipLaunchKernelGGL(tree_live_roots_kernel, dim3(gt(t.B)), dim3(kBlock), 0, as_stream(stream), t);
+        for (int64_t s = 0; s <= sims; ++s) {
+            rc = lz_net_forward_packed_counted_f16(net, d->live_state, B, d->live_count + s, lp1, lp2, lpmc, nullptr, values,
+                                                   stream);
+            if (rc) return rc;
+            if (s == sims) {
+                if (s == 0)
+                    hipLaunchKernelGGL((tree_expand_kernel<true, true>), dim3(gw(t.B)), dim3(kBlock), 0, as_stream(stream), t,
+                                       lp1, lp2, lpmc, (const float*)nullptr, values, noise, (int)noise_stride, epsilon, (int)s);
+                else
+                    hipLaunchKernelGGL((tree_expand_kernel<false, true>), dim3(gw(t.B)), dim3(kBlock), 0, as_stream(stream), t,
+                                       lp1, lp2, lpmc, (const float*)nullptr, values, (const float*)nullptr, 0, 0.f, (int)s);
+            } else if (s == 0) {
+                hipLaunchKernelGGL((tree_expand_select_kernel<true, true>), dim3(gw(t.B)), dim3(kBlock), 0, as_stream(stream),
+                                   t, lp1, lp2, lpmc, values, noise, (int)noise_stride, epsilon, (int)s);
+            } else {
+                (void)lz_prof_aux_begin(0, stream);
+                hipLaunchKernelGGL((tree_expand_select_kernel<false, true>), dim3(gw(t.B)), dim3(kBlock), 0, as_stream(stream),
+                                   t, lp1, lp2, lpmc, values, nullptr, 0, 0.f, (int)s);
+                (void)lz_prof_aux_end(0, stream, B);
+            }
+        }
+        return st();
+    }
     for (int64_t s = 0; s <= sims; ++s) {
         rc = lz_net_forward_packed_f16(net, d->leaf_state, B, lp1, lp2, lpmc, nullptr, values, stream);
         if (rc) return rc;

@@ -43,7 +43,8 @@ class LzTreeDesc(C.Structure):
                    "trace_kind", "trace_leaf", "trace_heads", "trace_priors", "trace_value")] + \
                [("trace_cap", C.c_int64), ("eval_count", C.c_void_p)] + \
                [(n, C.c_void_p) for n in ("chunk_list", "n_chunks", "free_chunks", "pool_top", "pool_stats")] + \
-               [("pool_chunks", C.c_int64)]
+               [("pool_chunks", C.c_int64)] + \
+               [(n, C.c_void_p) for n in ("live_state", "live_row", "live_count")] + [("live_count_cap", C.c_int64)]
 
 
 class LzTreeWaveDesc(C.Structure):
@@ -101,11 +102,22 @@ def auto_pool_chunks(num_games: int, max_sims: int, node_cap: int, chunk: int, d
     return max(n, 2)
 
 
+def samples_per_launch_pass(net) -> int:
+    """Positions one pass of the fused network kernel evaluates over the whole chip: workgroups per launch x samples per
+    workgroup (csrc/lz_net.hip: 256 x 16 for 64 channels, 512 x 8 in the half-workgroup shape, 256 x 8 for 128 channels)."""
+    ch, flags = int(net.desc.channels), int(net.desc.flags)
+    groups = int(net.desc.max_blocks) if int(net.desc.max_blocks) > 0 else (512 if (ch == 64 and flags & 1) else 256)
+    return groups * (16 if (ch == 64 and not flags & 1) else 8)
+
+
 class TreeEngine:
     def __init__(self, num_games: int, max_sims: int, device, exploration_weight: float = 1.0,
                  reuse_factor: float = 0.0, batch_k: int = 1, edge_chunk: int = EDGE_CHUNK,
-                 pool_chunks: Optional[int] = None) -> None:
-        """`reuse_factor` > 0 reserves room for kept subtrees of up to reuse_factor * max_sims nodes in every game's node
+                 pool_chunks: Optional[int] = None, compact_evals: bool = False) -> None:
+        """`compact_evals`: the fused search evaluates, per simulation, only the leaves that need the network (compact
+        device-side list, `LzTreeDesc.live_*`) -- a launch then costs ceil(live / samples per pass) network passes instead
+        of one per slot, so a draining wave gets cheaper as its games end; bit-identical results.
+        `reuse_factor` > 0 reserves room for kept subtrees of up to reuse_factor * max_sims nodes in every game's node
         arena (advance(); < 0: auto_reuse_factor).  Edges live in ONE pool per engine, handed out in chunks of `edge_chunk`
         records (`pool_chunks`: None = auto_pool_chunks).
         `batch_k` > 1: the legacy search's waves (src/mcts.py `batch_K`): up to batch_k distinct leaves per game are
@@ -194,6 +206,14 @@ class TreeEngine:
         self.reuse_dropped = z((2,), torch.int32)      # [0] kept subtrees dropped whole (defensive), [1] pruned to fit
         self.eval_count = z((B,), torch.int32)          # evaluations the games' expand steps consumed (LzTreeDesc.eval_count)
         self.desc.eval_count = self.eval_count.data_ptr()
+        self.compact_evals = bool(compact_evals) and self.batch_k == 1
+        self.live_total = z((1,), torch.int64)          # compact_evals: evaluations launched so far (sum of the per-simulation counts)
+        if self.compact_evals:
+            self.live = {"live_state": z((B, 4), torch.int64), "live_row": z((B,), torch.int32),
+                         "live_count": z((self.max_sims + 2,), torch.int64)}
+            for name, t in self.live.items():
+                setattr(self.desc, name, t.data_ptr())
+            self.desc.live_count_cap = self.max_sims + 2
         # persistent search kernel (lz_tree_search_persistent, one launch per move): built, parity-tested and MEASURED
         # SLOWER than the two-stream launch pairs at C2 (profiles/r03_experiments.md: 164-170 k against 192-194 k
         # positions/s), so it is opt-in (LZ_TREE_PERSISTENT=1 / the `persistent` attribute).  The CU's second workgroup
@@ -399,11 +419,14 @@ class TreeEngine:
                        L.ptr(self.lp1), L.ptr(self.lp2), L.ptr(self.lpm), L.ptr(self.values),
                        L.ptr(noise), L.i64(nz_stride), C.c_float(float(epsilon)), self._stream()),
                     "tree_search")
+        if self.compact_evals:                                      # evaluations launched = the leaves the lists held
+            self.live_total.add_(self.live["live_count"][: int(sims) + 1].sum())
 
     def persistent_ok(self, net: FusedNet) -> bool:
         """Whether search() runs the one-launch-per-move kernel: 64-channel net in fp16 mode, not switched off
         (`persistent` attribute; env LZ_TREE_PERSISTENT=0)."""
-        return bool(self.persistent) and self.batch_k <= 1 and int(net.desc.channels) == 64 and not (int(net.desc.flags) & 4)
+        return (bool(self.persistent) and self.batch_k <= 1 and int(net.desc.channels) == 64 and not (int(net.desc.flags) & 4)
+                and not self.compact_evals)
 
     def enable_phase_ticks(self) -> torch.Tensor:
         """Measurement aid: int64[workgroups, 4] = 100 MHz ticks each workgroup of the persistent search kernel spent in
@@ -456,8 +479,11 @@ class PortableTreeMCTS:
                  reuse_factor: float = -1.0, policy_target_temperature: Optional[float] = None,
                  policy_target_prior_pseudocount: float = 0.0, batch_k: int = 1, seed: int = 12345,
                  game_offset: int = 0, game_stride: Optional[int] = None, trace: bool = False,
-                 collect_timing: bool = False) -> None:
-        """`net`: a FusedNet (the production path: the whole search of a move is enqueued from C++ with the fused network
+                 collect_timing: bool = False, compact_evals: Optional[bool] = None) -> None:
+        """`compact_evals` (fused network only): per simulation only the leaves that need the network are evaluated
+        (`TreeEngine(compact_evals=True)`); None = when a launch of all slots is at least two network passes per CU (C3:
+        eight), i.e. when fewer live leaves make a launch shorter -- env LZ_TREE_COMPACT=0 / 1 overrides.
+        `net`: a FusedNet (the production path: the whole search of a move is enqueued from C++ with the fused network
         kernel in the loop, one hipGraph per move), or any module returning `ChessNet.forward`'s 4-tuple -- then the search
         runs the split-phase protocol (select -> planes -> module -> expand) with that module as an external fp32
         evaluator, on its own device (the reference's `PortableMCTS` with an arbitrary model, portable_mcts.py:381-386).
@@ -472,8 +498,14 @@ class PortableTreeMCTS:
         self.fused = isinstance(net, FusedNet)
         self.reuse_tree = bool(reuse_tree)
         self.batch_k = max(1, int(batch_k))
+        env_c = os.environ.get("LZ_TREE_COMPACT", "").strip()
+        if env_c in ("0", "1"):
+            compact_evals = env_c == "1"
+        if compact_evals is None:
+            compact_evals = self.fused and int(num_games) >= 2 * samples_per_launch_pass(net)
         self.engine = TreeEngine(num_games, num_simulations, device, exploration_weight,
-                                 reuse_factor=float(reuse_factor) if self.reuse_tree else 0.0, batch_k=self.batch_k)
+                                 reuse_factor=float(reuse_factor) if self.reuse_tree else 0.0, batch_k=self.batch_k,
+                                 compact_evals=bool(compact_evals) and self.fused and self.batch_k == 1)
         if trace:
             self.engine.enable_trace()
         if not self.fused:
@@ -614,6 +646,8 @@ class PortableTreeMCTS:
     @property
     def leaf_evals(self) -> int:
         """Network evaluations so far (batch_k > 1: one host read of the device-side counters)."""
+        if self.engine.compact_evals:
+            return int(self.engine.live_total.item())
         n = self._root_evals
         if self.batch_k > 1:
             n += int(self.engine.wbuf["eval_total"].item()) + int(self.engine.wbuf["eval_count"].item())
@@ -669,6 +703,7 @@ class PortableTreeMCTS:
         self._root_evals = 0
         self.extra_rounds = 0
         self.engine.eval_count.zero_()
+        self.engine.live_total.zero_()
         self.engine.reuse_dropped.zero_()
         # refused expansions / fewest free chunks are per run too (a cached engine must not report an earlier run's)
         self.engine.buf["pool_stats"].copy_(torch.tensor([0, self.engine.pool_chunks], dtype=torch.int32))
@@ -689,6 +724,7 @@ class PortableTreeMCTS:
         self._root_evals = 0
         self.extra_rounds = 0
         self.engine.eval_count.zero_()
+        self.engine.live_total.zero_()
         self.get_timing(reset=True)
         if self.batch_k > 1:
             self.engine.wbuf["eval_total"].zero_(); self.engine.wbuf["eval_count"].zero_()
@@ -1135,6 +1171,7 @@ def self_play_tree_gpu(model, num_games: int, mcts_simulations: int, temperature
     # what the bounded arenas did to this run (the reference's tree is unbounded): must all be 0 for results that equal an
     # unbounded tree's; a refused expansion means the edge pool was sized too small for this workload -- say so loudly
     engines = [p.engine for p in getattr(mcts, "parts", [])] or [mcts.engine]
+    compact_lists = all(e.compact_evals for e in engines)
     refused = sum(e.pool_status()["refused_expansions"] for e in engines)
     dropped = sum(int(e.reuse_dropped[0].item()) for e in engines)
     pruned = sum(int(e.reuse_dropped[1].item()) for e in engines)
@@ -1149,8 +1186,10 @@ def self_play_tree_gpu(model, num_games: int, mcts_simulations: int, temperature
         step_timing_ms=t_ms, step_timing_ratio={k: (t_ms[k] / t_total if t_total > 0 else 0.0) for k in keys},
         step_timing_calls={k: int(timing["timing_calls"].get(k, 0)) for k in keys},
         # the device-tail loop runs one fully masked ply per wave after the last game has ended (wave_tail.WaveTail.run)
+        # (with compact evaluation lists a fully masked ply launches no evaluation at all)
         mcts_counters={"leaf_eval_count": int(mcts.leaf_evals) - (wasted_plies * wave * (int(mcts_simulations) + 1)
-                                                                  if int(batch_k) <= 1 else 0),
+                                                                  if int(batch_k) <= 1 and not compact_lists else 0),
+                       "compact_eval_lists": int(compact_lists),
                        "masked_extra_plies": wasted_plies, "graph_retry_off": int(bool(mcts.graph_retry_off)),
                        # where the wall time outside `elapsed_sec` (the plies) goes: engine construction or cache hit,
                        # build() of the five tensors; graph capture happens inside the first plies

@@ -635,6 +635,27 @@ def test_production_search_path_c3_arithmetic():
     print(f"production parity C3 arithmetic: {tot}")
 
 
+@pytest.mark.parametrize("model_name,games,sims", [("b6c64", 77, 96), ("b10c128", 64, 800)])
+def test_compact_evaluation_lists_equal_the_dense_search(model_name, games, sims):
+    """`compact_evals` (LzTreeDesc.live_*): per simulation only the leaves that need the network are evaluated, through a
+    device-side list and lz_net_forward_packed_counted_f16.  The production replay in the oracle passes unchanged (same
+    leaf at every simulation, bit-identical visit counts / W sums / priors, network rows == a direct launch on the same
+    states), the root edge records equal the dense search's byte for byte, and every launched evaluation is a consumed one."""
+    _need_gpu()
+    from tests.tree_parity import run_production_parity, root_edges, EDGE_LOGICAL
+    dense, _ = run_production_parity(DEV, model_name, num_games=games, sims=sims, moves=3, seed=31)
+    assert not dense.engine.compact_evals
+    got, tot = run_production_parity(DEV, model_name, num_games=games, sims=sims, moves=3, seed=31, compact_evals=True)
+    assert got.engine.compact_evals and got.use_graph and not got.graph_retry_off and tot["kept"] > 0
+    for x, y in zip(root_edges(got.engine), root_edges(dense.engine)):
+        assert all(x[f].tobytes() == y[f].tobytes() for f in EDGE_LOGICAL) and ((x["child"] >= 0) == (y["child"] >= 0)).all()
+    assert torch.equal(got.engine.chosen_index, dense.engine.chosen_index)
+    assert torch.equal(got.engine.policy_dense, dense.engine.policy_dense)
+    assert got.consumed_evals == dense.consumed_evals                      # the same leaves needed the network ...
+    assert got.leaf_evals == got.consumed_evals < dense.leaf_evals        # ... and nothing else was launched
+    print(f"compact lists {model_name}: launched {got.leaf_evals} of the dense search's {dense.leaf_evals}")
+
+
 def test_production_search_direct_launches_equal_graph_replay():
     """The same search with direct launches (LZ_TREE_GRAPH=off path) and as a replayed hipGraph: identical trees."""
     _need_gpu()

@@ -447,7 +447,7 @@ def replay_part_in_oracle(part, trees, move, c_eps, check_net=None, float_tol=1e
 
 
 def run_production_parity(device, model_name="b6c64", num_games=128, sims=200, moves=3, dual=False, seed=0, use_graph=True,
-                          noise=True, temperature=1.0, reuse_factor=4.0, rng_seed=777, states=None):
+                          noise=True, temperature=1.0, reuse_factor=4.0, rng_seed=777, states=None, compact_evals=False):
     """bench.py's search (PortableTreeMCTS / DualStreamTreeMCTS with the fused network, hipGraph, subtree reuse, Philox
     noise and sampled moves) over `moves` consecutive moves from a mixed-phase batch, replayed in the oracle."""
     from liuzhou_amd.net import ChessNet, MODEL_CONFIGS
@@ -467,7 +467,8 @@ def run_production_parity(device, model_name="b6c64", num_games=128, sims=200, m
         states = {f: np.ascontiguousarray(np.asarray(st_all[f])[idx0]) for f in FIELDS}
     B = num_games = int(np.asarray(states["board"]).shape[0])
     kw = dict(exploration_weight=1.0, add_dirichlet_noise=noise, dirichlet_alpha=0.3, dirichlet_epsilon=0.25,
-              sample_moves=True, use_graph=use_graph, reuse_tree=True, reuse_factor=reuse_factor, trace=True, seed=rng_seed)
+              sample_moves=True, use_graph=use_graph, reuse_tree=True, reuse_factor=reuse_factor, trace=True, seed=rng_seed,
+              compact_evals=bool(compact_evals))
     mcts = (DualStreamTreeMCTS if dual else PortableTreeMCTS)(net, B, sims, dev, **kw)
     parts = list(zip(mcts.bounds, mcts.parts)) if dual else [((0, B), mcts)]
     cur = [O.state_from_batch(states, i) for i in range(B)]
