@@ -60,6 +60,9 @@ def main() -> int:
     ap.add_argument("--soft-label-alpha", type=float, default=0.3)
     ap.add_argument("--overlap", type=int, default=0, choices=(0, 1),
                     help="1: lag-1 pipeline, the trainer trains on generation i-1 while generation i is played")
+    ap.add_argument("--net-check", type=int, default=0,
+                    help="single process: after every checkpoint hand-off evaluate this many of the iteration's positions "
+                         "with the refreshed fp16 kernel, the fp32 module and torch.autocast(float16) and log the differences")
     ap.add_argument("--check-digests", type=int, default=1,
                     help="after every hand-off compare an exact digest of each player's packed device weights with the "
                          "trainer's (outside the timed part of the iteration)")
@@ -171,6 +174,29 @@ def main() -> int:
             fused.refresh(model)                                       # new checkpoint into the same device buffers
         torch.cuda.synchronize(dev)
         t_handoff = time.perf_counter() - t3
+        net_check = None
+        if args.net_check > 0 and world == 1 and fused is not None and batch.num_samples > 0:
+            # the TRAINED weights in the fp16-activation kernel: against the fp32 module and against the reference's own
+            # inference mode (torch.autocast(float16), v1/python/mcts_gpu.py:640-646) on positions of this iteration
+            x = batch.state_tensors[: int(args.net_check)].contiguous()
+            with torch.inference_mode():
+                r32 = model(x)
+                with torch.autocast("cuda", dtype=torch.float16):
+                    r16 = tuple(t.float() for t in model(x))
+            f = fused(x)
+            fv = fused.last_value
+            from liuzhou_amd.net import bucket_logits_to_scalar
+            v32, v16 = bucket_logits_to_scalar(r32[3]), bucket_logits_to_scalar(r16[3])
+            finite = all(bool(torch.isfinite(t).all()) for t in f) and bool(torch.isfinite(fv).all())
+            d_f = max(float((f[k].exp() - r32[k].exp()).abs().max()) for k in range(3))
+            d_a = max(float((r16[k].exp() - r32[k].exp()).abs().max()) for k in range(3))
+            agree = min(float((f[k].argmax(1) == r32[k].argmax(1)).float().mean()) for k in range(3))
+            net_check = {"positions": int(x.shape[0]), "finite": finite, "max_dprob_fused_vs_fp32": d_f,
+                         "max_dprob_autocast_vs_fp32": d_a, "argmax_agreement_min_head": agree,
+                         "max_dvalue_fused_vs_fp32": float((fv - v32).abs().max()),
+                         "max_dvalue_autocast_vs_fp32": float((v16 - v32).abs().max()),
+                         "max_abs_logprob_fp32": max(float(r32[k].abs().max()) for k in range(3)),
+                         "policy_entropy_mean_fp32": float(-(r32[0].exp() * r32[0]).sum(1).mean())}
         if world > 1:
             dist.barrier()
         t_total = time.perf_counter() - t0
@@ -193,7 +219,7 @@ def main() -> int:
                         "positions_per_sec": round(n / max(t_total, 1e-9), 1),
                         "train_samples": trained, "avg_loss": (loss or {}).get("avg_loss"),
                         "samples_stepped": (loss or {}).get("samples_stepped"), "weights_equal_on_all_ranks": same,
-                        "weights_digest": digests_seen[-1] if digests_seen else None})
+                        "weights_digest": digests_seen[-1] if digests_seen else None, "net_check": net_check})
     tail = None
     if trains and overlap and pending is not None:                     # the last generation, nothing left to overlap with
         t0 = time.perf_counter()

@@ -223,3 +223,92 @@ def test_fused_fp16_kernel_against_autocast_and_its_effect_on_the_search():
     # between two children decided by the last bits of a prior is legitimate; more than that would be a defect)
     n_live = int(live.sum())
     assert same >= 1.0 - 1.0 / n_live - 1e-9 and arg >= 1.0 - 1.0 / n_live - 1e-9 and l1.mean() <= 2.0 / (128 * n_live) + 1e-9
+
+
+def _scaled_net(name, scale, seed=20260314):
+    """A net whose activations are `scale` times those of the random-init net: the stem's weights are scaled, the residual
+    stream (ReLU and the eval-mode BatchNorm affines are positively homogeneous up to their shifts) carries the factor to
+    the heads, whose logits then spread like a trained net's."""
+    from liuzhou_amd.net import ChessNet, MODEL_CONFIGS
+    torch.manual_seed(seed)
+    m = ChessNet(**MODEL_CONFIGS[name]).eval()
+    with torch.no_grad():
+        m.stem_conv.weight.mul_(float(scale))
+    return m.to(DEV)
+
+
+@pytest.mark.parametrize("name,scale", [("b6c64", 8.0), ("b6c64", 64.0), ("b10c128", 8.0), ("b10c128", 64.0)])
+def test_fused_fp16_kernel_on_trained_scale_activations(name, scale):
+    """Every other network test uses random-init weights (activations of order 1).  Here the activations are 8x / 64x
+    larger: no inf / NaN out of the fp16 activation board, the fused kernel stays within 4x of what the reference's own
+    inference mode (torch.autocast(float16), v1/python/mcts_gpu.py:640-646) loses against fp32, the most probable action of
+    every head is the fp32 module's wherever fp32 itself separates the top two by more than that error, scalar values too."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from liuzhou_amd.net import bucket_logits_to_scalar
+    from liuzhou_amd.net_hip import FusedNet
+    m = _scaled_net(name, scale)
+    x = _planes(1500, seed=int(scale))
+    with torch.inference_mode():
+        r32 = m(x)
+        with torch.autocast("cuda", dtype=torch.float16):
+            r16 = tuple(t.float() for t in m(x))
+    fused = FusedNet(m)
+    f = fused(x)
+    fv = fused.last_value
+    for t in (*f, fv):
+        assert torch.isfinite(t).all(), "inf / NaN out of the fp16 kernel"
+    v32, v16 = bucket_logits_to_scalar(r32[3]), bucket_logits_to_scalar(r16[3])
+    d_f = max(float((f[k].exp() - r32[k].exp()).abs().max()) for k in range(3))
+    d_a = max(float((r16[k].exp() - r32[k].exp()).abs().max()) for k in range(3))
+    dv_f, dv_a = float((fv - v32).abs().max()), float((v16 - v32).abs().max())
+    spread = max(float(r32[k].abs().max()) for k in range(3))
+    print(f"trained-scale {name} x{scale:g}: max |log-prob| {spread:.1f}; max |dprob| fused {d_f:.2e} / autocast {d_a:.2e}; "
+          f"max |dvalue| fused {dv_f:.2e} / autocast {dv_a:.2e}")
+    assert spread > 2.0 * float(np.log(36.0)), "the scaled net is not peaked: the test would not exercise anything"
+    assert d_f <= 4.0 * d_a + 1e-5 and dv_f <= 4.0 * dv_a + 1e-5
+    for k in range(3):
+        top2 = r32[k].exp().topk(2, dim=1).values
+        clear = (top2[:, 0] - top2[:, 1]) > 4.0 * max(d_a, d_f) + 1e-6
+        assert int(clear.sum()) > 100
+        assert bool((f[k].argmax(1) == r32[k].argmax(1))[clear].all())
+
+
+def test_fused_fp16_kernel_after_real_optimizer_steps():
+    """A few dozen real optimizer steps (train_network_from_tensors, the reference's AdamW + AMP loop) on self-play rows,
+    with a learning rate high enough to move the weights visibly; then `FusedNet.refresh` -- the checkpoint hand-off of the
+    staged loop -- and the same comparison against fp32 / autocast."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from liuzhou_amd.net import ChessNet, MODEL_CONFIGS, bucket_logits_to_scalar
+    from liuzhou_amd.net_hip import FusedNet
+    from liuzhou_amd.train_bridge import train_network_from_tensors
+    from liuzhou_amd.tree_engine import clear_engine_cache, self_play_tree_gpu
+    torch.manual_seed(20260314)
+    m = ChessNet(**MODEL_CONFIGS["b6c64"]).eval().to(DEV)
+    fused = FusedNet(m)
+    batch, _ = self_play_tree_gpu(fused, num_games=256, mcts_simulations=16, temperature_init=1.0, temperature_final=0.1,
+                                  temperature_threshold=10, exploration_weight=1.0, device=DEV, max_game_plies=48,
+                                  concurrent_games=256)
+    clear_engine_cache()
+    before = [p.detach().clone() for p in m.parameters()]
+    m, metrics = train_network_from_tensors(m, batch, batch_size=512, epochs=3, lr=5e-3, device=DEV)
+    m.eval()
+    moved = max(float((a - b).abs().max()) for a, b in zip(before, m.parameters()))
+    assert metrics["epoch_stats"][-1]["avg_loss"] < metrics["epoch_stats"][0]["avg_loss"] and moved > 1e-2
+    fused.refresh(m)
+    x = batch.state_tensors[:2048].contiguous()
+    with torch.inference_mode():
+        r32 = m(x)
+        with torch.autocast("cuda", dtype=torch.float16):
+            r16 = tuple(t.float() for t in m(x))
+    f = fused(x)
+    for t in (*f, fused.last_value):
+        assert torch.isfinite(t).all()
+    d_f = max(float((f[k].exp() - r32[k].exp()).abs().max()) for k in range(3))
+    d_a = max(float((r16[k].exp() - r32[k].exp()).abs().max()) for k in range(3))
+    dv_f = float((fused.last_value - bucket_logits_to_scalar(r32[3])).abs().max())
+    dv_a = float((bucket_logits_to_scalar(r16[3]) - bucket_logits_to_scalar(r32[3])).abs().max())
+    print(f"after {sum(e['steps'] if 'steps' in e else 0 for e in metrics['epoch_stats'])} optimizer steps (max |dw| {moved:.3f}): "
+          f"max |dprob| fused {d_f:.2e} / autocast {d_a:.2e}; max |dvalue| fused {dv_f:.2e} / autocast {dv_a:.2e}")
+    assert d_f <= 4.0 * d_a + 1e-5 and dv_f <= 4.0 * dv_a + 1e-5

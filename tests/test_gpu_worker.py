@@ -104,6 +104,38 @@ def test_staged_loop_single_process(tmp_path):
     assert out["iterations"][1]["avg_loss"] is not None
 
 
+def test_staged_loop_searches_with_weights_of_three_real_training_iterations():
+    """Four iterations of the staged loop with a learning rate that moves the weights: iterations 2..4 search with
+    checkpoints that went through 1..3 real training passes and `FusedNet.refresh`; after every hand-off the refreshed
+    fp16 kernel is compared with the fp32 module and with torch.autocast(float16) on that iteration's positions."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, os.path.join(root, "scripts", "staged_loop.py"), "--iterations", "4",
+                          "--games-per-gpu", "128", "--sims", "16", "--max-game-plies", "48", "--batch-size", "512",
+                          "--epochs", "2", "--lr", "0.004", "--net-check", "2048"],
+                         capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout + res.stderr
+    out = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+    its = out["iterations"]
+    assert len(its) == 4 and len({it["weights_digest"] for it in its}) == 4          # every hand-off carried new weights
+    for it in its:
+        nc = it["net_check"]
+        assert nc["finite"] and nc["positions"] == 2048
+        assert nc["max_dprob_fused_vs_fp32"] <= 4.0 * nc["max_dprob_autocast_vs_fp32"] + 1e-5, nc
+        assert nc["max_dvalue_fused_vs_fp32"] <= 4.0 * nc["max_dvalue_autocast_vs_fp32"] + 1e-5, nc
+        assert nc["argmax_agreement_min_head"] >= 0.99, nc
+        assert it["positions"] > 0 and it["avg_loss"] is not None
+    assert its[-1]["avg_loss"] < its[0]["avg_loss"]
+    print("net_check per iteration:", [(round(it["net_check"]["max_dprob_fused_vs_fp32"], 7),
+                                        round(it["net_check"]["max_dprob_autocast_vs_fp32"], 7),
+                                        round(it["net_check"]["max_abs_logprob_fp32"], 2)) for it in its])
+
+
 def test_one_full_iteration_selfplay_train_eval_through_the_clis(tmp_path):
     """selfplay_stage.py -> train_stage.py (streaming) -> eval_arena.py: the three stages of one big_train_v1 iteration."""
     if not torch.cuda.is_available():
