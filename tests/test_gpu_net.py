@@ -265,7 +265,10 @@ def test_fused_fp16_kernel_on_trained_scale_activations(name, scale):
     spread = max(float(r32[k].abs().max()) for k in range(3))
     print(f"trained-scale {name} x{scale:g}: max |log-prob| {spread:.1f}; max |dprob| fused {d_f:.2e} / autocast {d_a:.2e}; "
           f"max |dvalue| fused {dv_f:.2e} / autocast {dv_a:.2e}")
-    assert spread > 2.0 * float(np.log(36.0)), "the scaled net is not peaked: the test would not exercise anything"
+    with torch.inference_mode():
+        act, act1 = float(m.trunk(x[:256]).abs().max()), float(_scaled_net(name, 1.0).trunk(x[:256]).abs().max())
+    print(f"   trunk output max |activation| {act:.1f} (random init: {act1:.2f})")
+    assert act > 0.8 * scale * act1, "the scaled net's activations are not `scale` times larger: nothing is exercised"
     assert d_f <= 4.0 * d_a + 1e-5 and dv_f <= 4.0 * dv_a + 1e-5
     for k in range(3):
         top2 = r32[k].exp().topk(2, dim=1).values
@@ -294,7 +297,7 @@ def test_fused_fp16_kernel_after_real_optimizer_steps():
     before = [p.detach().clone() for p in m.parameters()]
     m, metrics = train_network_from_tensors(m, batch, batch_size=512, epochs=3, lr=5e-3, device=DEV)
     m.eval()
-    moved = max(float((a - b).abs().max()) for a, b in zip(before, m.parameters()))
+    moved = max(float((a - b.detach()).abs().max()) for a, b in zip(before, m.parameters()))
     assert metrics["epoch_stats"][-1]["avg_loss"] < metrics["epoch_stats"][0]["avg_loss"] and moved > 1e-2
     fused.refresh(m)
     x = batch.state_tensors[:2048].contiguous()
@@ -309,6 +312,6 @@ def test_fused_fp16_kernel_after_real_optimizer_steps():
     d_a = max(float((r16[k].exp() - r32[k].exp()).abs().max()) for k in range(3))
     dv_f = float((fused.last_value - bucket_logits_to_scalar(r32[3])).abs().max())
     dv_a = float((bucket_logits_to_scalar(r16[3]) - bucket_logits_to_scalar(r32[3])).abs().max())
-    print(f"after {sum(e['steps'] if 'steps' in e else 0 for e in metrics['epoch_stats'])} optimizer steps (max |dw| {moved:.3f}): "
+    print(f"after {len(metrics['epoch_stats'])} epochs over {batch.num_samples} rows (max |dw| {moved:.3f}): "
           f"max |dprob| fused {d_f:.2e} / autocast {d_a:.2e}; max |dvalue| fused {dv_f:.2e} / autocast {dv_a:.2e}")
     assert d_f <= 4.0 * d_a + 1e-5 and dv_f <= 4.0 * dv_a + 1e-5
