@@ -62,6 +62,44 @@ def build_hip(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+EXT_SOURCE = os.path.join(CSRC, "v0_core_ext.cpp")
+EXT_NAME = "_v0_core_native"
+
+
+def ext_path() -> str:
+    import sysconfig
+    return os.path.join(PKG, EXT_NAME + (sysconfig.get_config_var("EXT_SUFFIX") or ".so"))
+
+
+def build_ext(force: bool = False, verbose: bool = False) -> str:
+    """g++ -> liuzhou_amd/_v0_core_native*.so: the compiled (PyBind11 + torch) `v0_core` operator layer over the C ABI
+    (csrc/v0_core_ext.cpp) -- what the reference's v0/src/bindings/module.cpp is to its kernels.  Plain g++ against the
+    torch / pybind11 / HIP headers of the image (no cmake, no JIT cache); needs no GPU to build."""
+    out = ext_path()
+    deps = [EXT_SOURCE, os.path.join(PKG, "..", "include", "liuzhou_hip.h")]
+    if not force and os.path.exists(out) and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in deps):
+        return out
+    import sysconfig
+    import pybind11
+    from torch.utils import cpp_extension as ce
+    cxx = os.environ.get("CXX") or shutil.which("g++") or shutil.which("c++")
+    if not cxx:
+        raise RuntimeError("no host C++ compiler (g++) found for the compiled v0_core layer")
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    inc = ["-I" + p for p in ce.include_paths()] + ["-I" + sysconfig.get_paths()["include"], "-I" + pybind11.get_include(),
+                                                    "-I" + os.path.join(rocm, "include")]
+    libdir = ce.library_paths()[0]
+    cmd = [cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-w", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
+           "-DTORCH_API_INCLUDE_EXTENSION_H", "-DTORCH_EXTENSION_NAME=" + EXT_NAME, "-D_GLIBCXX_USE_CXX11_ABI=1", *inc,
+           "-o", out, EXT_SOURCE, "-L" + libdir, "-Wl,-rpath," + libdir, "-ltorch_python", "-ltorch", "-ltorch_cpu", "-lc10",
+           "-lc10_hip", "-ldl", "-lpthread"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return out
+
+
 if __name__ == "__main__":
     print(build_hip(force=True, verbose=True))
     print(build_host(force=True, verbose=True))
+    print(build_ext(force=True, verbose=True))

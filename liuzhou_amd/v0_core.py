@@ -8,6 +8,15 @@ libliuzhou_hip.so on the *current* torch stream.  Like the reference extension, 
 (libliuzhou_host.so, csrc/lz_host.cpp: plain loops over the same bitboard rules) with the reference's CPU error
 convention (an illegal action raises); the search engines and the network kernel are HIP-only.
 
+Two bindings of the same C ABI carry the operators (round 5):
+  * `native`  -- the compiled PyBind11 + torch layer `liuzhou_amd/_v0_core_native*.so` (csrc/v0_core_ext.cpp, built by
+                 `liuzhou_amd.build.build_ext` / `__graft_entry__.build()`): what the reference's module.cpp is to its
+                 kernels; a few microseconds of host time per call.  Used when it is built (LZ_V0_CORE_NATIVE=0 turns it off).
+  * `python`  -- the ctypes layer below (12 - 22 us per call); always available, and the only carrier of the helpers that
+                 are not part of the reference surface (`self_play_step_raw`, ...).
+`binding("native" | "python")` returns either as a namespace (the parity tests run over both); the module-level names
+are the native ones when available.
+
 Drop-in use: put `liuzhou_amd/dropin` on PYTHONPATH, then `import v0_core` resolves to this module.
 """
 from __future__ import annotations
@@ -370,6 +379,134 @@ def finalize_trajectory_inplace(value_targets, soft_value_targets, player_signs,
     L.check(st, "finalize_trajectory_inplace")
     kidx = torch.nonzero(keep).view(-1)
     return sl.index_select(0, kidx), fcounts.index_select(0, kidx), counts_out
+
+
+def root_sparse_writeback(legal_index_mat, action_code_mat, valid_mask, legal_policy, local_picks, valid_root_indices,
+                          batch_size: int, total_action_dim: int):
+    """module.cpp:365-439, :1364-1373 -> (policy_dense f32[B,T], chosen_action_indices i64[B] (-1 where no root),
+    chosen_action_codes i32[B,4] (-1), chosen_valid_mask bool[B]): the packed per-root policy scattered back to dense rows
+    and the picked actions' codes.  A tensor-library composition in the reference too (no kernel of its own); the fused
+    `root_finalize_from_visits` is what the hot path uses."""
+    if int(batch_size) < 0:
+        raise RuntimeError("batch_size must be non-negative")
+    if int(total_action_dim) <= 0:
+        raise RuntimeError("total_action_dim must be positive")
+    if legal_index_mat.dim() != 2 or valid_mask.dim() != 2 or legal_policy.dim() != 2:
+        raise RuntimeError("legal_index_mat / valid_mask / legal_policy must be [R, M]")
+    if action_code_mat.dim() != 3 or int(action_code_mat.shape[2]) != 4:
+        raise RuntimeError("action_code_mat must be [R, M, 4]")
+    R, M = int(legal_index_mat.shape[0]), int(legal_index_mat.shape[1])
+    if tuple(valid_mask.shape) != (R, M) or tuple(legal_policy.shape) != (R, M) or tuple(action_code_mat.shape[:2]) != (R, M):
+        raise RuntimeError("legal_index_mat / valid_mask / legal_policy / action_code_mat shape mismatch")
+    if local_picks.dim() != 1 or int(local_picks.shape[0]) != R or valid_root_indices.dim() != 1 or \
+            int(valid_root_indices.shape[0]) != R:
+        raise RuntimeError("local_picks / valid_root_indices must be [R]")
+    dev = legal_index_mat.device
+    if any(t.device != dev for t in (action_code_mat, valid_mask, legal_policy, local_picks, valid_root_indices)):
+        raise RuntimeError("all tensors must be on the same device")
+    idx, codes = _c(legal_index_mat, torch.int64), _c(action_code_mat, torch.int32)
+    weights = _c(legal_policy, torch.float32) * _c(valid_mask, torch.bool).to(torch.float32)
+    picks, roots = _c(local_picks, torch.int64), _c(valid_root_indices, torch.int64)
+    B, T = int(batch_size), int(total_action_dim)
+    rows = torch.zeros((R, T), dtype=torch.float32, device=dev).scatter_add_(1, idx, weights)
+    policy_dense = torch.zeros((B, T), dtype=torch.float32, device=dev)
+    chosen_idx = torch.full((B,), -1, dtype=torch.int64, device=dev)
+    chosen_codes = torch.full((B, 4), -1, dtype=torch.int32, device=dev)
+    chosen_valid = torch.zeros((B,), dtype=torch.bool, device=dev)
+    policy_dense.index_copy_(0, roots, rows)
+    chosen_idx.index_copy_(0, roots, idx.gather(1, picks.view(-1, 1)).view(-1))
+    chosen_codes.index_copy_(0, roots, codes.gather(1, picks.view(-1, 1, 1).expand(-1, 1, 4)).view(-1, 4))
+    chosen_valid.index_fill_(0, roots, True)
+    return policy_dense, chosen_idx, chosen_codes, chosen_valid
+
+
+def postprocess_value_head(raw_values: torch.Tensor) -> torch.Tensor:
+    """v0/src/net/encoding.cpp:81-89 (module.cpp:1340-1342): a (..., 3) win/draw/loss head -> P(win) - P(loss), a scalar
+    head -> tanh."""
+    if raw_values.dim() >= 2 and int(raw_values.shape[-1]) == 3:
+        p = torch.softmax(raw_values, dim=-1)
+        return p[..., 0] - p[..., 2]
+    return torch.tanh(raw_values)
+
+
+def apply_temperature_scaling(probs: torch.Tensor, temperature: float, dim: int = -1) -> torch.Tensor:
+    """v0/src/net/encoding.cpp:91-113 (module.cpp:1344-1348): p ** (1 / T) over the positive entries, renormalised along
+    `dim`; T <= 1e-6 returns a copy."""
+    probs = probs.contiguous()
+    if float(temperature) <= 1e-6:
+        return probs.clone()
+    d = dim + probs.dim() if dim < 0 else dim
+    if not 0 <= d < probs.dim():
+        raise RuntimeError("Invalid dimension for temperature scaling")
+    powered = torch.where(probs > 0, probs.pow(1.0 / max(float(temperature), 1e-6)), torch.zeros_like(probs))
+    sums = powered.sum(d, keepdim=True)
+    return torch.where(sums > 0, powered / sums, torch.zeros_like(powered))
+
+
+# ---- the two bindings ---------------------------------------------------------------------------------------------------
+NATIVE_OPS = ("encode_actions_fast", "batch_apply_moves", "batch_apply_moves_inplace", "states_to_model_input",
+              "project_policy_logits_fast", "root_pack_rows", "root_pack_sparse_actions", "root_puct_allocate_visits",
+              "root_finalize_from_visits", "self_play_step_inplace", "finalize_trajectory_inplace", "root_sparse_writeback",
+              "postprocess_value_head", "apply_temperature_scaling")
+_python_ops = {name: globals()[name] for name in NATIVE_OPS}
+_native = None
+_native_error = None
+
+
+def _load_native():
+    """Import liuzhou_amd/_v0_core_native*.so (if built) and hand it the two builds of the C ABI."""
+    import importlib.util
+    import os
+    from .build import HOST_LIB, LIB, build_host, ext_path
+    path = ext_path()
+    if not os.path.exists(path):
+        return None
+    spec = importlib.util.spec_from_file_location("liuzhou_amd._v0_core_native", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    hip = os.environ.get("LZ_HIP_LIB", LIB)
+    host = os.environ.get("LZ_HOST_LIB") or (HOST_LIB if os.path.exists(HOST_LIB) else build_host())
+    mod.bind_libraries(hip if os.path.exists(hip) else "", host)       # a missing HIP library: HIP tensors raise, no fallback
+    return mod
+
+
+def binding(kind: str = "auto"):
+    """The operator surface over one binding: "native" (compiled), "python" (ctypes) or "auto" (what this module exports)."""
+    import types
+    if kind == "auto":
+        kind = "native" if _native is not None else "python"
+    if kind == "python":
+        return types.SimpleNamespace(kind="python", **_python_ops)
+    if kind == "native":
+        if _native is None:
+            raise RuntimeError(f"the compiled v0_core layer is not available ({_native_error or 'not built: python -m liuzhou_amd.build'})")
+        return types.SimpleNamespace(kind="native", **{name: getattr(_native, name) for name in NATIVE_OPS})
+    raise ValueError(f"binding must be native / python / auto, got {kind!r}")
+
+
+def active_binding() -> str:
+    return "native" if _native is not None else "python"
+
+
+def _activate():
+    global _native, _native_error
+    import os
+    if os.environ.get("LZ_V0_CORE_NATIVE", "1").strip() in ("0", "off", "false"):
+        _native_error = "switched off by LZ_V0_CORE_NATIVE"
+        return
+    try:
+        _native = _load_native()
+    except Exception as exc:      # a stale or broken build must not take the operators away: the ctypes layer stays
+        _native, _native_error = None, repr(exc)
+        return
+    if _native is None:
+        _native_error = "not built"
+        return
+    for name in NATIVE_OPS:
+        globals()[name] = getattr(_native, name)
+
+
+_activate()
 
 
 def __getattr__(name: str):

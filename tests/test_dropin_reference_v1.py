@@ -36,21 +36,26 @@ np.savez(sys.argv[1], state_tensors=batch.state_tensors.numpy(), legal_masks=bat
          policy_targets=batch.policy_targets.numpy(), value_targets=batch.value_targets.numpy(),
          soft_value_targets=batch.soft_value_targets.numpy(),
          outcome=np.asarray([stats.black_wins, stats.white_wins, stats.draws]),
-         libs=np.asarray([int(_lib._host is not None), int(_lib._lib is not None)]))
+         libs=np.asarray([int(_lib._host is not None), int(_lib._lib is not None), int(v0_core.active_binding() == "native")]))
 '''
 
 
 @pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "v1", "python")), reason="reference not mounted")
-def test_reference_v1_selfplay_runs_unmodified_over_our_v0_core(tmp_path):
+@pytest.mark.parametrize("binding", ["native", "python"])
+def test_reference_v1_selfplay_runs_unmodified_over_our_v0_core(tmp_path, binding):
+    """`binding`: the compiled PyBind11 layer (what `import v0_core` gives once it is built) and the ctypes layer."""
     out = tmp_path / "trace.npz"
     env = dict(os.environ)
+    env["LZ_V0_CORE_NATIVE"] = "1" if binding == "native" else "0"
     env["PYTHONPATH"] = os.pathsep.join([os.path.join(ROOT, "liuzhou_amd", "dropin"), ROOT, REF])
     env["PYTHONDONTWRITEBYTECODE"] = "1"
     r = subprocess.run([sys.executable, "-c", CHILD, str(out)], env=env, cwd=str(tmp_path), capture_output=True, text=True,
                        timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     got, z = np.load(out), load("g8_selfplay.npz")
-    assert got["libs"].tolist() == [1, 0]        # the host build of our C ABI served the CPU tensors; the HIP one was never loaded
+    # the host build of our C ABI served the CPU tensors (ctypes layer: loaded by _lib; compiled layer: dlopen'ed by the
+    # extension itself, so _lib loaded nothing); the HIP library was never loaded through _lib either way
+    assert got["libs"].tolist() == ([0, 0, 1] if binding == "native" else [1, 0, 0])
     n = int(z["num_positions"])
     want_states = np.unpackbits(z["state_tensors"], axis=1)[:, :11 * 36].reshape(n, 11, 6, 6).astype(np.float32)
     assert got["state_tensors"].shape[0] == n and np.array_equal(got["state_tensors"], want_states)

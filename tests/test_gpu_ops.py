@@ -13,12 +13,31 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-@pytest.fixture(scope="module")
-def v0():
+class V0Binding:
+    """`v0_core` with its operators taken from ONE binding of the C ABI: "native" = the compiled PyBind11 layer
+    (csrc/v0_core_ext.cpp), "python" = the ctypes layer; everything else comes from the module."""
+
+    def __init__(self, kind: str) -> None:
+        from liuzhou_amd import v0_core
+        self._mod, self._ops, self.kind = v0_core, vars(v0_core.binding(kind)), kind
+
+    def __getattr__(self, name):
+        ops = object.__getattribute__(self, "_ops")
+        return ops[name] if name in ops else getattr(object.__getattribute__(self, "_mod"), name)
+
+
+def binding_or_skip(kind: str) -> V0Binding:
+    from liuzhou_amd import v0_core
+    if kind == "native" and v0_core._native is None:
+        pytest.skip(f"compiled v0_core layer unavailable: {v0_core._native_error}")
+    return V0Binding(kind)
+
+
+@pytest.fixture(scope="module", params=["native", "python"])
+def v0(request):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
-    from liuzhou_amd import v0_core
-    return v0_core
+    return binding_or_skip(request.param)
 
 
 def to_dev(st):
