@@ -332,9 +332,11 @@ LZ_API int lz_prof_aux_summary(int kind, double* total_ms, int64_t* launches, in
  *   chunk_list [g*chunk_cap .. +chunk_cap)  ids of the chunks game g owns, in the order it took them; n_chunks[g]
  *   free_chunks[pool_chunks], pool_top[1]   stack of free chunk ids and its height; the caller initialises them to
  *                                           0 .. pool_chunks-1 and pool_chunks, n_chunks / n_edges to 0
- *   pool_stats[2]   [0] += expansions refused because no chunk was free (the leaf stays unexpanded, its value is still
+ *   pool_stats[3]   [0] += expansions refused because no chunk was free (the leaf stays unexpanded, its value is still
  *                   backed up, the next visit tries again -- results then differ from an unbounded tree, so size the
- *                   pool so that this stays 0); [1] = min(free chunks seen) (initialise to pool_chunks)
+ *                   pool so that this stays 0); [1] = min(free chunks seen) (initialise to pool_chunks); [2] = fresh roots
+ *                   that have not taken the chunk of their first expansion yet (initialise to 0): a chunk stays reserved
+ *                   for each of them, so pool_chunks >= num_games is required
  * Every edge index in a record or hand-off array (node edge_begin, edge cbegin, path, leaf_edge) is an index into the
  * pool; (pool_chunks + 1) * edge_chunk <= 2^31.  chunk_cap * (edge_chunk - 71) >= node_cap * 72 makes the node arena the
  * only per-game bound (required by lz_tree_advance).  A kept subtree that would not leave room for the next search in
@@ -381,7 +383,7 @@ typedef struct LzTreeDesc {
     int32_t* n_chunks;             /* [B] */
     int32_t* free_chunks;          /* [pool_chunks] */
     int32_t* pool_top;             /* [1] */
-    int32_t* pool_stats;           /* [2] */
+    int32_t* pool_stats;           /* [3] */
     int64_t  pool_chunks;
     /* optional compact evaluation list of lz_tree_search / lz_tree_search_continue (all three set, live_count_cap >= sims + 2):
      * every simulation's leaves that NEED the network (live game, leaf to expand -- not a terminal leaf, not a kept

@@ -518,6 +518,7 @@ __global__ __launch_bounds__(kBlock) void tree_advance_kernel(Tree t, const int*
     const int n_chunks = t.n_chunks[g];
     const int CH = t.chunk;
     int ci = 0, off = 0;                                         // chunk being filled (index into the list), its fill
+    bool broken = false;                                         // the packing ran past the game's chunk list (wave-uniform)
     int list_reg = lane < n_chunks ? list[lane] : 0;             // list[64 * (ci / 64) + lane]: no load on a chunk change
     int cbase = lzw::lane_bcast(list_reg, 0) * CH;
     // (the records of two words are fetched together: a word's stores land below its own ids, never on the next word's)
@@ -555,7 +556,8 @@ __global__ __launch_bounds__(kBlock) void tree_advance_kernel(Tree t, const int*
                                                   : (lzw::lane_bcast(incl, first) - lzw::lane_bcast(c2, first));
                 off += placed;
                 if (!over) break;
-                ci = ci + 1 < n_chunks ? ci + 1 : ci;           // (always within the list: see the header comment)
+                if (ci + 1 >= n_chunks) broken = true;          // (cannot happen: see the header comment -- and below)
+                ci = ci + 1 < n_chunks ? ci + 1 : ci;
                 if ((ci & 63) == 0) list_reg = ci + lane < n_chunks ? list[ci + lane] : 0;
                 cbase = lzw::lane_bcast(list_reg, ci & 63) * CH;
                 off = 0;
@@ -572,6 +574,17 @@ __global__ __launch_bounds__(kBlock) void tree_advance_kernel(Tree t, const int*
     }
     __threadfence_block();
     if (ticks != nullptr && lane == 0) ticks[(size_t)g * 8 + 2] = (long long)wall_clock64();
+    if (broken) {
+        // The in-place packing is only safe while a run's new place is never behind its old one, which holds as long as
+        // every run was laid out by the same greedy rule (header comment).  Should a future change of the allocation rule
+        // break that, the kept subtree is DROPPED and counted instead of being packed over live records
+        release_chunks_wave(t, g, 0, lane);
+        if (lane == 0) {
+            if (dropped != nullptr) atomicAdd(dropped, 1);
+            begin_game(t, g, /*release=*/false);
+        }
+        return;
+    }
     // ---- pass 3: edge runs, FLAT over the kept edges of 64 nodes at a time.  The kernel's time is its slowest wave's --
     // a game that keeps well over a thousand nodes (a run of forced moves keeps the whole tree) -- and that wave is bound
     // by memory round trips, not by bytes: so a round moves kFlat x 64 records (about 48 nodes' runs) with ALL their loads

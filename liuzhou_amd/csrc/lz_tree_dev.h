@@ -63,7 +63,8 @@ struct Tree {
     Node* nodes; Edge* edges;
     int* n_nodes; int* n_edges;      // n_edges[g]: next free pool index of the game's open chunk (multiple of chunk: none)
     int* chunk_list; int* n_chunks; int* free_chunks; int* pool_top;
-    int* pool_stats;                 // [0] expansions refused because the pool was empty, [1] fewest free chunks seen
+    int* pool_stats;                 // [0] expansions refused because the pool was empty, [1] fewest free chunks seen,
+                                     // [2] fresh roots that have not taken the chunk of their first expansion yet
     int* root_visits; double* root_W; float* root_init_value;
     int* path; int* path_len; int* leaf_kind; Packed* leaf_state; float* leaf_value;
     uint8_t* root_terminal; const uint8_t* active;
@@ -132,12 +133,18 @@ __device__ __forceinline__ void release_chunks_wave(const Tree& t, int g, int ke
         if (lane == 0) t.n_chunks[g] = keep;
     }
 }
-// one thread takes a chunk from the pool for game g: its first pool index, or -1 (pool empty / list full; counted)
-__device__ __forceinline__ int take_chunk(const Tree& t, int g) {
+// one thread takes a chunk from the pool for game g: its first pool index, or -1 (pool empty / list full; counted).
+// A chunk stays reserved for every fresh root that has not expanded yet (pool_stats[2]; begin kernels count them up, the
+// root's own take counts down): games progress independently, and a root whose expansion found the pool drained by the
+// other games' deeper nodes would stay unexpanded for the whole search and end with an all-zero policy.
+// Inside an expand launch the count only falls, so a stale read is conservative.
+__device__ __forceinline__ int take_chunk(const Tree& t, int g, bool for_root = false) {
     const int nc = t.n_chunks[g];
     if (nc >= t.chunk_cap) { atomicAdd(t.pool_stats, 1); return -1; }
-    const int top = atomicSub(t.pool_top, 1) - 1;
-    if (top < 0) { atomicAdd(t.pool_top, 1); atomicAdd(t.pool_stats, 1); return -1; }
+    const int top = atomicSub(t.pool_top, 1) - 1;            // free chunks left after this take
+    const int reserved = for_root ? 0 : __atomic_load_n(t.pool_stats + 2, __ATOMIC_RELAXED);
+    if (top < reserved) { atomicAdd(t.pool_top, 1); atomicAdd(t.pool_stats, 1); return -1; }
+    if (for_root) atomicSub(t.pool_stats + 2, 1);
     atomicMin(t.pool_stats + 1, top);
     const int cid = t.free_chunks[top];
     t.chunk_list[(size_t)g * t.chunk_cap + nc] = cid;
@@ -164,6 +171,7 @@ __device__ __forceinline__ void begin_game(const Tree& t, int g, bool release = 
     const bool term = game_status(s) != 0;                // portable_mcts.py:601-603
     t.root_terminal[g] = (term || !act) ? 1 : 0;
     t.leaf_kind[g] = (term || !act) ? kLeafInactive : kLeafExpand;
+    if (!(term || !act)) atomicAdd(t.pool_stats + 2, 1);   // this root will need the chunk of its first expansion
     t.leaf_state[g] = rs;                                  // the root is the first pending evaluation
     t.leaf_value[g] = 0.f;
 }
@@ -475,7 +483,7 @@ __device__ __forceinline__ void tree_expand(const Tree& t, int g, int lane, cons
             if (lane == 0) {
                 e0 = ne_ld;
                 const int off = e0 & (t.chunk - 1);
-                if (off == 0 || off + n > t.chunk) e0 = take_chunk(t, g);
+                if (off == 0 || off + n > t.chunk) e0 = take_chunk(t, g, IS_ROOT);
                 if (e0 >= 0) {
                     t.n_edges[g] = e0 + n;
                     if (IS_ROOT) node_id = 0;
@@ -591,6 +599,7 @@ bool tree_ok(const LzTreeDesc* d) {
     return d && d->num_games >= 0 && d->node_cap >= 2 && d->path_cap >= 3 &&
            d->edge_chunk >= 128 && (d->edge_chunk & (d->edge_chunk - 1)) == 0 && d->chunk_cap >= 1 &&
            d->pool_chunks >= 1 && (d->pool_chunks + 1) * (int64_t)d->edge_chunk <= (int64_t)1 << 31 &&
+           d->pool_chunks >= d->num_games &&                      // a chunk for every root (see take_chunk)
            d->chunk_list && d->n_chunks && d->free_chunks && d->pool_top && d->pool_stats &&
            d->root_state && d->nodes && d->edges && d->n_nodes && d->n_edges &&
            d->root_visits && d->root_w && d->root_init_value && d->path && d->path_len && d->leaf_kind &&

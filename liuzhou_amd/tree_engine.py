@@ -158,7 +158,8 @@ class TreeEngine:
             "free_chunks": torch.arange(self.pool_chunks, dtype=torch.int32, device=dev),
             "pool_top": torch.full((1,), self.pool_chunks, dtype=torch.int32, device=dev),
             # [0] expansions refused because the pool was empty (0 in a correctly sized engine), [1] fewest free chunks seen
-            "pool_stats": torch.tensor([0, self.pool_chunks], dtype=torch.int32, device=dev),
+            # + [2] fresh roots that still have to take the chunk of their first expansion (reserved for them)
+            "pool_stats": torch.tensor([0, self.pool_chunks, 0], dtype=torch.int32, device=dev),
         }
         d = LzTreeDesc()
         d.num_games, d.node_cap, d.edge_chunk, d.path_cap = B, self.node_cap, self.edge_chunk, self.path_cap
@@ -268,7 +269,7 @@ class TreeEngine:
 
     def pool_status(self) -> Dict[str, int]:
         """Edge pool: chunks, free now, fewest free seen since construction, refused expansions (must stay 0)."""
-        refused, low = (int(v) for v in self.buf["pool_stats"].tolist())
+        refused, low = (int(v) for v in self.buf["pool_stats"][:2].tolist())
         return {"chunks": self.pool_chunks, "chunk_edges": self.edge_chunk, "free": int(self.buf["pool_top"].item()),
                 "fewest_free": low, "refused_expansions": refused,
                 "bytes": self.pool_chunks * self.edge_chunk * 32}
@@ -706,7 +707,7 @@ class PortableTreeMCTS:
         self.engine.live_total.zero_()
         self.engine.reuse_dropped.zero_()
         # refused expansions / fewest free chunks are per run too (a cached engine must not report an earlier run's)
-        self.engine.buf["pool_stats"].copy_(torch.tensor([0, self.engine.pool_chunks], dtype=torch.int32))
+        self.engine.buf["pool_stats"].copy_(torch.tensor([0, self.engine.pool_chunks, 0], dtype=torch.int32))
         self.get_timing(reset=True)
         if self.batch_k > 1:
             self.engine.wbuf["eval_total"].zero_(); self.engine.wbuf["eval_count"].zero_()

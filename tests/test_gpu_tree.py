@@ -507,6 +507,38 @@ def test_edge_pool_exhaustion_is_counted_not_a_fault():
     assert eng.pool_status()["free"] == eng.pool_chunks
 
 
+def test_a_chunk_is_reserved_for_every_fresh_root():
+    """The smallest pool the ABI accepts (one chunk per game): every root still expands -- a chunk stays reserved for each
+    fresh root until its first expansion (pool_stats[2]), so deeper expansions of other games cannot drain the pool under
+    a root, which would otherwise end its search with an all-zero policy -- and a pool smaller than the batch is refused."""
+    _need_gpu()
+    from liuzhou_amd.tree_engine import TreeEngine
+    from liuzhou_amd import _lib as L
+    from tests.tree_parity import hash_evaluator, unpack_packed
+    from oracle import lz_oracle as O
+    import ctypes as C
+    B, sims = 16, 20
+    eng = TreeEngine(B, sims, DEV, 1.0, edge_chunk=128, pool_chunks=B)
+    eng.set_roots(to_gpu_batch(O.initial_states(B), DEV))
+    eng.begin()
+    assert int(eng.buf["pool_stats"][2]) == B                    # B live roots are waiting for their chunk
+    for s in range(sims + 1):
+        if s:
+            eng.select()
+        leaf = unpack_packed(eng.buf["leaf_state"].cpu().numpy())
+        pri, val = hash_evaluator(leaf)
+        eng.expand(is_root=(s == 0), values=torch.from_numpy(val).to(DEV), priors220=torch.from_numpy(pri).to(DEV))
+        if s == 0:
+            assert int(eng.buf["pool_stats"][2]) == 0 and int(eng.buf["pool_top"]) == 0
+    eng.finish(torch.ones(B, device=DEV), None, sample_moves=False)
+    assert (eng.child_count.cpu().numpy() == 36).all() and bool(eng.chosen_valid.all())
+    assert torch.allclose(eng.policy_dense.sum(1), torch.ones(B, device=DEV), atol=1e-5)
+    assert eng.pool_status()["refused_expansions"] > 0
+    small = TreeEngine(B, sims, DEV, 1.0, edge_chunk=128, pool_chunks=B - 1)
+    with torch.cuda.device(DEV):
+        assert L.lib().lz_tree_begin(C.byref(small.desc), L.stream_ptr(torch.device(DEV))) == -1      # LZ_ERR_ARG
+
+
 @pytest.mark.parametrize("batch_k,sims", [(16, 50), (4, 30), (16, 200)])
 def test_gpu_wave_batched_search_matches_oracle(batch_k, sims):
     """The legacy search's waves (src/mcts.py `batch_K` leaves per tree and wave, no virtual loss; oracle pinned by
