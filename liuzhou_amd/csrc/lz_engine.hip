@@ -100,19 +100,38 @@ __global__ __launch_bounds__(kBlock) void tree_expand_kernel(Tree t, const float
                          noise_stride, epsilon, sc, nullptr, step);
 }
 
-// the roots that need an evaluation (fresh trees: all live games; after lz_tree_advance: the games that did not keep a
-// subtree) -> the compact list of simulation 0
-__global__ __launch_bounds__(kBlock) void tree_live_roots_kernel(Tree t) {
-    const int g = blockIdx.x * kBlock + threadIdx.x;
-    if (g >= t.B) return;
-    if (t.leaf_kind[g] != kLeafExpand) return;
-    const int row = (int)atomicAdd(t.live_count, 1ull);
-    t.live_state[row] = t.leaf_state[g];
-    t.live_row[g] = row;
-}
-__global__ __launch_bounds__(kBlock) void zero_counts_kernel(unsigned long long* p, int n) {
-    const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i < n) p[i] = 0ull;
+// The leaves that need the network (leaf_kind == kLeafExpand: fresh roots, leaves to expand -- not terminal leaves, kept
+// roots, finished games) -> the compact list of the next network launch, in game order: live_row[g] = rank of g among
+// them, live_state[rank] = leaf_state[g], *count = how many.  ONE workgroup, ordered scan (as wave_rows_kernel of
+// lz_ops.hip): ~6 us for 16 384 games.  (A first version let every select wave append with one atomicAdd on a shared
+// counter: 16 384 same-address atomics serialise at ~9.5 ns each -- the tree kernel went from 63 to 219 us per simulation at
+// C3, profiles/r05_experiments.md section 2.)
+constexpr int kScanBlock = 1024;
+__global__ __launch_bounds__(kScanBlock) void tree_live_scan_kernel(Tree t, unsigned long long* __restrict__ count) {
+    __shared__ int wave_total[kScanBlock / kWave];
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), w = tid / kWave;
+    const int per = (t.B + kScanBlock - 1) / kScanBlock;
+    const int lo = tid * per, hi = (lo + per < t.B) ? lo + per : t.B;
+    int cnt = 0;
+    for (int g = lo; g < hi; ++g) cnt += t.leaf_kind[g] == kLeafExpand ? 1 : 0;
+    int incl = cnt;
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+        const int v = __shfl_up(incl, d, kWave);
+        if (lane >= d) incl += v;
+    }
+    if (lane == kWave - 1) wave_total[w] = incl;
+    __syncthreads();
+    int before = 0, total = 0;
+    for (int i = 0; i < kScanBlock / kWave; ++i) { if (i < w) before += wave_total[i]; total += wave_total[i]; }
+    int row = before + incl - cnt;
+    for (int g = lo; g < hi; ++g) {
+        if (t.leaf_kind[g] != kLeafExpand) continue;
+        t.live_row[g] = row;
+        t.live_state[row] = t.leaf_state[g];
+        ++row;
+    }
+    if (tid == 0) *count = (unsigned long long)total;
 }
 
 // expand + backup of simulation s fused with the selection of simulation s+1 (same wave, same game: the edge
@@ -142,7 +161,7 @@ __global__ __launch_bounds__(kBlock) void tree_expand_select_kernel(Tree t, cons
                          epsilon, sc, &root, step);
     __threadfence_block();
     if (IS_ROOT) root = load_root_info(t, g);                  // the root record itself was just written
-    tree_select(t, g, lane, root, COMPACT ? t.live_count + (step + 1) : nullptr);     // the leaves of simulation step + 1
+    tree_select(t, g, lane, root);
 }
 
 // ---- wave-batched leaves: the legacy search of src/mcts.py (batch_K leaves per tree and wave, no virtual loss) ------
@@ -1122,9 +1141,7 @@ static int tree_search_impl(const LzTreeDesc* d, const LzNetDesc* net, int64_t s
     if (t.live_count != nullptr) {
         // compact evaluation lists: simulation s evaluates live_count[s] leaves (see LzTreeDesc.live_*)
         if (d->live_count_cap < sims + 2) return LZ_ERR_ARG;
-        hipLaunchKernelGGL(zero_counts_kernel, dim3(gt(sims + 2)), dim3(kBlock), 0, as_stream(stream), t.live_count,
-                           (int)(sims + 2));
-        hipLaunchKernelGGL(tree_live_roots_kernel, dim3(gt(t.B)), dim3(kBlock), 0, as_stream(stream), t);
+        hipLaunchKernelGGL(tree_live_scan_kernel, dim3(1), dim3(kScanBlock), 0, as_stream(stream), t, t.live_count);   // the roots
         for (int64_t s = 0; s <= sims; ++s) {
             rc = lz_net_forward_packed_counted_f16(net, d->live_state, B, d->live_count + s, lp1, lp2, lpmc, nullptr, values,
                                                    stream);
@@ -1145,6 +1162,9 @@ static int tree_search_impl(const LzTreeDesc* d, const LzNetDesc* net, int64_t s
                                    t, lp1, lp2, lpmc, values, nullptr, 0, 0.f, (int)s);
                 (void)lz_prof_aux_end(0, stream, B);
             }
+            if (s < sims)                                           // the leaves of simulation s + 1
+                hipLaunchKernelGGL(tree_live_scan_kernel, dim3(1), dim3(kScanBlock), 0, as_stream(stream), t,
+                                   t.live_count + (s + 1));
         }
         return st();
     }

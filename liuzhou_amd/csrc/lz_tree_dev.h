@@ -74,8 +74,9 @@ struct Tree {
     int* trace_kind; Packed* trace_leaf; float* trace_heads; float* trace_priors; float* trace_value;
     int trace_cap;
     int* eval_count;      // optional per-game count of consumed evaluations
-    // optional compact evaluation list (LzTreeDesc.live_*): the leaves that need the network, appended by select, so that
-    // a network launch runs ceil(live / samples-per-pass) passes instead of one per slot of the batch
+    // optional compact evaluation list (LzTreeDesc.live_*): the leaves that need the network, gathered after every select
+    // step by an ordered one-workgroup scan (tree_live_scan_kernel), so that a network launch runs
+    // ceil(live / samples-per-pass) passes instead of one per slot of the batch
     Packed* live_state; int* live_row; unsigned long long* live_count;
 };
 
@@ -191,11 +192,7 @@ __device__ __forceinline__ RootInfo load_root_info(const Tree& t, int g) {
     return r;
 }
 
-// `live_counter` (optional): the leaf that needs an evaluation is also appended to the compact list t.live_state at
-// atomicAdd(live_counter, 1); its row goes to t.live_row[g].  The append order is arbitrary (an atomic), a game's
-// results do not depend on it: a sample's network outputs do not depend on its position in the batch.
-__device__ __forceinline__ void tree_select(const Tree& t, int g, int lane, const RootInfo& root,
-                                            unsigned long long* live_counter = nullptr) {
+__device__ __forceinline__ void tree_select(const Tree& t, int g, int lane, const RootInfo& root) {
     if (t.root_terminal[g]) { if (lane == 0) t.leaf_kind[g] = kLeafInactive; return; }
     const Node* nodes = t.nodes + (size_t)g * t.node_cap;
     const Edge* edges = t.edges;                               // pool indices
@@ -282,13 +279,7 @@ __device__ __forceinline__ void tree_select(const Tree& t, int g, int lane, cons
             int kd, p, q2, ex;
             index_to_code(leaf.phase, leaf_action, kd, p, q2, ex);
             apply_legal(leaf, kd, p, q2);                   // an action this engine enumerated: no re-validation
-            const Packed lp = pack(leaf);
-            t.leaf_state[g] = lp;
-            if (live_counter != nullptr) {
-                const int row = (int)atomicAdd(live_counter, 1ull);
-                t.live_state[row] = lp;
-                t.live_row[g] = row;
-            }
+            t.leaf_state[g] = pack(leaf);
         }
     }
 }

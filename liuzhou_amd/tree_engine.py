@@ -387,9 +387,11 @@ class TreeEngine:
                                             self._stream()), "tree_advance")
 
     def search(self, net: FusedNet, sims: int, noise: Optional[torch.Tensor] = None, epsilon: float = 0.25,
-               continue_trees: bool = False) -> None:
+               continue_trees: bool = False, compact: Optional[bool] = None) -> None:
         """Whole search of one move (C++ loop: begin, root, sims x select/eval/expand); `continue_trees`: the
-        trees were prepared by advance() (kept subtrees / fresh roots), no begin."""
+        trees were prepared by advance() (kept subtrees / fresh roots), no begin.  `compact` (engines built with
+        `compact_evals`): False launches every slot of every simulation (cheaper while nearly all games are live: no scan
+        kernel per simulation), True / None the compact lists; results are bit-identical either way."""
         if int(sims) > self.max_sims:
             raise ValueError(f"sims={sims} exceeds the arena capacity max_sims={self.max_sims}")
         if self.batch_k > 1:
@@ -415,13 +417,23 @@ class TreeEngine:
                 L.check(rc, "tree_search_persistent")
                 return
         fn = L.lib().lz_tree_search_continue if continue_trees else L.lib().lz_tree_search
+        use_lists = self.compact_evals and (compact is None or bool(compact))
+        desc = self.desc
+        if self.compact_evals and not use_lists:                    # the same engine, dense launches for this move
+            desc = LzTreeDesc()
+            C.memmove(C.byref(desc), C.byref(self.desc), C.sizeof(LzTreeDesc))
+            desc.live_state = desc.live_row = desc.live_count = None
+            desc.live_count_cap = 0
         with torch.cuda.device(self.device):
-            L.check(fn(C.byref(self.desc), C.byref(net.desc), L.i64(sims), L.ptr(self.planes),
+            L.check(fn(C.byref(desc), C.byref(net.desc), L.i64(sims), L.ptr(self.planes),
                        L.ptr(self.lp1), L.ptr(self.lp2), L.ptr(self.lpm), L.ptr(self.values),
                        L.ptr(noise), L.i64(nz_stride), C.c_float(float(epsilon)), self._stream()),
                     "tree_search")
-        if self.compact_evals:                                      # evaluations launched = the leaves the lists held
-            self.live_total.add_(self.live["live_count"][: int(sims) + 1].sum())
+        if self.compact_evals:                                      # evaluations launched: the leaves the lists held / every slot
+            if use_lists:
+                self.live_total.add_(self.live["live_count"][: int(sims) + 1].sum())
+            else:
+                self.live_total.add_(self.B * (int(sims) + 1))
 
     def persistent_ok(self, net: FusedNet) -> bool:
         """Whether search() runs the one-launch-per-move kernel: 64-channel net in fp16 mode, not switched off
@@ -482,8 +494,9 @@ class PortableTreeMCTS:
                  game_offset: int = 0, game_stride: Optional[int] = None, trace: bool = False,
                  collect_timing: bool = False, compact_evals: Optional[bool] = None) -> None:
         """`compact_evals` (fused network only): per simulation only the leaves that need the network are evaluated
-        (`TreeEngine(compact_evals=True)`); None = when a launch of all slots is at least two network passes per CU (C3:
-        eight), i.e. when fewer live leaves make a launch shorter -- env LZ_TREE_COMPACT=0 / 1 overrides.
+        (`TreeEngine(compact_evals=True)`); True = in every search; None = the engine is built for both forms when a launch
+        of all slots is at least two network passes per CU (C3: eight) and uses the lists for the searches that say so
+        (`search_batch(compact=True)`, the runner's hint that the wave is draining) -- env LZ_TREE_COMPACT=0 / 1 overrides.
         `net`: a FusedNet (the production path: the whole search of a move is enqueued from C++ with the fused network
         kernel in the loop, one hipGraph per move), or any module returning `ChessNet.forward`'s 4-tuple -- then the search
         runs the split-phase protocol (select -> planes -> module -> expand) with that module as an external fp32
@@ -502,6 +515,10 @@ class PortableTreeMCTS:
         env_c = os.environ.get("LZ_TREE_COMPACT", "").strip()
         if env_c in ("0", "1"):
             compact_evals = env_c == "1"
+        # asked for explicitly: every search uses the lists.  Chosen automatically: the engine can do both and launches
+        # every slot unless a search is told otherwise (`compact=` of search_batch: the runner's hint that the wave is
+        # draining) -- while nearly all games are live the lists shorten nothing and cost a scan kernel per simulation
+        self.compact_default = compact_evals is True
         if compact_evals is None:
             compact_evals = self.fused and int(num_games) >= 2 * samples_per_launch_pass(net)
         self.engine = TreeEngine(num_games, num_simulations, device, exploration_weight,
@@ -609,10 +626,11 @@ class PortableTreeMCTS:
         if not self.fused:
             self._search_split(noise, continue_trees)
             return
+        lists = bool(getattr(self, "compact_now", self.compact_default)) and e.compact_evals
         if not self.use_graph:
-            e.search(self.net, self.sims, noise, self.eps, continue_trees)
+            e.search(self.net, self.sims, noise, self.eps, continue_trees, compact=lists)
             return
-        key = (add_noise, continue_trees)
+        key = (add_noise, continue_trees, lists)
         g = self._graphs.get(key)
         if g is None:
             if not continue_trees:
@@ -621,12 +639,17 @@ class PortableTreeMCTS:
                 # fresh search starts by resetting the trees, so what the warm-up leaves behind does not matter -- a full
                 # search here cost 1.6 s per engine at C3.  A continued search must run exactly once and is only reached
                 # after a fresh one
-                e.search(self.net, min(self.sims, 2), noise, self.eps, False)
+                # (an engine with compact lists warms up both launch forms: the other one may be captured later inside a
+                #  continued search, which cannot be preceded by a warm-up of its own)
+                counted = (e.live_total.clone(), e.eval_count.clone())     # warm-ups are not searches: not counted
+                for form in ((lists, not lists) if e.compact_evals else (lists,)):
+                    e.search(self.net, min(self.sims, 2), noise, self.eps, False, compact=form)
+                e.live_total.copy_(counted[0]); e.eval_count.copy_(counted[1])
             torch.cuda.synchronize(e.device)
             try:
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
-                    e.search(self.net, self.sims, noise, self.eps, continue_trees)
+                    e.search(self.net, self.sims, noise, self.eps, continue_trees, compact=lists)
                 if os.environ.get("LZ_TREE_GRAPH_FAULT", "") == "capture":      # test hook: pretend the capture failed
                     raise RuntimeError("injected stream capture failure (LZ_TREE_GRAPH_FAULT=capture)")
             except RuntimeError as exc:
@@ -639,7 +662,7 @@ class PortableTreeMCTS:
                 self._graphs.clear()
                 print(f"[liuzhou_amd] hipGraph capture of the tree search failed ({exc!r}); falling back to direct launches",
                       flush=True)
-                e.search(self.net, self.sims, noise, self.eps, continue_trees)
+                e.search(self.net, self.sims, noise, self.eps, continue_trees, compact=lists)
                 return
             self._graphs[key] = g
         g.replay()
@@ -735,24 +758,28 @@ class PortableTreeMCTS:
                      played_action: Optional[torch.Tensor] = None,
                      force_uniform_random_mask: Optional[torch.Tensor] = None,
                      rng_game_ids: Optional[torch.Tensor] = None,
-                     rng_plies: Optional[torch.Tensor] = None) -> RootSearchBatchOutput:
-        """`state`: the games' current positions.  With `reuse_tree`, games whose position is the child reached by
+                     rng_plies: Optional[torch.Tensor] = None, compact: Optional[bool] = None) -> RootSearchBatchOutput:
+        """`compact`: see `launch_search`.
+        `state`: the games' current positions.  With `reuse_tree`, games whose position is the child reached by
         `played_action` (default: the move this engine picked last time) keep that child's subtree; `reset` marks
         games that were re-seated.  Anything that does not match simply starts a fresh tree.  `rng_game_ids` /
         `rng_plies` int64[B]: the runner's own game numbering and ply counters as RNG keys (default: slot-derived ids
         that advance on `reset`, plies counted per search)."""
         self.launch_search(state, active=active, add_dirichlet_noise=add_dirichlet_noise, reset=reset,
-                           played_action=played_action, rng_game_ids=rng_game_ids, rng_plies=rng_plies)
+                           played_action=played_action, rng_game_ids=rng_game_ids, rng_plies=rng_plies, compact=compact)
         return self.complete_search(state, temperatures=temperatures,
                                     force_uniform_random_mask=force_uniform_random_mask)
 
     def launch_search(self, state: GpuStateBatch, *, active: Optional[torch.Tensor] = None,
                       add_dirichlet_noise: Optional[bool] = None, reset: Optional[torch.Tensor] = None,
                       played_action: Optional[torch.Tensor] = None, rng_game_ids: Optional[torch.Tensor] = None,
-                      rng_plies: Optional[torch.Tensor] = None) -> None:
+                      rng_plies: Optional[torch.Tensor] = None, compact: Optional[bool] = None) -> None:
         """First half of search_batch: everything up to the end of the captured search, nothing that waits for the
         device (so that several engines on several streams can be launched back to back)."""
         e = self.engine
+        # compact lists or dense launches for this move (engines built with compact_evals; the runner passes a hint from
+        # the number of live games: the lists pay once a launch gets at least one network pass per CU shorter)
+        self.compact_now = self.compact_default if compact is None else bool(compact)
         add_noise = self.add_noise if add_dirichlet_noise is None else bool(add_dirichlet_noise)
         e.set_roots(state, active)
         continue_trees = self.reuse_tree and self._have_trees
@@ -892,7 +919,7 @@ class DualStreamTreeMCTS:
                      played_action: Optional[torch.Tensor] = None,
                      force_uniform_random_mask: Optional[torch.Tensor] = None,
                      rng_game_ids: Optional[torch.Tensor] = None,
-                     rng_plies: Optional[torch.Tensor] = None) -> RootSearchBatchOutput:
+                     rng_plies: Optional[torch.Tensor] = None, compact: Optional[bool] = None) -> RootSearchBatchOutput:
         main = torch.cuda.current_stream(self.device)
         cut = lambda t, a, b: None if t is None else t[a:b]
         outs = []
@@ -903,7 +930,7 @@ class DualStreamTreeMCTS:
             with torch.cuda.stream(st):
                 part.launch_search(sub, active=cut(active, a, b), add_dirichlet_noise=add_dirichlet_noise,
                                    reset=cut(reset, a, b), played_action=cut(played_action, a, b),
-                                   rng_game_ids=cut(rng_game_ids, a, b), rng_plies=cut(rng_plies, a, b))
+                                   rng_game_ids=cut(rng_game_ids, a, b), rng_plies=cut(rng_plies, a, b), compact=compact)
         todo = list(zip(self.parts, streams))                  # leftover rounds (batch_k > 1): the parts take turns,
         while todo:                                            # so that their small rounds overlap on the device
             nxt = []
@@ -1109,10 +1136,14 @@ def self_play_tree_gpu(model, num_games: int, mcts_simulations: int, temperature
         slot_ids = torch.arange(wave, dtype=torch.int64, device=dev)
         if tail is not None:
             force_n = int(opening_random_moves)
+            # compact evaluation lists once the wave has drained by at least one network pass per CU (the engine was built
+            # for both launch forms if that can happen at all; two plies of lag in the estimate only delay the switch)
+            lists_below = wave - (samples_per_launch_pass(net) if use_fused else 0)
             tail.run(lambda st, temps, dn, reseated: mcts.search_batch(
                          st, temperatures=temps, active=~dn, reset=reseated,
                          force_uniform_random_mask=(plies < force_n) if force_n > 0 else None,
-                         rng_game_ids=tail.slot_game + (0 if continuous else base), rng_plies=plies),
+                         rng_game_ids=tail.slot_game + (0 if continuous else base), rng_plies=plies,
+                         **({"compact": True} if (use_fused and tail.live_estimate <= lists_below) else {})),
                      states, plies, done, step_index, step_counts, lengths if continuous else lengths[base:base + g],
                      temperature_init, temperature_final, temperature_threshold,
                      games_to_start=int(num_games) - wave if continuous else 0)

@@ -36,6 +36,7 @@ class WaveTail:
         self.slot_game = torch.arange(self.G, dtype=torch.int64, device=dev)   # game number played in each slot (run())
         self.collect_timing = False
         self._timing_events = []
+        self.live_estimate = self.G                          # run(): live slots two plies ago (host-visible without a wait)
         self.host_wait_ms = self.loop_ms = 0.0              # run(): time the host spent waiting for the device / in the loop
         self.plies_launched = 0
         # finished_log.FinishedRowLog: the live rows are slot-major (row = slot * max_plies + step, no step_index matrix)
@@ -143,6 +144,8 @@ class WaveTail:
         if (log is None) == (step_index is None):
             raise ValueError("WaveTail.run: pass a step_index matrix, or build the tail with a finished-row log")
         flags = [torch.zeros((1,), dtype=torch.bool).pin_memory() for _ in range(2)]
+        live = [torch.full((1,), g, dtype=torch.int64).pin_memory() for _ in range(2)]     # live slots, as of two plies ago
+        self.live_estimate = g
         events = [torch.cuda.Event() for _ in range(2)]
         budget = torch.full((1,), int(games_to_start), dtype=torch.int64, device=dev)
         next_game = torch.full((1,), g, dtype=torch.int64, device=dev)
@@ -159,6 +162,7 @@ class WaveTail:
                 self.host_wait_ms += (time.perf_counter() - t_w) * 1e3      # ~0 for a whole run: the HOST is the bottleneck
                 if bool(flags[k].item()):
                     break
+                self.live_estimate = int(live[k].item())          # a search may size its launches by it (compact lists)
                 if log is not None:
                     log.poll(k)                                   # may switch log arenas (a segment leaves)
             if games_to_start > 0 and ply > 0:
@@ -178,6 +182,7 @@ class WaveTail:
                 flags[k].copy_((done.all() & (budget <= 0).all() & (log.waiting() == 0)).view(1), non_blocking=True)
             else:
                 flags[k].copy_((done.all() & (budget <= 0).all()).view(1), non_blocking=True)
+            live[k].copy_((~done).sum().view(1), non_blocking=True)
             events[k].record(torch.cuda.current_stream(dev))
             ply += 1
         self.loop_ms += (time.perf_counter() - t_run) * 1e3
