@@ -101,19 +101,31 @@ __global__ __launch_bounds__(kBlock) void tree_expand_kernel(Tree t, const float
 }
 
 // The leaves that need the network (leaf_kind == kLeafExpand: fresh roots, leaves to expand -- not terminal leaves, kept
-// roots, finished games) -> the compact list of the next network launch, in game order: live_row[g] = rank of g among
-// them, live_state[rank] = leaf_state[g], *count = how many.  ONE workgroup, ordered scan (as wave_rows_kernel of
-// lz_ops.hip): ~6 us for 16 384 games.  (A first version let every select wave append with one atomicAdd on a shared
+// roots, finished games) -> the compact list of the next network launch: live_row[g] = row of game g's leaf,
+// live_state[row] = leaf_state[g], *count = how many.  ONE workgroup, one scan over per-thread counts.  (A first version let every select wave append with one atomicAdd on a shared
 // counter: 16 384 same-address atomics serialise at ~9.5 ns each -- the tree kernel went from 63 to 219 us per simulation at
 // C3, profiles/r05_experiments.md section 2.)
 constexpr int kScanBlock = 1024;
+constexpr int kScanUnroll = 8;
+// Thread t looks at games t, t + 1024, t + 2048, ... (coalesced rounds; every load of a group of 8 rounds is in flight
+// before the first is used -- a first version that gave each thread 16 CONSECUTIVE games and walked them one dependent
+// load after the other took 54 us at 16 384 games) and its live leaves get consecutive rows behind those of the threads
+// below it: the order of the list is a fixed function of the flags (deterministic), which is all a game's results need.
 __global__ __launch_bounds__(kScanBlock) void tree_live_scan_kernel(Tree t, unsigned long long* __restrict__ count) {
     __shared__ int wave_total[kScanBlock / kWave];
     const int tid = threadIdx.x, lane = tid & (kWave - 1), w = tid / kWave;
-    const int per = (t.B + kScanBlock - 1) / kScanBlock;
-    const int lo = tid * per, hi = (lo + per < t.B) ? lo + per : t.B;
+    const int rounds = (t.B + kScanBlock - 1) / kScanBlock;
     int cnt = 0;
-    for (int g = lo; g < hi; ++g) cnt += t.leaf_kind[g] == kLeafExpand ? 1 : 0;
+    for (int r0 = 0; r0 < rounds; r0 += kScanUnroll) {
+        int kind[kScanUnroll];
+#pragma unroll
+        for (int u = 0; u < kScanUnroll; ++u) {
+            const int g = (r0 + u) * kScanBlock + tid;
+            kind[u] = (r0 + u < rounds && g < t.B) ? t.leaf_kind[g] : kLeafInactive;
+        }
+#pragma unroll
+        for (int u = 0; u < kScanUnroll; ++u) cnt += kind[u] == kLeafExpand ? 1 : 0;
+    }
     int incl = cnt;
 #pragma unroll
     for (int d = 1; d < kWave; d <<= 1) {
@@ -125,11 +137,24 @@ __global__ __launch_bounds__(kScanBlock) void tree_live_scan_kernel(Tree t, unsi
     int before = 0, total = 0;
     for (int i = 0; i < kScanBlock / kWave; ++i) { if (i < w) before += wave_total[i]; total += wave_total[i]; }
     int row = before + incl - cnt;
-    for (int g = lo; g < hi; ++g) {
-        if (t.leaf_kind[g] != kLeafExpand) continue;
-        t.live_row[g] = row;
-        t.live_state[row] = t.leaf_state[g];
-        ++row;
+    for (int r0 = 0; r0 < rounds; r0 += kScanUnroll) {
+        int kind[kScanUnroll];
+        Packed st[kScanUnroll];
+#pragma unroll
+        for (int u = 0; u < kScanUnroll; ++u) {
+            const int g = (r0 + u) * kScanBlock + tid;
+            const bool in = r0 + u < rounds && g < t.B;
+            kind[u] = in ? t.leaf_kind[g] : kLeafInactive;          // second read: L2 hits
+            if (in) st[u] = load_state(&t.leaf_state[g]);          // speculative: most leaves are live
+        }
+#pragma unroll
+        for (int u = 0; u < kScanUnroll; ++u) {
+            if (kind[u] != kLeafExpand) continue;
+            const int g = (r0 + u) * kScanBlock + tid;
+            t.live_row[g] = row;
+            t.live_state[row] = st[u];
+            ++row;
+        }
     }
     if (tid == 0) *count = (unsigned long long)total;
 }

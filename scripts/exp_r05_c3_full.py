@@ -9,7 +9,12 @@ from liuzhou_amd.net_hip import FusedNet
 from liuzhou_amd.tree_engine import clear_engine_cache, self_play_tree_gpu
 
 def run(compact, games=16384, sims=800, model="b10c128", plies=512):
-    os.environ["LZ_TREE_COMPACT"] = "1" if compact else "0"
+    """compact: True = lists in every search, False = dense launches only, None = the product default (dense while nearly
+    all games are live, lists once the wave has drained by a network pass per CU)."""
+    if compact is None:
+        os.environ.pop("LZ_TREE_COMPACT", None)
+    else:
+        os.environ["LZ_TREE_COMPACT"] = "1" if compact else "0"
     dev = torch.device("cuda:0")
     torch.manual_seed(20260314)
     net = FusedNet(ChessNet(**MODEL_CONFIGS[model]).eval().to(dev))
@@ -27,7 +32,7 @@ def run(compact, games=16384, sims=800, model="b10c128", plies=512):
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     stop = True
     mc = st.mcts_counters
-    print(json.dumps({"run": "self_play_tree_gpu full length", "compact_eval_lists": bool(compact), "games": games, "sims": sims,
+    print(json.dumps({"run": "self_play_tree_gpu full length", "compact_eval_lists": "auto" if compact is None else bool(compact), "games": games, "sims": sims,
                       "net": model, "positions": int(batch.num_samples), "elapsed_s": round(dt, 2),
                       "positions_per_s": round(batch.num_samples / dt, 1), "avg_game_length": round(st.avg_game_length, 2),
                       "plies_launched": mc.get("plies_launched"), "leaf_evals": mc.get("leaf_eval_count"),
@@ -42,6 +47,8 @@ if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "compact"
     games = int(sys.argv[2]) if len(sys.argv) > 2 else 16384
     sims = int(sys.argv[3]) if len(sys.argv) > 3 else 800
+    if which == "auto":
+        run(None, games, sims)
     if which in ("compact", "both"):
         run(True, games, sims)
     if which in ("dense", "both"):
