@@ -12,7 +12,8 @@ import json
 import os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = "r04"
+import sys
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"        # `summarize_profiles_r04.py r05`: the same tables for round 5
 src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
 out = os.path.join(ROOT, "profiles")
 
@@ -32,7 +33,7 @@ def bench_table(sub, title, launches_per_step):
     kp = bj["roofline"].get("kernel_probe", {})
     ck = bj.get("clocks") or {}
     net = [r for r in rows if "net_forward_kernel" in r["Name"]]
-    tree = [r for r in rows if "tree_expand_select_kernel<false>" in r["Name"] or "tree_expand_select_kernelILb0" in r["Name"]]
+    tree = [r for r in rows if "tree_expand_select_kernel<false" in r["Name"] or "tree_expand_select_kernelILb0" in r["Name"]]
     with open(os.path.join(out, f"{tag}_{sub}_kernel_stats.md"), "w") as f:
         f.write(f"# {tag}: rocprofv3 --kernel-trace --stats of `{title}`\n\n{bj['config']['workload']}\n\n")
         f.write(f"Bench line of the same (profiled) run: value = {bj['value']} {bj['unit']}, ms_per_step = {bj['ms_per_step']} "
@@ -98,7 +99,7 @@ def traffic():
         return
     with open(os.path.join(out, f"{tag}_pmc_net_forward.md"), "w") as f:
         f.write(f"# {tag} PMC passes of `net_forward_kernel` at the three launch shapes of bench.py\n\n"
-                "One counter per pass with `--kernel-trace` only (HBM section of MI355X_MICROARCH.md), `scripts/prof_r04.sh`:\n\n"
+                f"One counter per pass with `--kernel-trace` only (HBM section of MI355X_MICROARCH.md), `scripts/prof_{tag}.sh`:\n\n"
                 "    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -- python3 scripts/prof_net_once.py <model> <batch> <full|half>\n"
                 "    rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -- python3 scripts/prof_net_once.py <model> <batch> <full|half>\n\n"
                 "Launch = one network evaluation of the whole batch from 32-byte packed states (the search loop's shape), mean "
@@ -127,7 +128,7 @@ def sq():
     keys = sorted(set(k for c, _, _ in cols.values() for k in c))
     with open(os.path.join(out, f"{tag}_pmc_sq_net_forward.md"), "w") as g:
         g.write(f"# {tag}: SQ counters of the network kernel at the two production launch shapes\n\n"
-                "`scripts/prof_r04.sh`: two `rocprofv3 --pmc ... --kernel-trace` passes (no other trace domain) per shape of "
+                f"`scripts/prof_{tag}.sh`: two `rocprofv3 --pmc ... --kernel-trace` passes (no other trace domain) per shape of "
                 "`scripts/prof_net_once.py` (20 launches alone on the device; means per launch).\n\n"
                 "| counter | " + " | ".join(cols) + " |\n|---|" + "---:|" * len(cols) + "\n")
         for k in keys:
