@@ -11,6 +11,7 @@
 #include <stdlib.h>
 
 #include <mutex>
+#include <vector>
 
 #include "lz_soa.h"
 #include "lz_wave.h"
@@ -723,48 +724,92 @@ __device__ __forceinline__ void puct_pulls_pair(int sims, int lane, float cp, fl
     }
 }
 
-template <int SLOTS>
-__global__ __launch_bounds__(kBlock) void root_puct_fast_kernel(const float* __restrict__ priors,
-                                                                const float* __restrict__ leaf,
-                                                                const uint8_t* __restrict__ valid, int64_t R,
-                                                                int A, int sims, float c,
-                                                                float* __restrict__ visits,
-                                                                float* __restrict__ value_sum,
-                                                                float* __restrict__ root_values) {
-    const int lane = lane_id();
-    const int64_t root = wave_item();
-    if (root >= R) return;
-    // ---- two roots per wave where both fit 32 lanes: the even wave of a pair works for both, the odd one leaves ----
-    {
-        const int64_t ra = root & ~(int64_t)1, rb = ra + 1;
-        bool wide = false;                                        // a valid action at index >= 32 in either row
-        if (rb < R) {
-            for (int a = 32 + lane; a < A; a += kWave) wide = wide || valid[ra * A + a] != 0 || valid[rb * A + a] != 0;
-        }
-        if (rb < R && __ballot(wide) == 0ull) {
-            if (root != ra) return;
-            const int a = lane & 31;
-            const int64_t r = lane < 32 ? ra : rb;
-            const bool ok = a < A && valid[r * A + (a < A ? a : 0)] != 0;
-            const float cp1 = ok ? c * priors[r * A + a] : __builtin_nanf("");
-            const float lv1 = a < A ? leaf[r * A + a] : 0.f;
-            float vis1 = 0.f, vs1 = 0.f;
-            const float acp = fabsf(cp1), alv = fabsf(lv1);
-            const bool tiny1 = ok && ((acp != 0.f && acp < 0x1p-100f) || (alv != 0.f && alv < 0x1p-100f));
-            if (__ballot(tiny1) != 0ull) puct_pulls_pair<true>(sims, lane, cp1, lv1, vis1, vs1);
-            else puct_pulls_pair<false>(sims, lane, cp1, lv1, vis1, vs1);
-            if (a < A) { visits[r * A + a] = vis1; value_sum[r * A + a] = vs1; }
-            for (int a2 = 32 + lane; a2 < A; a2 += kWave) {       // the rest of both rows: never visited
-                visits[ra * A + a2] = 0.f; value_sum[ra * A + a2] = 0.f;
-                visits[rb * A + a2] = 0.f; value_sum[rb * A + a2] = 0.f;
-            }
-            float sv1 = vis1, sw1 = vs1;                          // per-half butterfly: the same additions as wave_sum
-#pragma unroll                                                    // performs for a root alone in a wave (x + 0 == x)
-            for (int o = 16; o > 0; o >>= 1) { sv1 += __shfl_xor(sv1, o); sw1 += __shfl_xor(sw1, o); }
-            if ((lane & 31) == 0) root_values[r] = sw1 / fmaxf(sv1, 1.0f);
-            return;
+// Four roots in one wave (lanes 16k .. 16k + 15 = root k) when every valid action of all four sits below index 16 -- 81 % of
+// the positions of a game have at most 16 legal moves (g15: mean 11.7).  The row maximum comes from four cyclic row
+// rotations (every lane of a row ends up with its row's maximum: no readlane / select per quarter), one ballot serves the
+// four roots; a pull costs about the instructions of one root, so a packed quadruple takes a quarter of the issue slots.
+__device__ __forceinline__ float row16_max(float v) {
+    asm volatile("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_ror:1 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1"
+                 : "+v"(v));
+    return v;
+}
+
+template <bool EXACT_DIV>
+__device__ __forceinline__ void puct_pulls_quad(int sims, int lane, float cp, float lv, float& vis, float& vs) {
+    float q = 0.f;
+    double rd_u = 1.0, rd_next = 0.5;
+    int nv = 0;
+    for (int sim = 0; sim < sims; ++sim) {
+        const float sqrt_total = g_puct_sqrt[sim];
+        const float x = cp * sqrt_total;
+        const float u = EXACT_DIV ? x / (1.0f + vis) : div_by_int(x, rd_u);
+        const float sc = q + u;                                  // NaN on lanes without a valid action
+        const float m = row16_max(sc > -INFINITY ? sc : -INFINITY);
+        const unsigned long long hit = __ballot(sc == m);
+        if (hit == 0ull) break;                                  // no root of the four has a candidate: none later either
+        const uint32_t lo = (uint32_t)hit, hi = (uint32_t)(hit >> 32);
+        const uint32_t f0 = lo & 0xFFFFu, f1 = lo >> 16, f2 = hi & 0xFFFFu, f3 = hi >> 16;
+        const int c0 = f0 ? __builtin_ctz(f0) : -1, c1 = f1 ? 16 + __builtin_ctz(f1) : -1;
+        const int c2 = f2 ? 32 + __builtin_ctz(f2) : -1, c3 = f3 ? 48 + __builtin_ctz(f3) : -1;
+        if (lane == c0 || lane == c1 || lane == c2 || lane == c3) {
+            nv += 1;
+            vis += 1.0f;
+            vs += lv;
+            const double rd_q = rd_u;
+            rd_u = rd_next;
+            if (!EXACT_DIV) rd_next = g_puct_recip[nv + 2];
+            q = EXACT_DIV ? vs / vis : div_by_int(vs, rd_q);
         }
     }
+}
+
+__device__ __forceinline__ bool tiny_magnitude(bool ok, float cp, float lv) {
+    const float acp = fabsf(cp), alv = fabsf(lv);
+    return ok && ((acp != 0.f && acp < 0x1p-100f) || (alv != 0.f && alv < 0x1p-100f));
+}
+
+// G roots (2 or 4, any of them may be missing: index < 0) whose valid actions all sit below 64 / G
+template <int G>
+__device__ __forceinline__ void puct_group_job(const int64_t (&roots)[G], int lane, const float* __restrict__ priors,
+                                               const float* __restrict__ leaf, const uint8_t* __restrict__ valid, int A,
+                                               int sims, float c, float* __restrict__ visits,
+                                               float* __restrict__ value_sum, float* __restrict__ root_values) {
+    constexpr int W = kWave / G;                                 // lanes per root
+    const int a = lane & (W - 1), k = lane / W;
+    int64_t r = roots[0];
+#pragma unroll
+    for (int j = 1; j < G; ++j) r = k == j ? roots[j] : r;
+    const bool have = r >= 0;
+    const bool ok = have && a < A && valid[(have ? r : 0) * A + (a < A ? a : 0)] != 0;
+    const float cp1 = ok ? c * priors[r * A + a] : __builtin_nanf("");
+    const float lv1 = have && a < A ? leaf[r * A + a] : 0.f;
+    float vis1 = 0.f, vs1 = 0.f;
+    const bool exact = __ballot(tiny_magnitude(ok, cp1, lv1)) != 0ull;    // wave-uniform: the plain divisions
+    if (G == 2) {
+        if (exact) puct_pulls_pair<true>(sims, lane, cp1, lv1, vis1, vs1);
+        else puct_pulls_pair<false>(sims, lane, cp1, lv1, vis1, vs1);
+    } else {
+        if (exact) puct_pulls_quad<true>(sims, lane, cp1, lv1, vis1, vs1);
+        else puct_pulls_quad<false>(sims, lane, cp1, lv1, vis1, vs1);
+    }
+    if (have && a < A) { visits[r * A + a] = vis1; value_sum[r * A + a] = vs1; }
+    if (have)
+        for (int a2 = W + a; a2 < A; a2 += W) { visits[r * A + a2] = 0.f; value_sum[r * A + a2] = 0.f; }   // never visited
+    float sv1 = vis1, sw1 = vs1;                                  // per-root butterfly: the same additions as wave_sum
+#pragma unroll                                                    // performs for a root alone in a wave (x + 0 == x)
+    for (int o = W / 2; o > 0; o >>= 1) { sv1 += __shfl_xor(sv1, o); sw1 += __shfl_xor(sw1, o); }
+    if (have && a == 0) root_values[r] = sw1 / fmaxf(sv1, 1.0f);
+}
+
+template <int SLOTS>
+__device__ __forceinline__ void puct_single_job(int64_t root, int lane, const float* __restrict__ priors,
+                                                const float* __restrict__ leaf, const uint8_t* __restrict__ valid, int A,
+                                                int sims, float c, float* __restrict__ visits,
+                                                float* __restrict__ value_sum, float* __restrict__ root_values) {
     float cp[SLOTS], lv[SLOTS], vis[SLOTS], vs[SLOTS];
     int live = 0;
     bool tiny = false;
@@ -777,8 +822,7 @@ __global__ __launch_bounds__(kBlock) void root_puct_fast_kernel(const float* __r
         lv[j] = a < A ? leaf[root * A + a] : 0.f;
         vis[j] = 0.f; vs[j] = 0.f;
         if (__ballot(ok) != 0ull) live = j + 1;
-        const float acp = fabsf(cp[j]), alv = fabsf(lv[j]);
-        tiny = tiny || (ok && ((acp != 0.f && acp < 0x1p-100f) || (alv != 0.f && alv < 0x1p-100f)));
+        tiny = tiny || tiny_magnitude(ok, cp[j], lv[j]);
     }
     // wave-uniform: the plain divisions for this root (two instantiations of the loop, one real branch)
     if (__ballot(tiny) != 0ull) puct_pulls<SLOTS, true>(sims, lane, live, cp, lv, vis, vs);
@@ -794,6 +838,84 @@ __global__ __launch_bounds__(kBlock) void root_puct_fast_kernel(const float* __r
     sv = wave_sum(sv);
     sw = wave_sum(sw);
     if (lane == 0) root_values[root] = sw / fmaxf(sv, 1.0f);
+}
+
+// without scratch memory (a capture in progress before any eager call): consecutive roots pair up where both fit 32 lanes
+template <int SLOTS>
+__global__ __launch_bounds__(kBlock) void root_puct_fast_kernel(const float* __restrict__ priors,
+                                                                const float* __restrict__ leaf,
+                                                                const uint8_t* __restrict__ valid, int64_t R,
+                                                                int A, int sims, float c,
+                                                                float* __restrict__ visits,
+                                                                float* __restrict__ value_sum,
+                                                                float* __restrict__ root_values) {
+    const int lane = lane_id();
+    const int64_t root = wave_item();
+    if (root >= R) return;
+    const int64_t ra = root & ~(int64_t)1, rb = ra + 1;
+    bool wide = false;                                            // a valid action at index >= 32 in either row
+    if (rb < R)
+        for (int a = 32 + lane; a < A; a += kWave) wide = wide || valid[ra * A + a] != 0 || valid[rb * A + a] != 0;
+    if (rb < R && __ballot(wide) == 0ull) {                      // the even wave of the pair works for both, the odd one leaves
+        if (root != ra) return;
+        const int64_t pair[2] = {ra, rb};
+        puct_group_job<2>(pair, lane, priors, leaf, valid, A, sims, c, visits, value_sum, root_values);
+        return;
+    }
+    puct_single_job<SLOTS>(root, lane, priors, leaf, valid, A, sims, c, visits, value_sum, root_values);
+}
+
+// ---- roots binned by width first (round 5): rows of <= 16 valid actions go four to a wave, <= 32 two to a wave, the rest
+// alone -- whichever roots happen to be neighbours.  puct_bin_kernel: one wave per root finds the row's width (index of
+// its last valid action + 1) and appends the root to its class list (atomics on three counters, once per ply: the list
+// order varies from run to run, a root's results do not depend on its companions).  The pull kernel's wave w then takes
+// quadruple w, pair w - quads, or single w - quads - pairs, from the device-side counts (no host read).
+__global__ void puct_zero_counts_kernel(unsigned* counts) { if (threadIdx.x < 4) counts[threadIdx.x] = 0u; }
+
+__global__ __launch_bounds__(kBlock) void puct_bin_kernel(const uint8_t* __restrict__ valid, int64_t R, int A,
+                                                          int* __restrict__ lists, unsigned* __restrict__ counts, int64_t cap) {
+    const int lane = lane_id();
+    const int64_t root = wave_item();
+    if (root >= R) return;
+    int width = 0;
+    for (int a0 = 0; a0 < A; a0 += kWave) {
+        const unsigned long long b = __ballot(a0 + lane < A && valid[root * A + (a0 + lane < A ? a0 + lane : 0)] != 0);
+        if (b != 0ull) width = a0 + 64 - __builtin_clzll(b);
+    }
+    if (lane == 0) {
+        const int cls = width <= 16 ? 0 : (width <= 32 ? 1 : 2);
+        const unsigned pos = atomicAdd(&counts[cls], 1u);
+        lists[(int64_t)cls * cap + pos] = (int)root;
+    }
+}
+
+template <int SLOTS>
+__global__ __launch_bounds__(kBlock) void root_puct_binned_kernel(const float* __restrict__ priors,
+                                                                  const float* __restrict__ leaf,
+                                                                  const uint8_t* __restrict__ valid, int64_t R, int A,
+                                                                  int sims, float c, float* __restrict__ visits,
+                                                                  float* __restrict__ value_sum,
+                                                                  float* __restrict__ root_values,
+                                                                  const int* __restrict__ lists,
+                                                                  const unsigned* __restrict__ counts, int64_t cap) {
+    const int lane = lane_id();
+    const int64_t w = wave_item();
+    if (w >= R) return;
+    const int64_t n0 = counts[0], n1 = counts[1], n2 = counts[2];
+    const int64_t quads = (n0 + 3) >> 2, pairs = (n1 + 1) >> 1;
+    if (w < quads) {
+        int64_t r[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) r[k] = 4 * w + k < n0 ? (int64_t)lists[4 * w + k] : -1;
+        puct_group_job<4>(r, lane, priors, leaf, valid, A, sims, c, visits, value_sum, root_values);
+    } else if (w < quads + pairs) {
+        const int64_t i = 2 * (w - quads);
+        const int64_t r[2] = {(int64_t)lists[cap + i], i + 1 < n1 ? (int64_t)lists[cap + i + 1] : -1};
+        puct_group_job<2>(r, lane, priors, leaf, valid, A, sims, c, visits, value_sum, root_values);
+    } else if (w < quads + pairs + n2) {
+        puct_single_job<SLOTS>((int64_t)lists[2 * cap + (w - quads - pairs)], lane, priors, leaf, valid, A, sims, c, visits,
+                               value_sum, root_values);
+    }
 }
 
 // =================================================================================================
@@ -1319,6 +1441,31 @@ inline bool soa_aligned(const LzStateSoA* s) {
 
 }  // namespace
 
+// Scratch memory of the binned bandit: three lists of `cap` root indices + the class counts, one block per (device,
+// stream) so that two streams never share lists.  Allocated by the first eager call that needs it; a call on a capturing
+// stream only uses what exists already (hipMalloc is not capturable).  A block that is too small is replaced, the old one is
+// kept alive: captured graphs may still point at it.
+struct PuctScratch { int* lists; unsigned* counts; int64_t cap; };
+static bool puct_scratch(int device, hipStream_t st, int64_t R, PuctScratch* out) {
+    struct Entry { int device; hipStream_t st; PuctScratch s; };
+    static std::mutex mu;
+    static std::vector<Entry> entries;                            // newest last; superseded blocks stay (never freed)
+    std::lock_guard<std::mutex> lk(mu);
+    for (auto it = entries.rbegin(); it != entries.rend(); ++it)
+        if (it->device == device && it->st == st && it->s.cap >= R) { *out = it->s; return true; }
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return false;
+    PuctScratch s{};
+    s.cap = R < 1024 ? 1024 : R;
+    void* p = nullptr;
+    if (hipMalloc(&p, (size_t)s.cap * 3 * sizeof(int) + 4 * sizeof(unsigned)) != hipSuccess) { (void)hipGetLastError(); return false; }
+    s.lists = static_cast<int*>(p);
+    s.counts = reinterpret_cast<unsigned*>(s.lists + 3 * s.cap);
+    entries.push_back({device, st, s});
+    *out = s;
+    return true;
+}
+
 // =================================================================================================
 // C ABI
 // =================================================================================================
@@ -1458,6 +1605,7 @@ int lz_root_puct_allocate_visits(const float* priors, const float* leaf, const u
     // LZ_ROOT_PUCT_DIV=1 forces the division kernel (tests compare the two)
     const char* force = getenv("LZ_ROOT_PUCT_DIV");
     bool use_tables = sims <= kPuctTable && !(force && force[0] == '1');
+    int device = 0;
     if (use_tables) {
         // The tables are filled ONCE per device, synchronously: the flag is only set after the fill has completed and
         // been checked, so no launch on any stream can read a partial table.  A stream that is being
@@ -1465,7 +1613,6 @@ int lz_root_puct_allocate_visits(const float* priors, const float* leaf, const u
         // tables (FusedRootSearch makes one before it captures).
         static std::mutex tables_mu;
         static bool tables_ready[64] = {};
-        int device = 0;
         if (hipGetDevice(&device) != hipSuccess || device < 0 || device >= 64) return LZ_ERR_LAUNCH;
         std::lock_guard<std::mutex> lk(tables_mu);
         if (!tables_ready[device]) {
@@ -1481,6 +1628,19 @@ int lz_root_puct_allocate_visits(const float* priors, const float* leaf, const u
         }
     }
     if (use_tables) {
+        // binned by width when this stream has scratch memory for the lists (allocated once per device and stream by an
+        // eager call; never during a capture -- FusedRootSearch warms up eagerly before it captures); LZ_ROOT_PUCT_BIN=0
+        // keeps neighbours-pair-up (tests compare the two)
+        const char* nobin = getenv("LZ_ROOT_PUCT_BIN");
+        PuctScratch sc{};
+        if (!(nobin && nobin[0] == '0') && puct_scratch(device, st, R, &sc)) {
+            hipLaunchKernelGGL(puct_zero_counts_kernel, dim3(1), dim3(64), 0, st, sc.counts);
+            hipLaunchKernelGGL(puct_bin_kernel, grid, block, 0, st, valid, R, (int)A, sc.lists, sc.counts, sc.cap);
+            if (A <= 64) hipLaunchKernelGGL(root_puct_binned_kernel<1>, grid, block, 0, st, priors, leaf, valid, R, (int)A, (int)sims, c, visits, value_sum, root_values, sc.lists, sc.counts, sc.cap);
+            else if (A <= 128) hipLaunchKernelGGL(root_puct_binned_kernel<2>, grid, block, 0, st, priors, leaf, valid, R, (int)A, (int)sims, c, visits, value_sum, root_values, sc.lists, sc.counts, sc.cap);
+            else hipLaunchKernelGGL(root_puct_binned_kernel<4>, grid, block, 0, st, priors, leaf, valid, R, (int)A, (int)sims, c, visits, value_sum, root_values, sc.lists, sc.counts, sc.cap);
+            return launch_status();
+        }
         if (A <= 64) hipLaunchKernelGGL(root_puct_fast_kernel<1>, grid, block, 0, st, priors, leaf, valid, R, (int)A, (int)sims, c, visits, value_sum, root_values);
         else if (A <= 128) hipLaunchKernelGGL(root_puct_fast_kernel<2>, grid, block, 0, st, priors, leaf, valid, R, (int)A, (int)sims, c, visits, value_sum, root_values);
         else hipLaunchKernelGGL(root_puct_fast_kernel<4>, grid, block, 0, st, priors, leaf, valid, R, (int)A, (int)sims, c, visits, value_sum, root_values);

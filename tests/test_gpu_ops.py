@@ -318,6 +318,66 @@ def test_root_puct_table_kernel_equals_division_kernel(v0, A, sims, monkeypatch)
     assert np.array_equal(got_v, want_v)
 
 
+@pytest.mark.parametrize("R,A,sims", [(4, 36, 64), (5, 72, 1024), (1023, 80, 700), (6, 16, 8192), (130, 130, 300)])
+def test_root_puct_binned_by_width_equals_neighbour_pairs_and_the_division_kernel(v0, R, A, sims, monkeypatch):
+    """Round 5: rows of <= 16 valid actions go FOUR to a wave, <= 32 two to a wave, the rest alone, whichever roots they
+    are (csrc/lz_ops.hip: puct_bin_kernel + root_puct_binned_kernel).  Byte-identical visits / value sums / root values to
+    the round-4 kernel (LZ_ROOT_PUCT_BIN=0: neighbours pair up) and to the IEEE-division kernel (LZ_ROOT_PUCT_DIV=1), over
+    widths 0 / 1 / 15 / 16 / 17 / 31 / 32 / 33 / 64+, root counts that leave incomplete quadruples and pairs, ties,
+    rows that must take the division branch, and the same call captured into a hipGraph and replayed."""
+    if DEV == "cpu":
+        pytest.skip("the host build has one loop per root: nothing to bin")
+    rng = np.random.default_rng(R * 1000 + A)
+    special = [0, 1, 15, 16, 17, 31, 32, 33, min(A, 64), A, 16, 16, 16, 3, 16]
+    n = np.minimum(np.where(np.arange(R) < len(special), np.resize(special, R), rng.integers(0, min(A, 40) + 1, R)), A)
+    narrow = rng.random(R) < 0.5
+    n[narrow & (np.arange(R) >= len(special))] = np.minimum(n, 16)[narrow & (np.arange(R) >= len(special))]     # most rows are narrow
+    valid = np.arange(A)[None, :] < n[:, None]
+    holes = rng.random((R, A)) < 0.15                               # not every row is packed to the left
+    valid = valid & ~holes
+    valid[np.arange(R), np.maximum(n - 1, 0)] = n > 0               # ... but its width is what it is
+    pri = (rng.random((R, A)) ** 2 * valid).astype(np.float32)
+    pri /= np.maximum(pri.sum(1, keepdims=True), 1e-8)
+    leaf = ((rng.random((R, A)) * 2 - 1) * valid).astype(np.float32)
+    if R > 12:
+        pri[11, :] = np.where(valid[11], 1.0 / max(1, valid[11].sum()), 0).astype(np.float32); leaf[11] = 0.25 * valid[11]   # ties
+        leaf[12, 0] = np.float32(2.0 ** -120); valid[12, 0] = True                                   # division branch
+    args = [torch.from_numpy(x).to(DEV) for x in (pri, leaf, valid)]
+    run = lambda: [t.cpu().numpy() for t in v0.root_puct_allocate_visits(*args, sims, 1.3)]
+    monkeypatch.delenv("LZ_ROOT_PUCT_DIV", raising=False)
+    monkeypatch.delenv("LZ_ROOT_PUCT_BIN", raising=False)
+    binned = run()
+    monkeypatch.setenv("LZ_ROOT_PUCT_BIN", "0")
+    pairs = run()
+    monkeypatch.setenv("LZ_ROOT_PUCT_DIV", "1")
+    division = run()
+    for x, y, z in zip(binned, pairs, division):
+        assert x.tobytes() == y.tobytes() == z.tobytes()
+    width = np.where(valid.any(1), A - np.argmax(valid[:, ::-1], axis=1), 0)
+    assert (binned[0].sum(1) == np.where(width > 0, sims, 0)).all() and (binned[0][~valid] == 0).all()
+    # the same call inside a captured graph (the scratch lists exist since the eager call above)
+    monkeypatch.delenv("LZ_ROOT_PUCT_DIV", raising=False)
+    monkeypatch.delenv("LZ_ROOT_PUCT_BIN", raising=False)
+    from liuzhou_amd import _lib as L
+    import ctypes as C
+    vis, vs, rv = (torch.zeros((R, A), device=DEV), torch.zeros((R, A), device=DEV), torch.zeros((R,), device=DEV))
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        call = lambda: L.check(L.lib().lz_root_puct_allocate_visits(
+            L.ptr(args[0]), L.ptr(args[1]), L.ptr(args[2]), L.i64(R), L.i64(A), L.i64(sims), C.c_float(1.3), L.ptr(vis),
+            L.ptr(vs), L.ptr(rv), L.stream_ptr(torch.device(DEV))), "root_puct")
+        call()                                                      # eager on this stream: its scratch lists
+        torch.cuda.synchronize()
+        vis.zero_(); vs.zero_(); rv.zero_()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            call()
+        g.replay(); g.replay()
+    torch.cuda.synchronize()
+    for x, y in zip(binned, (vis, vs, rv)):
+        assert x.tobytes() == y.cpu().numpy().tobytes()
+
+
 @pytest.mark.parametrize("A", [5, 64, 72, 130])
 def test_root_puct_random_vs_oracle(v0, A):
     rng = np.random.default_rng(A)
