@@ -156,6 +156,15 @@ LZ_API int lz_root_puct_allocate_visits(const float* priors, const float* leaf_v
                                         int64_t num_actions, int64_t num_simulations,
                                         float exploration_weight, float* visits, float* value_sum,
                                         float* root_values, void* stream);
+/* The same with caller-owned scratch (`workspace` >= *bytes of lz_root_puct_workspace_bytes(num_roots, &bytes) of device
+ * memory, 4-byte aligned): allocation-free like every other entry point, so it can be captured on any stream -- what the fused
+ * root search of liuzhou_amd/root_search_fused.py launches. */
+LZ_API int lz_root_puct_workspace_bytes(int64_t num_roots, int64_t* bytes);
+LZ_API int lz_root_puct_allocate_visits_ws(const float* priors, const float* leaf_values,
+                                           const uint8_t* valid_mask, int64_t num_roots, int64_t num_actions,
+                                           int64_t num_simulations, float exploration_weight, float* visits,
+                                           float* value_sum, float* root_values, void* workspace,
+                                           int64_t workspace_bytes, void* stream);
 
 /* v0_core.root_finalize_from_visits  (module.cpp:1374-1386, :441-535) fused with the v1 sampling
  * step (mcts_gpu.py:1410-1424).  `uniforms` float32[R] in [0,1) selects sampled picks from the

@@ -1592,9 +1592,13 @@ int lz_root_pack_fill(const int32_t* counts, const int32_t* legal_index, const f
     return launch_status();
 }
 
-int lz_root_puct_allocate_visits(const float* priors, const float* leaf, const uint8_t* valid, int64_t R,
-                                 int64_t A, int64_t sims, float c, float* visits, float* value_sum,
-                                 float* root_values, void* stream) {
+static int64_t puct_workspace_bytes(int64_t num_roots) {
+    return (num_roots < 0 ? 0 : num_roots) * 3 * (int64_t)sizeof(int) + 4 * (int64_t)sizeof(unsigned);
+}
+
+static int root_puct_impl(const float* priors, const float* leaf, const uint8_t* valid, int64_t R, int64_t A, int64_t sims,
+                          float c, float* visits, float* value_sum, float* root_values, void* workspace,
+                          int64_t workspace_bytes, void* stream) {
     if (R < 0 || A < 0 || sims <= 0) return LZ_ERR_ARG;
     if (A > 256) return LZ_ERR_UNSUPPORTED;
     if (R == 0 || A == 0) return LZ_OK;
@@ -1633,7 +1637,17 @@ int lz_root_puct_allocate_visits(const float* priors, const float* leaf, const u
         // keeps neighbours-pair-up (tests compare the two)
         const char* nobin = getenv("LZ_ROOT_PUCT_BIN");
         PuctScratch sc{};
-        if (!(nobin && nobin[0] == '0') && puct_scratch(device, st, R, &sc)) {
+        bool have = false;
+        if (workspace != nullptr) {                                // the caller's own lists (graph-safe, any stream)
+            if (workspace_bytes < puct_workspace_bytes(R) || !aligned(workspace, 4)) return LZ_ERR_ARG;
+            sc.lists = static_cast<int*>(workspace);
+            sc.cap = R;
+            sc.counts = reinterpret_cast<unsigned*>(sc.lists + 3 * sc.cap);
+            have = true;
+        } else {
+            have = puct_scratch(device, st, R, &sc);
+        }
+        if (!(nobin && nobin[0] == '0') && have) {
             hipLaunchKernelGGL(puct_zero_counts_kernel, dim3(1), dim3(64), 0, st, sc.counts);
             hipLaunchKernelGGL(puct_bin_kernel, grid, block, 0, st, valid, R, (int)A, sc.lists, sc.counts, sc.cap);
             if (A <= 64) hipLaunchKernelGGL(root_puct_binned_kernel<1>, grid, block, 0, st, priors, leaf, valid, R, (int)A, (int)sims, c, visits, value_sum, root_values, sc.lists, sc.counts, sc.cap);
@@ -1650,6 +1664,26 @@ int lz_root_puct_allocate_visits(const float* priors, const float* leaf, const u
     else if (A <= 128) hipLaunchKernelGGL(root_puct_kernel<2>, grid, block, 0, st, priors, leaf, valid, R, (int)A, sims, c, visits, value_sum, root_values);
     else hipLaunchKernelGGL(root_puct_kernel<4>, grid, block, 0, st, priors, leaf, valid, R, (int)A, sims, c, visits, value_sum, root_values);
     return launch_status();
+}
+
+int lz_root_puct_workspace_bytes(int64_t num_roots, int64_t* bytes) {
+    if (num_roots < 0 || !bytes) return LZ_ERR_ARG;
+    *bytes = puct_workspace_bytes(num_roots);
+    return LZ_OK;
+}
+
+int lz_root_puct_allocate_visits(const float* priors, const float* leaf, const uint8_t* valid, int64_t R,
+                                 int64_t A, int64_t sims, float c, float* visits, float* value_sum,
+                                 float* root_values, void* stream) {
+    return root_puct_impl(priors, leaf, valid, R, A, sims, c, visits, value_sum, root_values, nullptr, 0, stream);
+}
+
+int lz_root_puct_allocate_visits_ws(const float* priors, const float* leaf, const uint8_t* valid, int64_t R,
+                                    int64_t A, int64_t sims, float c, float* visits, float* value_sum,
+                                    float* root_values, void* workspace, int64_t workspace_bytes, void* stream) {
+    if (!workspace) return LZ_ERR_ARG;
+    return root_puct_impl(priors, leaf, valid, R, A, sims, c, visits, value_sum, root_values, workspace, workspace_bytes,
+                          stream);
 }
 
 int lz_root_finalize_from_visits(const int64_t* lidx, const int32_t* codes, const uint8_t* valid,

@@ -66,6 +66,11 @@ class FusedRootSearch:
         self.root_value_vec = o("root_value_vec", (B,), torch.float32)
         self._graphs = {}
         self._evals_dev = z((1,), torch.int64)              # network evaluations so far, kept on the device
+        # lists of the width-binned bandit (rows of <= 16 / <= 32 actions share a wave four / two at a time): caller-owned,
+        # so that the launch is allocation-free and can be captured on whatever stream torch captures on
+        ws_bytes = C.c_int64(0)
+        L.check(L.lib().lz_root_puct_workspace_bytes(L.i64(B), C.byref(ws_bytes)), "root_puct_workspace_bytes")
+        self.puct_ws = z((int(ws_bytes.value),), torch.uint8)
 
     def _launch(self, add_noise: bool, sample: bool) -> None:
         lib, st, B, p = L.lib(), L.stream_ptr(self.device), self.B, L.ptr
@@ -82,9 +87,10 @@ class FusedRootSearch:
            "net_forward_packed_counted")
         ck(lib.lz_root_collect(p(self.root_packed), p(self.child_states), p(self.child_ref), p(self.child_values),
                                p(self.n_children), L.i64(B * CAP), C.c_float(self.soft_k), p(self.leaf), st), "root_collect")
-        ck(lib.lz_root_puct_allocate_visits(p(self.priors), p(self.leaf), p(self.valid), L.i64(B), L.i64(CAP),
-                                            L.i64(self.sims), C.c_float(self.c), p(self.visits), p(self.value_sum),
-                                            p(self.puct_root_values), st), "root_puct")
+        ck(lib.lz_root_puct_allocate_visits_ws(p(self.priors), p(self.leaf), p(self.valid), L.i64(B), L.i64(CAP),
+                                               L.i64(self.sims), C.c_float(self.c), p(self.visits), p(self.value_sum),
+                                               p(self.puct_root_values), p(self.puct_ws), L.i64(int(self.puct_ws.numel())),
+                                               st), "root_puct")
         ck(lib.lz_root_finalize_from_visits(p(self.legal_index), p(self.codes), p(self.valid), p(self.visits),
                                             p(self.value_sum), p(self.roots), L.i64(B), L.i64(CAP), L.i64(B),
                                             L.i64(TOTAL_ACTION_DIM), p(self.temps), p(self.uniforms) if sample else None,

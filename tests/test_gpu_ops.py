@@ -361,19 +361,26 @@ def test_root_puct_binned_by_width_equals_neighbour_pairs_and_the_division_kerne
     from liuzhou_amd import _lib as L
     import ctypes as C
     vis, vs, rv = (torch.zeros((R, A), device=DEV), torch.zeros((R, A), device=DEV), torch.zeros((R,), device=DEV))
-    side = torch.cuda.Stream()
-    with torch.cuda.stream(side):
-        call = lambda: L.check(L.lib().lz_root_puct_allocate_visits(
-            L.ptr(args[0]), L.ptr(args[1]), L.ptr(args[2]), L.i64(R), L.i64(A), L.i64(sims), C.c_float(1.3), L.ptr(vis),
-            L.ptr(vs), L.ptr(rv), L.stream_ptr(torch.device(DEV))), "root_puct")
-        call()                                                      # eager on this stream: its scratch lists
-        torch.cuda.synchronize()
-        vis.zero_(); vs.zero_(); rv.zero_()
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, stream=side):
-            call()
-        g.replay(); g.replay()
+    nbytes = C.c_int64(0)
+    L.check(L.lib().lz_root_puct_workspace_bytes(L.i64(R), C.byref(nbytes)), "workspace_bytes")
+    ws = torch.zeros((int(nbytes.value),), dtype=torch.uint8, device=DEV)      # caller-owned lists: allocation-free launch
+    call = lambda: L.check(L.lib().lz_root_puct_allocate_visits_ws(
+        L.ptr(args[0]), L.ptr(args[1]), L.ptr(args[2]), L.i64(R), L.i64(A), L.i64(sims), C.c_float(1.3), L.ptr(vis),
+        L.ptr(vs), L.ptr(rv), L.ptr(ws), L.i64(int(ws.numel())), L.stream_ptr(torch.device(DEV))), "root_puct_ws")
+    call()
     torch.cuda.synchronize()
+    for x, y in zip(binned, (vis, vs, rv)):
+        assert x.tobytes() == y.cpu().numpy().tobytes()
+    vis.zero_(); vs.zero_(); rv.zero_()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):                                       # torch captures on a stream of its own
+        call()
+    g.replay(); g.replay()
+    torch.cuda.synchronize()
+    small = torch.zeros((8,), dtype=torch.uint8, device=DEV)
+    assert L.lib().lz_root_puct_allocate_visits_ws(
+        L.ptr(args[0]), L.ptr(args[1]), L.ptr(args[2]), L.i64(R), L.i64(A), L.i64(sims), C.c_float(1.3), L.ptr(vis),
+        L.ptr(vs), L.ptr(rv), L.ptr(small), L.i64(8), L.stream_ptr(torch.device(DEV))) == -1     # LZ_ERR_ARG
     for x, y in zip(binned, (vis, vs, rv)):
         assert x.tobytes() == y.cpu().numpy().tobytes()
 
