@@ -182,6 +182,18 @@ LZ_API int lz_root_finalize_from_visits(const int64_t* legal_index_mat, const in
 
 /* ---- self-play step operators --------------------------------------------------------------- */
 
+/* Opening plies of a game (`opening_random_moves` of v1/python/self_play_gpu_runner.py; mcts_gpu.py:1425-1447 replaces
+ * the search's pick by torch.multinomial over the uniform policy of the valid actions): for every packed row r whose root
+ * valid_root_indices[r] (NULL: r itself) has force_mask[root] != 0, the chosen action becomes the k-th valid slot of the row
+ * in ascending order, k = min(floor(uniforms[r] * n), n - 1), n = valid slots; chosen_valid_mask[root] = 1.  Rows without a
+ * valid slot and unflagged roots are left alone; the policy target is not touched.  Run after
+ * lz_root_finalize_from_visits on the same buffers. */
+LZ_API int lz_root_force_uniform_picks(const int64_t* legal_index_mat, const int32_t* action_code_mat,
+                                       const uint8_t* valid_mask, const int64_t* valid_root_indices, int64_t num_roots,
+                                       int64_t max_actions, const uint8_t* force_mask, const float* uniforms,
+                                       int64_t* chosen_action_indices, int32_t* chosen_action_codes,
+                                       uint8_t* chosen_valid_mask, void* stream);
+
 /* v0_core.self_play_step_inplace  (module.cpp:1387-1409, :632-871).  Mutates states / plies / done.
  * Per active row i it reports fin_kind[i] = 0 (game continues), 1 (ended before the move: terminal
  * root or no valid choice) or 2 (ended by the move: winner / draw / ply cap), with

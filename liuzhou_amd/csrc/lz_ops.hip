@@ -1441,6 +1441,40 @@ inline bool soa_aligned(const LzStateSoA* s) {
 
 }  // namespace
 
+// Opening plies (self_play_gpu_runner.py `opening_random_moves`; mcts_gpu.py:1425-1447): the move of a flagged root is a
+// uniform pick among its valid actions -- the k-th valid slot of its packed row in ascending order, k = min(floor(u n),
+// n - 1) -- whatever the search chose; its policy target stays the search's.  One wave per row.
+__global__ __launch_bounds__(kBlock) void root_force_uniform_kernel(
+    const int64_t* __restrict__ lidx, const int4* __restrict__ codes, const uint8_t* __restrict__ valid,
+    const int64_t* __restrict__ roots, int64_t R, int M, const uint8_t* __restrict__ force, const float* __restrict__ uniforms,
+    int64_t* __restrict__ cidx, int4* __restrict__ ccodes, uint8_t* __restrict__ cvalid) {
+    const int lane = lane_id();
+    const int64_t r = wave_item();
+    if (r >= R) return;
+    const int64_t b = roots ? roots[r] : r;
+    if (force[b] == 0) return;
+    int n = 0;
+    for (int a0 = 0; a0 < M; a0 += kWave)
+        n += __popcll(__ballot(a0 + lane < M && valid[r * M + (a0 + lane < M ? a0 + lane : 0)] != 0));
+    if (n == 0) return;                                          // no legal action: the search's (invalid) pick stands
+    int k = (int)(uniforms[r] * (float)n);
+    k = k < 0 ? 0 : (k >= n ? n - 1 : k);
+    for (int a0 = 0; a0 < M; a0 += kWave) {
+        const bool v = a0 + lane < M && valid[r * M + (a0 + lane < M ? a0 + lane : 0)] != 0;
+        const unsigned long long bal = __ballot(v);
+        const int here = __popcll(bal);
+        if (k < here) {
+            if (v && __popcll(bal & ((1ull << lane) - 1ull)) == k) {
+                cidx[b] = lidx[r * M + a0 + lane];
+                ccodes[b] = codes[r * M + a0 + lane];
+                cvalid[b] = 1;
+            }
+            return;
+        }
+        k -= here;
+    }
+}
+
 // Scratch memory of the binned bandit: three lists of `cap` root indices + the class counts, one block per (device,
 // stream) so that two streams never share lists.  Allocated by the first eager call that needs it; a call on a capturing
 // stream only uses what exists already (hipMalloc is not capturable).  A block that is too small is replaced, the old one is
@@ -1713,6 +1747,19 @@ int lz_root_finalize_from_visits(const int64_t* lidx, const int32_t* codes, cons
         else if (M <= 128) hipLaunchKernelGGL(root_finalize_kernel<2>, grid, block, 0, st, lidx, c4, valid, visits, value_sum, roots, R, (int)M, B, (int)T, temps, uniforms, policy, cidx, o4, cvalid, root_value);
         else hipLaunchKernelGGL(root_finalize_kernel<4>, grid, block, 0, st, lidx, c4, valid, visits, value_sum, roots, R, (int)M, B, (int)T, temps, uniforms, policy, cidx, o4, cvalid, root_value);
     }
+    return launch_status();
+}
+
+int lz_root_force_uniform_picks(const int64_t* lidx, const int32_t* codes, const uint8_t* valid, const int64_t* roots,
+                                int64_t R, int64_t M, const uint8_t* force_mask, const float* uniforms, int64_t* cidx,
+                                int32_t* ccodes, uint8_t* cvalid, void* stream) {
+    if (R < 0 || M < 0) return LZ_ERR_ARG;
+    if (R == 0 || M == 0) return LZ_OK;
+    if (!lidx || !codes || !valid || !force_mask || !uniforms || !cidx || !ccodes || !cvalid) return LZ_ERR_ARG;
+    if (!aligned(codes, 16) || !aligned(ccodes, 16)) return LZ_ERR_ALIGN;
+    hipLaunchKernelGGL(root_force_uniform_kernel, dim3(grid_waves(R)), dim3(kBlock), 0, as_stream(stream), lidx,
+                       reinterpret_cast<const int4*>(codes), valid, roots, R, (int)M, force_mask, uniforms, cidx,
+                       reinterpret_cast<int4*>(ccodes), cvalid);
     return launch_status();
 }
 

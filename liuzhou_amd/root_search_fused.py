@@ -11,7 +11,7 @@ from typing import Optional
 import torch
 
 from . import _lib as L
-from .game_rng import GameRng, PURPOSE_PICK
+from .game_rng import GameRng, PURPOSE_OPENING, PURPOSE_PICK
 from .mcts_gpu import GpuStateBatch, RootSearchBatchOutput, TOTAL_ACTION_DIM, encode_actions_fast, states_to_model_input
 from .net_hip import FusedNet
 
@@ -58,6 +58,8 @@ class FusedRootSearch:
         self.temps = z((B,), torch.float32)
         self.noise = z((B, CAP), torch.float32)
         self.uniforms = z((B,), torch.float32)
+        self.force = z((B,), torch.uint8)                   # opening plies: the move is a uniform pick (search_batch)
+        self.force_uniforms = z((B,), torch.float32)
         self.rng = GameRng(B, dev, seed=seed, game_offset=game_offset, game_stride=game_stride)
         self.policy_dense = o("policy_dense", (B, TOTAL_ACTION_DIM), torch.float32)
         self.chosen_idx = o("chosen_idx", (B,), torch.int64)
@@ -72,7 +74,7 @@ class FusedRootSearch:
         L.check(L.lib().lz_root_puct_workspace_bytes(L.i64(B), C.byref(ws_bytes)), "root_puct_workspace_bytes")
         self.puct_ws = z((int(ws_bytes.value),), torch.uint8)
 
-    def _launch(self, add_noise: bool, sample: bool) -> None:
+    def _launch(self, add_noise: bool, sample: bool, forced: bool = False) -> None:
         lib, st, B, p = L.lib(), L.stream_ptr(self.device), self.B, L.ptr
         ck = L.check
         ck(lib.lz_net_forward_packed_f16(C.byref(self.net.desc), p(self.root_packed), L.i64(B), p(self.lp1), p(self.lp2),
@@ -96,14 +98,23 @@ class FusedRootSearch:
                                             L.i64(TOTAL_ACTION_DIM), p(self.temps), p(self.uniforms) if sample else None,
                                             p(self.policy_dense), p(self.chosen_idx), p(self.chosen_codes),
                                             p(self.chosen_valid), p(self.root_value_vec), st), "root_finalize")
+        if forced:                                           # opening plies (mcts_gpu.py:1425-1447): uniform picks replace the search's
+            ck(lib.lz_root_force_uniform_picks(p(self.legal_index), p(self.codes), p(self.valid), p(self.roots), L.i64(B),
+                                               L.i64(CAP), p(self.force), p(self.force_uniforms), p(self.chosen_idx),
+                                               p(self.chosen_codes), p(self.chosen_valid), st), "root_force_uniform_picks")
 
     def search_batch(self, state: GpuStateBatch, *, temperatures: torch.Tensor, add_dirichlet_noise: Optional[bool] = None,
                      injected_noise: Optional[torch.Tensor] = None, injected_uniforms: Optional[torch.Tensor] = None,
                      want_output: bool = True, reset: Optional[torch.Tensor] = None,
                      rng_game_ids: Optional[torch.Tensor] = None,
-                     rng_plies: Optional[torch.Tensor] = None) -> Optional[RootSearchBatchOutput]:
+                     rng_plies: Optional[torch.Tensor] = None,
+                     force_uniform_random_mask: Optional[torch.Tensor] = None,
+                     injected_force_uniforms: Optional[torch.Tensor] = None) -> Optional[RootSearchBatchOutput]:
         """`reset` uint8[B]: slots whose game was re-seated since the last search (their RNG key moves on to the next
-        game id); `rng_game_ids` / `rng_plies`: the runner's own numbering instead."""
+        game id); `rng_game_ids` / `rng_plies`: the runner's own numbering instead.
+        `force_uniform_random_mask` bool[B] (the reference's opening plies, v1/python/mcts_gpu.py:1255-1272,1425-1447):
+        flagged games play a uniformly random legal move, drawn from the per-game RNG (purpose OPENING); their policy
+        target is still the search's."""
         B, dev = self.B, self.device
         if int(state.batch_size) != B:
             raise ValueError(f"FusedRootSearch was built for {B} games, got {int(state.batch_size)}")
@@ -125,19 +136,26 @@ class FusedRootSearch:
                 self.uniforms.copy_(injected_uniforms.to(torch.float32))
             else:
                 self.rng.uniform_into(self.uniforms, PURPOSE_PICK)
+        forced = force_uniform_random_mask is not None
+        if forced:
+            self.force.copy_(force_uniform_random_mask.reshape(-1).to(torch.uint8))
+            if injected_force_uniforms is not None:
+                self.force_uniforms.copy_(injected_force_uniforms.to(torch.float32))
+            else:
+                self.rng.uniform_into(self.force_uniforms, PURPOSE_OPENING)
         self.rng.end_move(rng_plies is not None)
-        key = (add_noise, sample)
+        key = (add_noise, sample, forced)
         with torch.cuda.device(dev):
             if not self.use_graph:
-                self._launch(add_noise, sample)
+                self._launch(add_noise, sample, forced)
             else:
                 g = self._graphs.get(key)
                 if g is None:
-                    self._launch(add_noise, sample)                  # warm-up (idempotent: every buffer is rewritten)
+                    self._launch(add_noise, sample, forced)          # warm-up (idempotent: every buffer is rewritten)
                     torch.cuda.synchronize(dev)
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g):
-                        self._launch(add_noise, sample)
+                        self._launch(add_noise, sample, forced)
                     self._graphs[key] = g
                 g.replay()
         self._evals_dev.add_(self.n_children).add_(B)
@@ -208,7 +226,8 @@ class DualStreamRootSearch:
     def search_batch(self, state: GpuStateBatch, *, temperatures: torch.Tensor, add_dirichlet_noise: Optional[bool] = None,
                      injected_noise: Optional[torch.Tensor] = None, injected_uniforms: Optional[torch.Tensor] = None,
                      reset: Optional[torch.Tensor] = None, rng_game_ids: Optional[torch.Tensor] = None,
-                     rng_plies: Optional[torch.Tensor] = None) -> RootSearchBatchOutput:
+                     rng_plies: Optional[torch.Tensor] = None,
+                     force_uniform_random_mask: Optional[torch.Tensor] = None) -> RootSearchBatchOutput:
         if int(state.batch_size) != self.B:
             raise ValueError(f"DualStreamRootSearch was built for {self.B} games, got {int(state.batch_size)}")
         main = torch.cuda.current_stream(self.device)
@@ -220,7 +239,8 @@ class DualStreamRootSearch:
                                   add_dirichlet_noise=add_dirichlet_noise, injected_noise=cut(injected_noise, a, b),
                                   injected_uniforms=cut(injected_uniforms, a, b), want_output=False,
                                   reset=cut(reset, a, b), rng_game_ids=cut(rng_game_ids, a, b),
-                                  rng_plies=cut(rng_plies, a, b))
+                                  rng_plies=cut(rng_plies, a, b),
+                                  force_uniform_random_mask=cut(force_uniform_random_mask, a, b))
         if not self.serialize:
             for st in self.streams:
                 main.wait_stream(st)

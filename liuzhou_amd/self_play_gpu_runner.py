@@ -24,8 +24,9 @@ _TRACKED = ("root_puct_ms", "pack_writeback_ms", "self_play_step_ms", "finalize_
 def streaming_supported(model, *, opening_random_moves: int = 0, child_eval_mode: str = "value_only", sparse_ply: int = 1,
                         inference_engine=None, collect_step_timing: bool = False) -> bool:
     """True when `self_play_v1_gpu` would take the fused search + device tail for these options, i.e. when it can feed a
-    finished-row log (`row_log`)."""
-    return (hasattr(model, "desc") and inference_engine is None and int(opening_random_moves) == 0 and
+    finished-row log (`row_log`).  (`opening_random_moves` is covered by the fused search since round 5 -- the reference's
+    training script starts with 6, scripts/big_train_v1.sh:42.)"""
+    return (hasattr(model, "desc") and inference_engine is None and
             str(child_eval_mode) == "value_only" and int(sparse_ply) <= 1 and not collect_step_timing and
             os.environ.get("LZ_WAVE_TAIL", "1") != "0")
 
@@ -61,11 +62,15 @@ def self_play_v1_gpu(model, num_games: int, mcts_simulations: int, temperature_i
     # fused network, a fixed batch (finished games of the wave are searched too and their rows dropped) and none of
     # the options only the operator chain implements.
     fused = None
-    if (fused_search and hasattr(model, "desc") and inference_engine is None and opening_n == 0 and
+    if (fused_search and hasattr(model, "desc") and inference_engine is None and
             str(child_eval_mode) == "value_only" and int(sparse_ply) <= 1 and not collect_step_timing and
             (int(num_games) % wave == 0 or continuous_waves)):
         from .root_search_fused import FusedRootSearch
-        fused = FusedRootSearch(model, wave, cfg.num_simulations, dev, exploration_weight=cfg.exploration_weight,
+        # The reference draws noise and moves from the process's torch generator, which its worker seeds per shard
+        # (v1/python/self_play_worker.py:300-303 `torch.manual_seed(seed)`); the per-game counter RNG here takes its key
+        # from that generator, so workers / chunks seeded differently play different games and a seed reproduces its games
+        rng_seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        fused = FusedRootSearch(model, wave, cfg.num_simulations, dev, seed=rng_seed, exploration_weight=cfg.exploration_weight,
                                 add_dirichlet_noise=cfg.add_dirichlet_noise, dirichlet_alpha=cfg.dirichlet_alpha,
                                 dirichlet_epsilon=cfg.dirichlet_epsilon, sample_moves=cfg.sample_moves,
                                 soft_value_k=cfg.soft_value_k)
@@ -111,8 +116,12 @@ def self_play_v1_gpu(model, num_games: int, mcts_simulations: int, temperature_i
         done = torch.zeros((g,), dtype=torch.bool, device=dev)
         ones = torch.ones((g,), dtype=torch.int64, device=dev)
         if tail is not None:
-            tail.run(lambda st, temps, dn, reseated: fused.search_batch(st, temperatures=temps,
-                                                                        add_dirichlet_noise=add_dirichlet_noise),
+            # reset / game ids / plies: the runner's own numbering keys the per-game RNG (noise, picks, opening moves), so a
+            # game's draws do not depend on the slot or the moment it is played
+            tail.run(lambda st, temps, dn, reseated: fused.search_batch(
+                         st, temperatures=temps, add_dirichlet_noise=add_dirichlet_noise,
+                         rng_game_ids=tail.slot_game + (0 if continuous else base), rng_plies=plies,
+                         force_uniform_random_mask=(plies < opening_n) if opening_n > 0 else None),
                      states, plies, done, step_index, step_counts, lengths if continuous else lengths[base:base + g],
                      temperature_init, temperature_final, temperature_threshold,
                      games_to_start=int(num_games) - wave if continuous else 0)

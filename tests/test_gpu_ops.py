@@ -507,3 +507,39 @@ def test_model_fp32_matches_reference_outputs(v0):
             out = m(x)
         for got, k in zip(out, ("lp1", "lp2", "lpmc", "value_logits")):
             np.testing.assert_allclose(got.cpu().numpy(), z[f"{name}_{k}"], atol=1e-5, rtol=0, err_msg=f"{name}/{k}")
+
+
+def test_root_force_uniform_picks():
+    """lz_root_force_uniform_picks (opening plies, mcts_gpu.py:1425-1447): the k-th valid slot, k = min(floor(u n), n - 1),
+    only for flagged roots; unflagged roots and rows without a valid slot keep the search's pick."""
+    if not torch.cuda.is_available() or DEV == "cpu":
+        pytest.skip("HIP only")
+    from liuzhou_amd import _lib as L
+    rng = np.random.default_rng(9)
+    B, R, M = 300, 260, 80
+    roots = np.sort(rng.choice(B, R, replace=False)).astype(np.int64)
+    valid = rng.random((R, M)) < 0.3
+    valid[0] = False; valid[1] = True; valid[2] = False; valid[2, 79] = True
+    lidx = rng.integers(0, 220, (R, M)).astype(np.int64)
+    codes = rng.integers(-1, 36, (R, M, 4)).astype(np.int32)
+    force = rng.random(B) < 0.6
+    force[roots[:3]] = True
+    u = rng.random(R).astype(np.float32); u[1] = 0.999999; u[3] = 0.0
+    cidx0 = rng.integers(0, 220, B).astype(np.int64); cc0 = rng.integers(0, 9, (B, 4)).astype(np.int32)
+    cv0 = np.zeros(B, bool)
+    t = lambda x: torch.from_numpy(x).to(DEV)
+    d = dict(lidx=t(lidx), codes=t(codes), valid=t(valid), roots=t(roots), force=t(force), u=t(u), cidx=t(cidx0.copy()),
+             cc=t(cc0.copy()), cv=t(cv0.copy()))
+    L.check(L.lib().lz_root_force_uniform_picks(L.ptr(d["lidx"]), L.ptr(d["codes"]), L.ptr(d["valid"]), L.ptr(d["roots"]),
+                                                L.i64(R), L.i64(M), L.ptr(d["force"]), L.ptr(d["u"]), L.ptr(d["cidx"]),
+                                                L.ptr(d["cc"]), L.ptr(d["cv"]), L.stream_ptr(torch.device(DEV))), "force")
+    want_idx, want_cc, want_cv = cidx0.copy(), cc0.copy(), cv0.copy()
+    for r in range(R):
+        b = roots[r]
+        slots = np.nonzero(valid[r])[0]
+        if not force[b] or len(slots) == 0:
+            continue
+        k = min(int(np.float32(u[r]) * np.float32(len(slots))), len(slots) - 1)
+        want_idx[b], want_cc[b], want_cv[b] = lidx[r, slots[k]], codes[r, slots[k]], True
+    assert np.array_equal(d["cidx"].cpu().numpy(), want_idx) and np.array_equal(d["cc"].cpu().numpy(), want_cc)
+    assert np.array_equal(d["cv"].cpu().numpy(), want_cv)
