@@ -14,7 +14,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 import time
-from typing import Dict, Optional, Tuple
+from typing import Dict, List, Optional, Tuple
 
 import torch
 
@@ -869,6 +869,16 @@ class DualStreamTreeMCTS:
                                                game_offset=a, game_stride=self.B, **kw))
         self.sims = int(num_simulations)
         self.serialize = False        # measurement aid: run the halves one after the other on the caller's stream
+        # Overlap watch.  A probed pair of streams can still end up on one hardware queue later (the runtime maps streams
+        # to its 4 queues when they become active; other streams of the process come and go): the halves then run one
+        # after the other, +50 % per ply, for the rest of the run (seen in ~1 of 6 worker runs inside a long-lived
+        # process).  So the first searches, and every 64th after them, are bracketed by events; a search whose two halves
+        # did not overlap (union of the two intervals ~ their sum) twice in a row makes the engine draw new streams.
+        self._watch: List[List[torch.cuda.Event]] = []
+        self._watch_left = 6
+        self._searches = 0
+        self._serial_seen = 0
+        self.stream_redraws = 0
 
     @property
     def leaf_evals(self) -> int:
@@ -899,6 +909,33 @@ class DualStreamTreeMCTS:
     def reset_run(self, seed: int) -> None:
         for p in self.parts:
             p.reset_run(seed)
+        self._watch, self._watch_left, self._searches, self._serial_seen = [], 6, 0, 0
+
+    def _check_overlap(self) -> None:
+        """Look at finished overlap brackets (never waits) and re-draw the streams if the halves ran one after the other."""
+        self._searches += 1
+        if self._watch_left <= 0 and self._searches % 64 == 0:
+            self._watch_left = 2
+        while self._watch and all(e.query() for e in self._watch[0]):
+            s0, e0, s1, e1 = self._watch.pop(0)
+            self._watch_left -= 1
+            d0, d1 = s0.elapsed_time(e0), s1.elapsed_time(e1)
+            lead = s0.elapsed_time(s1)                           # start of part 1 relative to part 0 (ms, may be < 0)
+            union = max(d0, lead + d1) - min(0.0, lead)
+            if d0 > 1.0 and d1 > 1.0 and union > 0.9 * (d0 + d1):
+                self._serial_seen += 1
+                self._watch_left = max(self._watch_left, 2)
+                if self._serial_seen >= 2 and self.stream_redraws < 6:
+                    from .streams import overlapping_streams
+                    self._old_streams = getattr(self, "_old_streams", []) + list(self.streams)   # keep them: work may be queued
+                    self.streams = overlapping_streams(self.device, len(self.parts))
+                    self.stream_redraws += 1
+                    self._serial_seen = 0
+                    self._watch_left = 4
+                    self._watch.clear()
+                    return
+            else:
+                self._serial_seen = 0
 
     @property
     def graph_retry_off(self) -> bool:
@@ -923,14 +960,24 @@ class DualStreamTreeMCTS:
         main = torch.cuda.current_stream(self.device)
         cut = lambda t, a, b: None if t is None else t[a:b]
         outs = []
+        self._check_overlap()
         streams = (main,) * len(self.parts) if self.serialize else self.streams
         subs = [state._map(lambda t, a=a, b=b: t[a:b]) for a, b in self.bounds]
-        for (a, b), part, st, sub in zip(self.bounds, self.parts, streams, subs):     # launch every part first ...
+        watch = None
+        if not self.serialize and len(self.parts) == 2 and self._watch_left > 0:
+            watch = [torch.cuda.Event(enable_timing=True) for _ in range(4)]           # start / end of the two searches
+        for i, ((a, b), part, st, sub) in enumerate(zip(self.bounds, self.parts, streams, subs)):     # launch every part first ...
             st.wait_stream(main)
             with torch.cuda.stream(st):
+                if watch is not None:
+                    watch[2 * i].record(st)
                 part.launch_search(sub, active=cut(active, a, b), add_dirichlet_noise=add_dirichlet_noise,
                                    reset=cut(reset, a, b), played_action=cut(played_action, a, b),
                                    rng_game_ids=cut(rng_game_ids, a, b), rng_plies=cut(rng_plies, a, b), compact=compact)
+                if watch is not None:
+                    watch[2 * i + 1].record(st)
+        if watch is not None:
+            self._watch.append(watch)
         todo = list(zip(self.parts, streams))                  # leftover rounds (batch_k > 1): the parts take turns,
         while todo:                                            # so that their small rounds overlap on the device
             nxt = []
@@ -1227,7 +1274,7 @@ def self_play_tree_gpu(model, num_games: int, mcts_simulations: int, temperature
                        # build() of the five tensors; graph capture happens inside the first plies
                        "engine_cache_hit": int(cache_hit), "setup_ms": int(setup_sec * 1e3), "build_ms": int(build_sec * 1e3),
                        "reuse_pruned": pruned, "reuse_dropped": dropped, "edge_pool_refused": refused,
-                       "final_sync_ms": int(sync_ms),
+                       "final_sync_ms": int(sync_ms), "stream_redraws": int(getattr(mcts, "stream_redraws", 0)),
                        **({"loop_ms": int(tail.loop_ms), "host_wait_ms": int(tail.host_wait_ms),
                            "plies_launched": int(tail.plies_launched)} if tail is not None else {})},
         piece_delta_buckets={str(d - 18): int(v) for d, v in enumerate(hist)}, device=str(dev))

@@ -6,7 +6,7 @@ from liuzhou_amd.net import ChessNet, MODEL_CONFIGS
 from liuzhou_amd.self_play_worker import run_self_play_worker
 from liuzhou_amd.tree_engine import clear_engine_cache
 
-def one(backend, model_name, games, slots, sims, stream, extra_env=None):
+def one(backend, model_name, games, slots, sims, stream, extra_env=None, opening=0):
     os.environ["LZ_WORKER_STREAM"] = "1" if stream else "0"
     for k, v in (extra_env or {}).items():
         os.environ[k] = v
@@ -20,14 +20,14 @@ def one(backend, model_name, games, slots, sims, stream, extra_env=None):
                                    model_state_path=os.path.join(tmp, "m.pt"), output_path=os.path.join(tmp, "w.pt"),
                                    mcts_simulations=sims, temperature_init=1.0, temperature_final=0.1, temperature_threshold=10,
                                    exploration_weight=1.0, dirichlet_alpha=0.3, dirichlet_epsilon=0.25, soft_value_k=2.0,
-                                   opening_random_moves=0, max_game_plies=512, concurrent_games_per_device=slots,
+                                   opening_random_moves=opening, max_game_plies=512, concurrent_games_per_device=slots,
                                    chunk_output_dir=tmp, chunk_file_prefix="w", search_backend=backend)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         man = torch.load(os.path.join(tmp, "w.pt"), map_location="cpu")
         st = man["stats"]
         print(json.dumps({"backend": backend, "stream": stream, "env": extra_env, "elapsed_s": round(dt, 2),
-                          "positions_per_s": round(res["num_samples"] / dt), "positions": res["num_samples"],
+                          "positions_per_s": round(res["num_samples"] / dt), "positions": res["num_samples"], "opening": opening,
                           "runner_elapsed": round(st.get("elapsed_sec", 0), 2), "chunks": res["saved_chunks"],
                           "timing_ms": {k: round(v) for k, v in st.get("step_timing_ms", {}).items()},
                           "counters": st.get("mcts_counters")}), flush=True)
@@ -39,6 +39,9 @@ def one(backend, model_name, games, slots, sims, stream, extra_env=None):
 
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "tree"
+    if which == "opening":
+        for op in (6, 0, 6, 0, 6, 0):
+            one("portable", "b6c64", 8192, 4096, 200, True, opening=op)
     if which == "tree":
         pass
         one("cuda_root", "b10c128", 32768, 16384, 1024, True)
