@@ -627,6 +627,7 @@ class PortableTreeMCTS:
             self._search_split(noise, continue_trees)
             return
         lists = bool(getattr(self, "compact_now", self.compact_default)) and e.compact_evals
+        self.list_searches = getattr(self, "list_searches", 0) + int(lists)      # searches that used the compact lists
         if not self.use_graph:
             e.search(self.net, self.sims, noise, self.eps, continue_trees, compact=lists)
             return
@@ -1269,6 +1270,7 @@ def self_play_tree_gpu(model, num_games: int, mcts_simulations: int, temperature
         mcts_counters={"leaf_eval_count": int(mcts.leaf_evals) - (wasted_plies * wave * (int(mcts_simulations) + 1)
                                                                   if int(batch_k) <= 1 and not compact_lists else 0),
                        "compact_eval_lists": int(compact_lists),
+                       "list_searches": int(sum(getattr(p, "list_searches", 0) for p in (getattr(mcts, "parts", None) or [mcts]))),
                        "masked_extra_plies": wasted_plies, "graph_retry_off": int(bool(mcts.graph_retry_off)),
                        # where the wall time outside `elapsed_sec` (the plies) goes: engine construction or cache hit,
                        # build() of the five tensors; graph capture happens inside the first plies

@@ -456,3 +456,42 @@ def test_fused_root_search_rng_is_independent_of_the_batch_split():
             v0_core.self_play_step_inplace(*s.tensors(), p, d, torch.arange(B, device=dev), o.chosen_action_codes.clone(),
                                            o.terminal_mask.clone(), o.chosen_valid_mask.clone(), 512, 2.0)
     assert differs
+
+
+def test_tree_runner_switches_to_compact_lists_in_the_drain_and_plays_the_same_games(monkeypatch):
+    """The product default of an engine whose full launch is several network passes per CU (10x128, 4 096 slots = 2
+    passes): dense launches while nearly all games are live, compact evaluation lists once the wave has drained by a pass
+    per CU (WaveTail.live_estimate, two plies old).  One full-length wave played three ways -- dense only, lists always,
+    automatic -- gives byte-identical trajectories; the automatic run used both launch forms."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from liuzhou_amd.net import ChessNet, MODEL_CONFIGS
+    from liuzhou_amd.net_hip import FusedNet
+    from liuzhou_amd.tree_engine import clear_engine_cache, self_play_tree_gpu
+    torch.manual_seed(20260314)
+    net = FusedNet(ChessNet(**MODEL_CONFIGS["b10c128"]).eval().to("cuda:0"))
+    out = {}
+    for mode in ("0", "1", "auto"):
+        if mode == "auto":
+            monkeypatch.delenv("LZ_TREE_COMPACT", raising=False)
+        else:
+            monkeypatch.setenv("LZ_TREE_COMPACT", mode)
+        batch, st = self_play_tree_gpu(net, num_games=4096, mcts_simulations=6, temperature_init=1.0, temperature_final=0.1,
+                                       temperature_threshold=10, exploration_weight=1.0, device="cuda:0",
+                                       add_dirichlet_noise=True, sample_moves=True, concurrent_games=4096,
+                                       max_game_plies=512, seed=77)
+        out[mode] = (batch, st)
+        clear_engine_cache()
+    ref = out["0"][0]
+    for mode in ("1", "auto"):
+        b = out[mode][0]
+        for f in ("state_tensors", "legal_masks", "policy_targets", "value_targets", "soft_value_targets"):
+            assert torch.equal(getattr(b, f), getattr(ref, f)), (mode, f)
+    c0, c1, ca = (out[m][1].mcts_counters for m in ("0", "1", "auto"))
+    plies = ca["plies_launched"]
+    assert c0["list_searches"] == 0 and c0["compact_eval_lists"] == 0
+    assert c1["list_searches"] >= plies - 1 and ca["compact_eval_lists"] == 1
+    assert 0 < ca["list_searches"] < plies - 8                      # dense first, lists in the drain
+    assert ca["leaf_eval_count"] < c0["leaf_eval_count"] and c1["leaf_eval_count"] <= ca["leaf_eval_count"]
+    print(f"{plies} plies: lists in {ca['list_searches']} of them; launched evaluations dense {c0['leaf_eval_count']}, "
+          f"auto {ca['leaf_eval_count']}, lists always {c1['leaf_eval_count']}")
