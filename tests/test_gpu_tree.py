@@ -689,6 +689,43 @@ def test_compact_evaluation_lists_equal_the_dense_search(model_name, games, sims
     print(f"compact lists {model_name}: launched {got.leaf_evals} of the dense search's {dense.leaf_evals}")
 
 
+def test_alternating_launch_forms_over_consecutive_moves_equal_the_dense_search():
+    """An engine built for both launch forms (what the runner gets when a full launch is several network passes per CU)
+    switches between dense launches and compact lists from move to move -- fresh search, continued searches with kept
+    subtrees, each form captured as its own graph on first use -- and ends with the dense engine's trees, byte for byte."""
+    _need_gpu()
+    from liuzhou_amd.net import ChessNet, MODEL_CONFIGS
+    from liuzhou_amd.net_hip import FusedNet
+    from liuzhou_amd.tree_engine import PortableTreeMCTS
+    from tests.tree_parity import root_edges, EDGE_LOGICAL, to_gpu_batch
+    from tests.golden_utils import load, states as gstates
+    torch.manual_seed(20260314)
+    net = FusedNet(ChessNet(**MODEL_CONFIGS["b6c64"]).eval().to(DEV))
+    st_all = gstates(load("g1_rules.npz"), "s")
+    idx = np.random.default_rng(5).integers(0, st_all["board"].shape[0], 96)
+    cur = {f: np.ascontiguousarray(np.asarray(st_all[f])[idx]) for f in FIELDS}
+    kw = dict(exploration_weight=1.0, add_dirichlet_noise=True, sample_moves=True, reuse_tree=True, reuse_factor=4.0, seed=99)
+    dense = PortableTreeMCTS(net, 96, 64, DEV, compact_evals=False, **kw)
+    both = PortableTreeMCTS(net, 96, 64, DEV, compact_evals=True, **kw)
+    both.compact_default = False                                   # as the automatic choice builds it: dense unless told otherwise
+    temps = torch.ones((96,), device=DEV)
+    for move, form in enumerate([False, True, True, False, True]):
+        batch = to_gpu_batch(cur, DEV)
+        a = dense.search_batch(batch, temperatures=temps)
+        b = both.search_batch(batch, temperatures=temps, compact=form)
+        torch.cuda.synchronize()
+        for x, y in zip(root_edges(both.engine), root_edges(dense.engine)):
+            assert all(x[f].tobytes() == y[f].tobytes() for f in EDGE_LOGICAL), (move, form)
+        assert torch.equal(a.chosen_action_indices, b.chosen_action_indices) and torch.equal(a.policy_dense, b.policy_dense)
+        # play the picked moves (the oracle's transition), so that the next search continues kept subtrees
+        from oracle import lz_oracle as O
+        pick = a.chosen_action_indices.cpu().numpy()
+        nxt = [O.apply_index(O.state_from_batch(cur, i), int(pick[i])) if pick[i] >= 0 else O.state_from_batch(cur, i) for i in range(96)]
+        cur = O.batch_from_states(nxt)
+    assert both.list_searches == 3 and both.use_graph and not both.graph_retry_off
+    assert len(both._graphs) >= 3                                  # fresh-dense, continued-lists, continued-dense
+
+
 def test_production_search_direct_launches_equal_graph_replay():
     """The same search with direct launches (LZ_TREE_GRAPH=off path) and as a replayed hipGraph: identical trees."""
     _need_gpu()
