@@ -628,6 +628,7 @@ class PortableTreeMCTS:
             return
         lists = bool(getattr(self, "compact_now", self.compact_default)) and e.compact_evals
         self.list_searches = getattr(self, "list_searches", 0) + int(lists)      # searches that used the compact lists
+        self.last_search_lists = lists
         if not self.use_graph:
             e.search(self.net, self.sims, noise, self.eps, continue_trees, compact=lists)
             return
@@ -1267,8 +1268,10 @@ def self_play_tree_gpu(model, num_games: int, mcts_simulations: int, temperature
         step_timing_calls={k: int(timing["timing_calls"].get(k, 0)) for k in keys},
         # the device-tail loop runs one fully masked ply per wave after the last game has ended (wave_tail.WaveTail.run)
         # (with compact evaluation lists a fully masked ply launches no evaluation at all)
-        mcts_counters={"leaf_eval_count": int(mcts.leaf_evals) - (wasted_plies * wave * (int(mcts_simulations) + 1)
-                                                                  if int(batch_k) <= 1 and not compact_lists else 0),
+        # (... unless that ply was launched densely: the two-plies-old live estimate had not seen the wave end yet)
+        mcts_counters={"leaf_eval_count": int(mcts.leaf_evals) - (
+                           wasted_plies * wave * (int(mcts_simulations) + 1)
+                           if int(batch_k) <= 1 and not (compact_lists and getattr(mcts, "last_search_lists", False)) else 0),
                        "compact_eval_lists": int(compact_lists),
                        "list_searches": int(sum(getattr(p, "list_searches", 0) for p in (getattr(mcts, "parts", None) or [mcts]))),
                        "masked_extra_plies": wasted_plies, "graph_retry_off": int(bool(mcts.graph_retry_off)),
