@@ -14,6 +14,7 @@ from . import _lib as L
 from .game_rng import GameRng, PURPOSE_OPENING, PURPOSE_PICK
 from .mcts_gpu import GpuStateBatch, RootSearchBatchOutput, TOTAL_ACTION_DIM, encode_actions_fast, states_to_model_input
 from .net_hip import FusedNet
+from .streams import CAPTURE_MODE
 
 CAP = 72
 
@@ -154,7 +155,7 @@ class FusedRootSearch:
                     self._launch(add_noise, sample, forced)          # warm-up (idempotent: every buffer is rewritten)
                     torch.cuda.synchronize(dev)
                     g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g):
+                    with torch.cuda.graph(g, capture_error_mode=CAPTURE_MODE):
                         self._launch(add_noise, sample, forced)
                     self._graphs[key] = g
                 g.replay()

@@ -76,3 +76,10 @@ def overlapping_streams(device, k: int = 2, max_tries: int = 12) -> Tuple[torch.
 
 
 overlapping_streams.last_rejected = 0
+
+
+# Stream capture mode of every hipGraph this package records.  "thread_local": only the CAPTURING thread is held to the
+# capture rules.  The default ("global") lets an allocation or a pinned-memory call made by ANY thread invalidate a capture
+# in progress -- and the streaming worker has a copier thread that pins staging buffers and copies segments while the
+# playing thread may be capturing a launch form it meets for the first time (the compact lists, in the drain of a wave).
+CAPTURE_MODE = "thread_local"

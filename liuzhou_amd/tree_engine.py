@@ -27,6 +27,7 @@ from .mcts_gpu import GpuStateBatch, RootSearchBatchOutput, TOTAL_ACTION_DIM, st
     encode_actions_fast
 from .net_hip import FusedNet, LzNetDesc
 from .self_play_types import SelfPlayV1Stats
+from .streams import CAPTURE_MODE
 from .trajectory_buffer import TensorSelfPlayBatch, TensorTrajectoryBuffer
 
 MAX_CHILDREN = 72
@@ -650,7 +651,7 @@ class PortableTreeMCTS:
             torch.cuda.synchronize(e.device)
             try:
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                with torch.cuda.graph(g, capture_error_mode=CAPTURE_MODE):
                     e.search(self.net, self.sims, noise, self.eps, continue_trees, compact=lists)
                 if os.environ.get("LZ_TREE_GRAPH_FAULT", "") == "capture":      # test hook: pretend the capture failed
                     raise RuntimeError("injected stream capture failure (LZ_TREE_GRAPH_FAULT=capture)")
@@ -707,7 +708,7 @@ class PortableTreeMCTS:
             if self._tail_graph is None:
                 torch.cuda.synchronize(e.device)
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                with torch.cuda.graph(g, capture_error_mode=CAPTURE_MODE):
                     e.search_waves(self.net, self.sims, 8, skip_roots=True)
                 self._tail_graph = g
             self._tail_graph.replay()
