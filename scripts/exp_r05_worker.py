@@ -39,6 +39,10 @@ def one(backend, model_name, games, slots, sims, stream, extra_env=None, opening
 
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "tree"
+    if which == "reference_shape":
+        # one worker of scripts/big_train_v1.sh's defaults: 522 488 games / 8 devices ~ 65 536 games on 8 192 slots,
+        # opening_random_moves 6, 10x128 (sims 1 024 here)
+        one("cuda_root", "b10c128", 65536, 8192, 1024, True, opening=6)
     if which == "opening":
         for op in (6, 0, 6, 0, 6, 0):
             one("portable", "b6c64", 8192, 4096, 200, True, opening=op)
