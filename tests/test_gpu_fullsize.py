@@ -127,6 +127,23 @@ def _pool_ok(pop, max_tree_gbytes):
     return total / 2**30
 
 
+def _advance_launch_us(fn):
+    """Average duration of the `tree_advance_kernel` launches inside `fn()` (HIP events around the launch,
+    lz_prof_aux_summary kind 1) -- the one kernel whose cost grows with the arenas, bounded by its slowest wave."""
+    import ctypes
+    from liuzhou_amd import _lib as LZ
+    LZ.check(LZ.lib().lz_prof_enable(1), "prof_enable")
+    try:
+        out = fn()
+        torch.cuda.synchronize()
+        ms, n, units = ctypes.c_double(0.0), ctypes.c_int64(0), ctypes.c_int64(0)
+        LZ.check(LZ.lib().lz_prof_aux_summary(1, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(units)), "prof_aux_summary")
+    finally:
+        LZ.lib().lz_prof_enable(0)
+    assert n.value >= 1, "no tree_advance_kernel launch was bracketed"
+    return out, ms.value / n.value * 1e3
+
+
 def test_c2_full_size_three_moves_and_same_seed_same_games():
     """C2 = 4 096 concurrent games, 200 simulations per move, 6x64 net, two streams: three consecutive moves with kept
     subtrees, checked move by move; a second population with the same seed plays bit-identical moves."""
@@ -136,7 +153,11 @@ def test_c2_full_size_three_moves_and_same_seed_same_games():
     for _ in range(2):
         pop = _population("b6c64", 4096, 200, 3, seed=9973, reuse_factor=8.0)
         assert pop.dual_stream and all(e.B == 2048 for e in _engines(pop))
-        steps = [_checked_step(pop, 200, first_move=(k == 0)) for k in range(3)]
+        steps = [_checked_step(pop, 200, first_move=True), _checked_step(pop, 200, first_move=False)]
+        # timing guard of the subtree compaction at scale: 65 - 180 us per half-batch launch measured
+        last, adv_us = _advance_launch_us(lambda: _checked_step(pop, 200, first_move=False))
+        steps.append(last)
+        assert adv_us < 600.0, f"tree_advance_kernel took {adv_us:.0f} us per launch at C2"
         kept_any = any(int((e.buf["root_visits"] > 200).sum()) > 0 for e in _engines(pop))
         assert kept_any, "no game kept a subtree over three moves"
         assert _dropped(pop) == [0, 0]
@@ -163,13 +184,14 @@ def test_c3_full_size_one_move_and_one_continued_move():
     pop = _population("b10c128", 16384, 800, 2, seed=9973)
     assert not pop.dual_stream and pop.mcts.use_graph
     _checked_step(pop, 800, first_move=True)
-    _checked_step(pop, 800, first_move=False)
+    _, adv_us = _advance_launch_us(lambda: _checked_step(pop, 800, first_move=False))
+    assert adv_us < 6000.0, f"tree_advance_kernel took {adv_us:.0f} us per launch at C3"      # 0.8 - 2.0 ms measured
     e = _engines(pop)[0]
     assert int((e.buf["root_visits"] > 800).sum()) > 0, "no game continued a kept subtree"
     assert not pop.mcts.graph_retry_off
     assert _dropped(pop) == [0, 0]
     # round 4: 24 GB of node arenas + 38.5 GB of edge pool (rounds 1-3: ~210 GB of worst-case regions per game)
-    print(f"C3 full size: arena factor {e.reuse_factor}, [dropped, pruned] subtrees {_dropped(pop)}, "
+    print(f"C3 full size: tree_advance_kernel {adv_us:.0f} us; arena factor {e.reuse_factor}, [dropped, pruned] subtrees {_dropped(pop)}, "
           f"tree memory {_pool_ok(pop, 120.0):.1f} GiB")
     del pop, e
     gc.collect()
