@@ -25,8 +25,6 @@ import torch
 
 from . import _lib as L
 
-_FIELDS = ("state", "legal", "policy", "value", "soft")
-
 
 @dataclass
 class LogArena:
