@@ -617,38 +617,80 @@ __global__ __launch_bounds__(kBlock) void root_puct_kernel(const float* __restri
 //     from every rounding boundary of fp32 -- x = m * d has no solution for a 25-bit odd midpoint m -- so the rounded
 //     result IS the correctly rounded quotient.  The bound needs a normal quotient: waves whose priors or leaf values
 //     hold non-zero magnitudes below 2^-100 (never seen; the denormal range allows exact ties) take the division path.
-//   * rd[1 + visits] / rd[visits] sit in registers per action; only the pulled action reloads one entry, one pull ahead.
+//   * rd[1 + visits] sits in a register pair per action; only the pulled action reloads it (PullState below).
 // Bit-identical visits / value sums by construction; checked against the division kernel and the reference op (g6).
 constexpr int kPuctTable = 65536;                 // pulls covered by the tables
-__device__ float g_puct_sqrt[kPuctTable];         // sqrtf(sim + 1)
+__device__ float g_puct_sqrt[kPuctTable + 1];     // sqrtf(sim + 1); one entry more than pulls: the loops read one ahead
 __device__ double g_puct_recip[kPuctTable + 3];   // 1.0 / d, d = 1 .. kPuctTable + 2 ([0] unused)
 __global__ void puct_tables_kernel() {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < kPuctTable) g_puct_sqrt[i] = sqrtf((float)i + 1.0f);
+    if (i < kPuctTable + 1) g_puct_sqrt[i] = sqrtf((float)i + 1.0f);
     if (i < kPuctTable + 3) g_puct_recip[i] = i > 0 ? 1.0 / (double)i : 0.0;
 }
 
 __device__ __forceinline__ float div_by_int(float x, double rd) { return (float)((double)x * rd); }
 
+// The pull loops get the tables as a kernel argument: the bases sit in scalar registers for the whole loop (addressed
+// through the variables, the compiler re-derived the reciprocal table's address from the program counter at every pull),
+// and the sqrt table is read through the constant address space, where a uniform load is a scalar load whatever else the
+// kernel does (one pull ahead of its use).
+typedef const __attribute__((address_space(4))) float* ConstFloats;
+typedef const __attribute__((address_space(4))) char* ConstBytes;
+struct PuctTables { ConstFloats sqrt_tab; const double* __restrict__ recip_tab; };
+
+// sqrt(total + 1) of the pull being made, as a scalar one pull ahead of its use; the loop around it is a plain counted loop
+// (three scalar instructions).  There is no early exit when no action has a usable score (all NaN): nothing is pulled from
+// then on either way -- NaN scores stay NaN as sqrt(total) grows -- so the result is the same as the reference's `break`.
+struct SqrtStream {
+    ConstBytes tab;
+    uint32_t off, end;
+    float ahead;
+    __device__ __forceinline__ SqrtStream(const PuctTables T, int sims)
+        : tab((ConstBytes)T.sqrt_tab), off(0u), end(4u * (uint32_t)sims), ahead(*T.sqrt_tab) {}
+    __device__ __forceinline__ bool more() const { return off < end; }
+    __device__ __forceinline__ float next() {
+        const float now = ahead;
+        off += 4u;
+        ahead = *(ConstFloats)(tab + off);                        // the table holds one entry more than pulls can be asked for
+        return now;
+    }
+};
+
+// One action's running numbers.  Table form: rd = 1 / (1 + visits) as a double, so u = x / (1 + visits) and, after a pull,
+// q = value_sum / visits are one multiplication each (div_by_int above); the next reciprocal is fetched in the pulled lane
+// straight into `rd` (addressed by 8 * visits against the table's base in scalar registers) and is first needed at the
+// top of the next pull.
+template <bool EXACT_DIV>
+struct PullState {
+    float q = 0.f;
+    double rd = 1.0;
+    uint32_t nv8 = 0u;                                           // 8 * visits
+    __device__ __forceinline__ float score(float x, float vis) const {
+        return q + (EXACT_DIV ? x / (1.0f + vis) : div_by_int(x, rd));
+    }
+    __device__ __forceinline__ void pull(const PuctTables T, float lv, float& vis, float& vs) {
+        vis += 1.0f;
+        vs += lv;
+        q = EXACT_DIV ? vs / vis : div_by_int(vs, rd);
+        if (!EXACT_DIV) rd = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(T.recip_tab) + nv8 + 16u);
+        nv8 += 8u;
+    }
+};
+
 template <int SLOTS, bool EXACT_DIV>
-__device__ __forceinline__ void puct_pulls(int sims, int lane, int live, const float (&cp)[SLOTS], const float (&lv)[SLOTS],
+__device__ __forceinline__ void puct_pulls(const PuctTables T, int sims, int lane, int live, const float (&cp)[SLOTS], const float (&lv)[SLOTS],
                                            float (&vis)[SLOTS], float (&vs)[SLOTS]) {
-    float q[SLOTS];
-    double rd_u[SLOTS], rd_next[SLOTS];                          // 1 / (1 + visits), 1 / (2 + visits)
-    int nv[SLOTS];
-#pragma unroll
-    for (int j = 0; j < SLOTS; ++j) { q[j] = 0.f; nv[j] = 0; rd_u[j] = 1.0; rd_next[j] = 0.5; }
-    for (int sim = 0; sim < sims; ++sim) {
-        const float sqrt_total = g_puct_sqrt[sim];               // uniform address: a scalar load
+    PullState<EXACT_DIV> st[SLOTS];
+    SqrtStream sq(T, sims);
+    while (sq.more()) {
+        const float sqrt_total = sq.next();
         float sc[SLOTS];
         float best = -INFINITY;
 #pragma unroll
         for (int j = 0; j < SLOTS; ++j) {
             sc[j] = __builtin_nanf("");
             if (j < live) {
-                const float x = cp[j] * sqrt_total;
-                const float u = EXACT_DIV ? x / (1.0f + vis[j]) : div_by_int(x, rd_u[j]);
-                sc[j] = q[j] + u;
+                sc[j] = st[j].score(cp[j] * sqrt_total, vis[j]);
                 best = sc[j] > best ? sc[j] : best;
             }
         }
@@ -661,109 +703,82 @@ __device__ __forceinline__ void puct_pulls(int sims, int lane, int live, const f
                 if (hit != 0ull) chosen = j * kWave + __builtin_ctzll(hit);
             }
         }
-        if (chosen < 0) break;                                   // no candidate now means none later either
 #pragma unroll
-        for (int j = 0; j < SLOTS; ++j) {
-            if (chosen == j * kWave + lane) {
-                nv[j] += 1;
-                vis[j] += 1.0f;
-                vs[j] += lv[j];
-                const double rd_q = rd_u[j];                     // 1 / visits
-                rd_u[j] = rd_next[j];                            // 1 / (1 + visits)
-                if (!EXACT_DIV) rd_next[j] = g_puct_recip[nv[j] + 2];   // needed at this action's next pull
-                q[j] = EXACT_DIV ? vs[j] / vis[j] : div_by_int(vs[j], rd_q);
-            }
-        }
+        for (int j = 0; j < SLOTS; ++j)
+            if (chosen == j * kWave + lane) st[j].pull(T, lv[j], vis[j], vs[j]);
     }
 }
 
-// Two roots in one wave: root A on lanes 0-31, root B on lanes 32-63, when every valid action of both sits below index
-// 32 (the fused root search packs its rows to the left; most positions have fewer than 32 legal moves).  The same
-// arithmetic per lane as puct_pulls; the maximum is taken per half (the row_bcast:31 step of the reduction is left out,
-// lanes 31 / 63 hold the halves' maxima), one ballot serves both halves.  A pull costs the same instructions as for one
-// root, so a packed pair takes half the issue slots.
-__device__ __forceinline__ void half_max2(float v, float& lo, float& hi) {
-    asm volatile("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-                 "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
-                 "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
-                 "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
-                 "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-                 "s_nop 1"
-                 : "+v"(v));
-    lo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 31));
-    hi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+// Which lane of each group of `width` lanes (16 or 32) takes the pull: the lowest one whose score is the group's maximum.
+// Decided per lane from the ballot and two per-lane constants (the bits of the lane's group below the lane) -- three vector
+// instructions; finding the winners with scalar bit scans per group cost ~35 scalar instructions per pull, and the scalar
+// unit was what bounded the packed loops (round 5: profiles/r05_pmc_sq_bandit.md).
+__device__ __forceinline__ void group_below_masks(int lane, int width, uint32_t& below_lo, uint32_t& below_hi) {
+    const int first = lane & ~(width - 1);
+    const unsigned long long below = ((1ull << lane) - 1ull) & ~((1ull << first) - 1ull);
+    below_lo = (uint32_t)below;
+    below_hi = (uint32_t)(below >> 32);
+}
+__device__ __forceinline__ bool first_hit_of_group(bool is_hit, unsigned long long hit, uint32_t below_lo, uint32_t below_hi) {
+    return is_hit && ((((uint32_t)hit & below_lo) | ((uint32_t)(hit >> 32) & below_hi)) == 0u);
 }
 
-template <bool EXACT_DIV>
-__device__ __forceinline__ void puct_pulls_pair(int sims, int lane, float cp, float lv, float& vis, float& vs) {
-    float q = 0.f;
-    double rd_u = 1.0, rd_next = 0.5;
-    int nv = 0;
-    const bool upper = lane >= 32;
-    for (int sim = 0; sim < sims; ++sim) {
-        const float sqrt_total = g_puct_sqrt[sim];
-        const float x = cp * sqrt_total;
-        const float u = EXACT_DIV ? x / (1.0f + vis) : div_by_int(x, rd_u);
-        const float sc = q + u;                                  // NaN on lanes without a valid action
-        const float best = sc > -INFINITY ? sc : -INFINITY;
-        float m_lo, m_hi;
-        half_max2(best, m_lo, m_hi);
-        const unsigned long long hit = __ballot(sc == (upper ? m_hi : m_lo));
-        const uint32_t hit_lo = (uint32_t)hit, hit_hi = (uint32_t)(hit >> 32);
-        if ((hit_lo | hit_hi) == 0u) break;                      // neither root has a candidate: none later either
-        const int ca = hit_lo ? __builtin_ctz(hit_lo) : -1, cb = hit_hi ? 32 + __builtin_ctz(hit_hi) : -1;
-        if (lane == ca || lane == cb) {
-            nv += 1;
-            vis += 1.0f;
-            vs += lv;
-            const double rd_q = rd_u;
-            rd_u = rd_next;
-            if (!EXACT_DIV) rd_next = g_puct_recip[nv + 2];
-            q = EXACT_DIV ? vs / vis : div_by_int(vs, rd_q);
-        }
-    }
-}
-
-// Four roots in one wave (lanes 16k .. 16k + 15 = root k) when every valid action of all four sits below index 16 -- 81 % of
-// the positions of a game have at most 16 legal moves (g15: mean 11.7).  The row maximum comes from four cyclic row
-// rotations (every lane of a row ends up with its row's maximum: no readlane / select per quarter), one ballot serves the
-// four roots; a pull costs about the instructions of one root, so a packed quadruple takes a quarter of the issue slots.
+// Packed roots.  Two roots in one wave (root A on lanes 0-31, root B on lanes 32-63) when every valid action of both sits
+// below index 32, four roots (lanes 16k .. 16k + 15 = root k) when all sit below 16: the fused root search packs its rows to
+// the left, and 81 % of the positions of a game have at most 16 legal moves (g15: mean 11.7).  The same arithmetic per lane
+// as puct_pulls; a pull of the pack costs about the instructions of one root's pull, so a packed quadruple takes a quarter
+// of the issue slots.  Every lane gets its own group's maximum (no readlane / select per group): four cyclic rotations
+// inside the rows of 16, and for halves gfx950's v_permlane16_swap on top (row 1 <-> row 0 of a copy, row 3 <-> row 2 puts
+// a half's two row maxima side by side in every lane).  Two wait states separate a VALU write from a DPP / permlane
+// read of the same register; the plain VALU compare that follows needs none.
 __device__ __forceinline__ float row16_max(float v) {
     asm volatile("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
                  "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
                  "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
-                 "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_ror:1 row_mask:0xf bank_mask:0xf\n\t"
-                 "s_nop 1"
+                 "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_ror:1 row_mask:0xf bank_mask:0xf"
                  : "+v"(v));
+    return v;
+}
+__device__ __forceinline__ float half32_max(float v) {
+    float t;
+    asm volatile("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_ror:1 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_mov_b32 %1, %0\n\t"
+                 "s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\t"
+                 "s_nop 1\n\tv_max_f32 %0, %0, %1"
+                 : "+v"(v), "=&v"(t));
     return v;
 }
 
 template <bool EXACT_DIV>
-__device__ __forceinline__ void puct_pulls_quad(int sims, int lane, float cp, float lv, float& vis, float& vs) {
-    float q = 0.f;
-    double rd_u = 1.0, rd_next = 0.5;
-    int nv = 0;
-    for (int sim = 0; sim < sims; ++sim) {
-        const float sqrt_total = g_puct_sqrt[sim];
-        const float x = cp * sqrt_total;
-        const float u = EXACT_DIV ? x / (1.0f + vis) : div_by_int(x, rd_u);
-        const float sc = q + u;                                  // NaN on lanes without a valid action
+__device__ __forceinline__ void puct_pulls_pair(const PuctTables T, int sims, int lane, float cp, float lv, float& vis, float& vs) {
+    uint32_t below_lo, below_hi;
+    group_below_masks(lane, 32, below_lo, below_hi);
+    PullState<EXACT_DIV> st;
+    SqrtStream sq(T, sims);
+    while (sq.more()) {
+        const float sc = st.score(cp * sq.next(), vis);          // NaN on lanes without a valid action
+        const float m = half32_max(sc > -INFINITY ? sc : -INFINITY);
+        const unsigned long long hit = __ballot(sc == m);
+        if (first_hit_of_group(sc == m, hit, below_lo, below_hi))    // the lowest maximal lane of each half
+            st.pull(T, lv, vis, vs);
+    }
+}
+
+template <bool EXACT_DIV>
+__device__ __forceinline__ void puct_pulls_quad(const PuctTables T, int sims, int lane, float cp, float lv, float& vis, float& vs) {
+    uint32_t below_lo, below_hi;
+    group_below_masks(lane, 16, below_lo, below_hi);
+    PullState<EXACT_DIV> st;
+    SqrtStream sq(T, sims);
+    while (sq.more()) {
+        const float sc = st.score(cp * sq.next(), vis);          // NaN on lanes without a valid action
         const float m = row16_max(sc > -INFINITY ? sc : -INFINITY);
         const unsigned long long hit = __ballot(sc == m);
-        if (hit == 0ull) break;                                  // no root of the four has a candidate: none later either
-        const uint32_t lo = (uint32_t)hit, hi = (uint32_t)(hit >> 32);
-        const uint32_t f0 = lo & 0xFFFFu, f1 = lo >> 16, f2 = hi & 0xFFFFu, f3 = hi >> 16;
-        const int c0 = f0 ? __builtin_ctz(f0) : -1, c1 = f1 ? 16 + __builtin_ctz(f1) : -1;
-        const int c2 = f2 ? 32 + __builtin_ctz(f2) : -1, c3 = f3 ? 48 + __builtin_ctz(f3) : -1;
-        if (lane == c0 || lane == c1 || lane == c2 || lane == c3) {
-            nv += 1;
-            vis += 1.0f;
-            vs += lv;
-            const double rd_q = rd_u;
-            rd_u = rd_next;
-            if (!EXACT_DIV) rd_next = g_puct_recip[nv + 2];
-            q = EXACT_DIV ? vs / vis : div_by_int(vs, rd_q);
-        }
+        if (first_hit_of_group(sc == m, hit, below_lo, below_hi))    // the lowest maximal lane of each 16-lane row
+            st.pull(T, lv, vis, vs);
     }
 }
 
@@ -774,7 +789,7 @@ __device__ __forceinline__ bool tiny_magnitude(bool ok, float cp, float lv) {
 
 // G roots (2 or 4, any of them may be missing: index < 0) whose valid actions all sit below 64 / G
 template <int G>
-__device__ __forceinline__ void puct_group_job(const int64_t (&roots)[G], int lane, const float* __restrict__ priors,
+__device__ __forceinline__ void puct_group_job(const PuctTables T, const int64_t (&roots)[G], int lane, const float* __restrict__ priors,
                                                const float* __restrict__ leaf, const uint8_t* __restrict__ valid, int A,
                                                int sims, float c, float* __restrict__ visits,
                                                float* __restrict__ value_sum, float* __restrict__ root_values) {
@@ -790,11 +805,11 @@ __device__ __forceinline__ void puct_group_job(const int64_t (&roots)[G], int la
     float vis1 = 0.f, vs1 = 0.f;
     const bool exact = __ballot(tiny_magnitude(ok, cp1, lv1)) != 0ull;    // wave-uniform: the plain divisions
     if (G == 2) {
-        if (exact) puct_pulls_pair<true>(sims, lane, cp1, lv1, vis1, vs1);
-        else puct_pulls_pair<false>(sims, lane, cp1, lv1, vis1, vs1);
+        if (exact) puct_pulls_pair<true>(T, sims, lane, cp1, lv1, vis1, vs1);
+        else puct_pulls_pair<false>(T, sims, lane, cp1, lv1, vis1, vs1);
     } else {
-        if (exact) puct_pulls_quad<true>(sims, lane, cp1, lv1, vis1, vs1);
-        else puct_pulls_quad<false>(sims, lane, cp1, lv1, vis1, vs1);
+        if (exact) puct_pulls_quad<true>(T, sims, lane, cp1, lv1, vis1, vs1);
+        else puct_pulls_quad<false>(T, sims, lane, cp1, lv1, vis1, vs1);
     }
     if (have && a < A) { visits[r * A + a] = vis1; value_sum[r * A + a] = vs1; }
     if (have)
@@ -806,7 +821,7 @@ __device__ __forceinline__ void puct_group_job(const int64_t (&roots)[G], int la
 }
 
 template <int SLOTS>
-__device__ __forceinline__ void puct_single_job(int64_t root, int lane, const float* __restrict__ priors,
+__device__ __forceinline__ void puct_single_job(const PuctTables T, int64_t root, int lane, const float* __restrict__ priors,
                                                 const float* __restrict__ leaf, const uint8_t* __restrict__ valid, int A,
                                                 int sims, float c, float* __restrict__ visits,
                                                 float* __restrict__ value_sum, float* __restrict__ root_values) {
@@ -825,8 +840,8 @@ __device__ __forceinline__ void puct_single_job(int64_t root, int lane, const fl
         tiny = tiny || tiny_magnitude(ok, cp[j], lv[j]);
     }
     // wave-uniform: the plain divisions for this root (two instantiations of the loop, one real branch)
-    if (__ballot(tiny) != 0ull) puct_pulls<SLOTS, true>(sims, lane, live, cp, lv, vis, vs);
-    else puct_pulls<SLOTS, false>(sims, lane, live, cp, lv, vis, vs);
+    if (__ballot(tiny) != 0ull) puct_pulls<SLOTS, true>(T, sims, lane, live, cp, lv, vis, vs);
+    else puct_pulls<SLOTS, false>(T, sims, lane, live, cp, lv, vis, vs);
     float sv = 0.f, sw = 0.f;
 #pragma unroll
     for (int j = 0; j < SLOTS; ++j) {
@@ -848,7 +863,7 @@ __global__ __launch_bounds__(kBlock) void root_puct_fast_kernel(const float* __r
                                                                 int A, int sims, float c,
                                                                 float* __restrict__ visits,
                                                                 float* __restrict__ value_sum,
-                                                                float* __restrict__ root_values) {
+                                                                float* __restrict__ root_values, const PuctTables T) {
     const int lane = lane_id();
     const int64_t root = wave_item();
     if (root >= R) return;
@@ -859,10 +874,10 @@ __global__ __launch_bounds__(kBlock) void root_puct_fast_kernel(const float* __r
     if (rb < R && __ballot(wide) == 0ull) {                      // the even wave of the pair works for both, the odd one leaves
         if (root != ra) return;
         const int64_t pair[2] = {ra, rb};
-        puct_group_job<2>(pair, lane, priors, leaf, valid, A, sims, c, visits, value_sum, root_values);
+        puct_group_job<2>(T, pair, lane, priors, leaf, valid, A, sims, c, visits, value_sum, root_values);
         return;
     }
-    puct_single_job<SLOTS>(root, lane, priors, leaf, valid, A, sims, c, visits, value_sum, root_values);
+    puct_single_job<SLOTS>(T, root, lane, priors, leaf, valid, A, sims, c, visits, value_sum, root_values);
 }
 
 // ---- roots binned by width first (round 5): rows of <= 16 valid actions go four to a wave, <= 32 two to a wave, the rest
@@ -897,7 +912,8 @@ __global__ __launch_bounds__(kBlock) void root_puct_binned_kernel(const float* _
                                                                   float* __restrict__ value_sum,
                                                                   float* __restrict__ root_values,
                                                                   const int* __restrict__ lists,
-                                                                  const unsigned* __restrict__ counts, int64_t cap) {
+                                                                  const unsigned* __restrict__ counts, int64_t cap,
+                                                                  const PuctTables T) {
     const int lane = lane_id();
     const int64_t w = wave_item();
     if (w >= R) return;
@@ -907,13 +923,13 @@ __global__ __launch_bounds__(kBlock) void root_puct_binned_kernel(const float* _
         int64_t r[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) r[k] = 4 * w + k < n0 ? (int64_t)lists[4 * w + k] : -1;
-        puct_group_job<4>(r, lane, priors, leaf, valid, A, sims, c, visits, value_sum, root_values);
+        puct_group_job<4>(T, r, lane, priors, leaf, valid, A, sims, c, visits, value_sum, root_values);
     } else if (w < quads + pairs) {
         const int64_t i = 2 * (w - quads);
         const int64_t r[2] = {(int64_t)lists[cap + i], i + 1 < n1 ? (int64_t)lists[cap + i + 1] : -1};
-        puct_group_job<2>(r, lane, priors, leaf, valid, A, sims, c, visits, value_sum, root_values);
+        puct_group_job<2>(T, r, lane, priors, leaf, valid, A, sims, c, visits, value_sum, root_values);
     } else if (w < quads + pairs + n2) {
-        puct_single_job<SLOTS>((int64_t)lists[2 * cap + (w - quads - pairs)], lane, priors, leaf, valid, A, sims, c, visits,
+        puct_single_job<SLOTS>(T, (int64_t)lists[2 * cap + (w - quads - pairs)], lane, priors, leaf, valid, A, sims, c, visits,
                                value_sum, root_values);
     }
 }
@@ -1666,6 +1682,15 @@ static int root_puct_impl(const float* priors, const float* leaf, const uint8_t*
         }
     }
     if (use_tables) {
+        PuctTables tables{};
+        {
+            void *ps = nullptr, *pr = nullptr;
+            if (hipGetSymbolAddress(&ps, HIP_SYMBOL(g_puct_sqrt)) != hipSuccess ||
+                hipGetSymbolAddress(&pr, HIP_SYMBOL(g_puct_recip)) != hipSuccess)
+                return LZ_ERR_LAUNCH;
+            tables.sqrt_tab = (ConstFloats)reinterpret_cast<uintptr_t>(ps);
+            tables.recip_tab = static_cast<const double*>(pr);
+        }
         // binned by width when this stream has scratch memory for the lists (allocated once per device and stream by an
         // eager call; never during a capture -- FusedRootSearch warms up eagerly before it captures); LZ_ROOT_PUCT_BIN=0
         // keeps neighbours-pair-up (tests compare the two)
@@ -1684,14 +1709,14 @@ static int root_puct_impl(const float* priors, const float* leaf, const uint8_t*
         if (!(nobin && nobin[0] == '0') && have) {
             hipLaunchKernelGGL(puct_zero_counts_kernel, dim3(1), dim3(64), 0, st, sc.counts);
             hipLaunchKernelGGL(puct_bin_kernel, grid, block, 0, st, valid, R, (int)A, sc.lists, sc.counts, sc.cap);
-            if (A <= 64) hipLaunchKernelGGL(root_puct_binned_kernel<1>, grid, block, 0, st, priors, leaf, valid, R, (int)A, (int)sims, c, visits, value_sum, root_values, sc.lists, sc.counts, sc.cap);
-            else if (A <= 128) hipLaunchKernelGGL(root_puct_binned_kernel<2>, grid, block, 0, st, priors, leaf, valid, R, (int)A, (int)sims, c, visits, value_sum, root_values, sc.lists, sc.counts, sc.cap);
-            else hipLaunchKernelGGL(root_puct_binned_kernel<4>, grid, block, 0, st, priors, leaf, valid, R, (int)A, (int)sims, c, visits, value_sum, root_values, sc.lists, sc.counts, sc.cap);
+            if (A <= 64) hipLaunchKernelGGL(root_puct_binned_kernel<1>, grid, block, 0, st, priors, leaf, valid, R, (int)A, (int)sims, c, visits, value_sum, root_values, sc.lists, sc.counts, sc.cap, tables);
+            else if (A <= 128) hipLaunchKernelGGL(root_puct_binned_kernel<2>, grid, block, 0, st, priors, leaf, valid, R, (int)A, (int)sims, c, visits, value_sum, root_values, sc.lists, sc.counts, sc.cap, tables);
+            else hipLaunchKernelGGL(root_puct_binned_kernel<4>, grid, block, 0, st, priors, leaf, valid, R, (int)A, (int)sims, c, visits, value_sum, root_values, sc.lists, sc.counts, sc.cap, tables);
             return launch_status();
         }
-        if (A <= 64) hipLaunchKernelGGL(root_puct_fast_kernel<1>, grid, block, 0, st, priors, leaf, valid, R, (int)A, (int)sims, c, visits, value_sum, root_values);
-        else if (A <= 128) hipLaunchKernelGGL(root_puct_fast_kernel<2>, grid, block, 0, st, priors, leaf, valid, R, (int)A, (int)sims, c, visits, value_sum, root_values);
-        else hipLaunchKernelGGL(root_puct_fast_kernel<4>, grid, block, 0, st, priors, leaf, valid, R, (int)A, (int)sims, c, visits, value_sum, root_values);
+        if (A <= 64) hipLaunchKernelGGL(root_puct_fast_kernel<1>, grid, block, 0, st, priors, leaf, valid, R, (int)A, (int)sims, c, visits, value_sum, root_values, tables);
+        else if (A <= 128) hipLaunchKernelGGL(root_puct_fast_kernel<2>, grid, block, 0, st, priors, leaf, valid, R, (int)A, (int)sims, c, visits, value_sum, root_values, tables);
+        else hipLaunchKernelGGL(root_puct_fast_kernel<4>, grid, block, 0, st, priors, leaf, valid, R, (int)A, (int)sims, c, visits, value_sum, root_values, tables);
         return launch_status();
     }
     if (A <= 64) hipLaunchKernelGGL(root_puct_kernel<1>, grid, block, 0, st, priors, leaf, valid, R, (int)A, sims, c, visits, value_sum, root_values);

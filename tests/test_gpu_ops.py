@@ -324,7 +324,7 @@ def test_root_puct_binned_by_width_equals_neighbour_pairs_and_the_division_kerne
     are (csrc/lz_ops.hip: puct_bin_kernel + root_puct_binned_kernel).  Byte-identical visits / value sums / root values to
     the round-4 kernel (LZ_ROOT_PUCT_BIN=0: neighbours pair up) and to the IEEE-division kernel (LZ_ROOT_PUCT_DIV=1), over
     widths 0 / 1 / 15 / 16 / 17 / 31 / 32 / 33 / 64+, root counts that leave incomplete quadruples and pairs, ties,
-    rows that must take the division branch, and the same call captured into a hipGraph and replayed."""
+    rows that must take the division branch, NaN scores, and the same call captured into a hipGraph and replayed."""
     if DEV == "cpu":
         pytest.skip("the host build has one loop per root: nothing to bin")
     rng = np.random.default_rng(R * 1000 + A)
@@ -342,6 +342,11 @@ def test_root_puct_binned_by_width_equals_neighbour_pairs_and_the_division_kerne
     if R > 12:
         pri[11, :] = np.where(valid[11], 1.0 / max(1, valid[11].sum()), 0).astype(np.float32); leaf[11] = 0.25 * valid[11]   # ties
         leaf[12, 0] = np.float32(2.0 ** -120); valid[12, 0] = True                                   # division branch
+    dead = np.zeros(R, dtype=bool)
+    if R > 15:                                                      # scores that are NaN from the start / become NaN / a root
+        pri[13, 0] = np.nan; valid[13, 0] = True                    # without any usable score inside a packed wave (the pull
+        leaf[14, 1] = np.nan; valid[14, 1] = True                   # loops have no early exit: nothing may be pulled there)
+        pri[10] = np.nan; dead[10] = True
     args = [torch.from_numpy(x).to(DEV) for x in (pri, leaf, valid)]
     run = lambda: [t.cpu().numpy() for t in v0.root_puct_allocate_visits(*args, sims, 1.3)]
     monkeypatch.delenv("LZ_ROOT_PUCT_DIV", raising=False)
@@ -354,7 +359,7 @@ def test_root_puct_binned_by_width_equals_neighbour_pairs_and_the_division_kerne
     for x, y, z in zip(binned, pairs, division):
         assert x.tobytes() == y.tobytes() == z.tobytes()
     width = np.where(valid.any(1), A - np.argmax(valid[:, ::-1], axis=1), 0)
-    assert (binned[0].sum(1) == np.where(width > 0, sims, 0)).all() and (binned[0][~valid] == 0).all()
+    assert (binned[0].sum(1) == np.where((width > 0) & ~dead, sims, 0)).all() and (binned[0][~valid] == 0).all()
     # the same call inside a captured graph (the scratch lists exist since the eager call above)
     monkeypatch.delenv("LZ_ROOT_PUCT_DIV", raising=False)
     monkeypatch.delenv("LZ_ROOT_PUCT_BIN", raising=False)
