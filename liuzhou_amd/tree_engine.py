@@ -1028,7 +1028,9 @@ class SteadyStateTreeSelfPlay:
         self.dual_stream = bool(dual_stream and allow and int(num_games) >= 2
                                 and not persistent_search_available(self.net, batch_k))
         if self.dual_stream:
-            self.mcts = DualStreamTreeMCTS(self.net, num_games, sims, dev, exploration_weight=exploration_weight,
+            parts = int(os.environ.get("LZ_TREE_PARTS", "0")) or None           # experiment: more than two parts
+            self.mcts = DualStreamTreeMCTS(self.net, num_games, sims, dev, num_parts=parts,
+                                           exploration_weight=exploration_weight,
                                            reuse_tree=reuse_tree, reuse_factor=reuse_factor, batch_k=batch_k, seed=seed)
         else:
             one = self.net
