@@ -21,11 +21,13 @@ def hipcc_path() -> str:
 
 HOST_LIB = os.path.join(PKG, "libliuzhou_host.so")
 HOST_SOURCE = os.path.join(CSRC, "lz_host.cpp")
+HOST_SOURCES = (HOST_SOURCE, os.path.join(CSRC, "lz_scalar.cpp"))       # the operator subset + the scalar rule surface
 
 
 def build_host(force: bool = False, verbose: bool = False) -> str:
-    """g++ -> liuzhou_amd/libliuzhou_host.so: the operator subset of the C ABI for CPU tensors (csrc/lz_host.cpp)."""
-    deps = [HOST_SOURCE] + [os.path.join(CSRC, h) for h in HEADERS]
+    """g++ -> liuzhou_amd/libliuzhou_host.so: the operator subset of the C ABI for CPU tensors (csrc/lz_host.cpp) and the
+    scalar rule surface of include/liuzhou_scalar.h (csrc/lz_scalar.cpp)."""
+    deps = list(HOST_SOURCES) + [os.path.join(CSRC, h) for h in HEADERS] + [os.path.join(PKG, "..", "include", "liuzhou_scalar.h")]
     if not force and os.path.exists(HOST_LIB) and all(
             (not os.path.exists(d)) or os.path.getmtime(d) <= os.path.getmtime(HOST_LIB) for d in deps):
         return HOST_LIB
@@ -33,7 +35,7 @@ def build_host(force: bool = False, verbose: bool = False) -> str:
     if not cxx:
         raise RuntimeError("no host C++ compiler (g++) found for libliuzhou_host.so")
     cmd = [cxx, "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-fvisibility=hidden", "-o", HOST_LIB,
-           HOST_SOURCE]
+           *HOST_SOURCES]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

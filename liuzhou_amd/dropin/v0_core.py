@@ -2,6 +2,7 @@
 resolves to the MI355X operator surface instead of the reference's CUDA extension."""
 from liuzhou_amd.v0_core import *  # noqa: F401,F403
 from liuzhou_amd.v0_core import Phase, version  # noqa: F401
+from liuzhou_amd.v0_scalar import *  # noqa: F401,F403  (GameState, MoveRecord, the scalar rule functions, exported enum values)
 
 
 def __getattr__(name):          # MCTSConfig / MCTSCore / InferenceEngine are resolved lazily by the package module

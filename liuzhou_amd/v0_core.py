@@ -17,12 +17,15 @@ Two bindings of the same C ABI carry the operators (round 5):
 `binding("native" | "python")` returns either as a namespace (the parity tests run over both); the module-level names
 are the native ones when available.
 
+The scalar half of the reference module -- `GameState`, `MoveRecord`, `ActionCode`, `TensorStateBatch`, `Player`,
+`ActionType` and the per-state rule functions (`generate_*`, `apply_*`, ...: module.cpp:877-1156) -- is `v0_scalar.py`
+over the host library's scalar C ABI (include/liuzhou_scalar.h), re-exported here.
+
 Drop-in use: put `liuzhou_amd/dropin` on PYTHONPATH, then `import v0_core` resolves to this module.
 """
 from __future__ import annotations
 
 import ctypes as C
-import enum
 from typing import Tuple
 
 import torch
@@ -30,15 +33,10 @@ import torch
 from . import _lib as L
 
 
-class Phase(enum.IntEnum):
-    """v0/include/v0/game_state.hpp (module.cpp:876-885)"""
-    PLACEMENT = 1
-    MARK_SELECTION = 2
-    REMOVAL = 3
-    MOVEMENT = 4
-    CAPTURE_SELECTION = 5
-    FORCED_REMOVAL = 6
-    COUNTER_REMOVAL = 7
+# The scalar half of the module (module.cpp:877-1155): enums, GameState / MoveRecord / ActionCode / TensorStateBatch and the
+# one-state rule functions, over include/liuzhou_scalar.h in the host library.  Shared by both operator bindings.
+from .v0_scalar import *  # noqa: F401,F403,E402
+from .v0_scalar import Phase  # noqa: F401,E402  (v0/include/v0/game_state.hpp, module.cpp:877-885)
 
 
 def version() -> str:
