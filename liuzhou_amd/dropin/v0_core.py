@@ -5,6 +5,6 @@ from liuzhou_amd.v0_core import Phase, version  # noqa: F401
 from liuzhou_amd.v0_scalar import *  # noqa: F401,F403  (GameState, MoveRecord, the scalar rule functions, exported enum values)
 
 
-def __getattr__(name):          # MCTSConfig / MCTSCore / InferenceEngine are resolved lazily by the package module
+def __getattr__(name):          # MCTSConfig / MCTSCore / InferenceEngine / EvalBatcher / TorchScriptRunner: resolved lazily by the package module
     import liuzhou_amd.v0_core as _m
     return getattr(_m, name)

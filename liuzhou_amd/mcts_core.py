@@ -1,4 +1,4 @@
-"""`MCTSConfig` / `MCTSCore` / `InferenceEngine`: the class surface of the reference's `v0_core` that `v0/python/mcts.py`
+"""`MCTSConfig` / `MCTSCore` / `InferenceEngine` / `EvalBatcher` / `TorchScriptRunner`: the class surface of the reference's `v0_core` that `v0/python/mcts.py`
 (:138-470) and the web backend's model loader bind, as thin adapters over the device-resident tree engine (SURVEY.md
 section 8 row f4).
 
@@ -6,6 +6,8 @@ section 8 row f4).
   v0/src/bindings/module.cpp:1158-1173  MCTSConfig              `MCTSConfig` (same fields / defaults)
   v0/src/bindings/module.cpp:1175-1284  MCTSCore                `MCTSCore`: one game on a `TreeEngine(1, ...)`
   v0/src/bindings/module.cpp:1422-1438  InferenceEngine         `InferenceEngine`: the fused network kernel (or any module)
+  v0/src/bindings/module.cpp:1440-1469  EvalBatcher             `EvalBatcher`: worker thread packing callers' inputs into the engine's batch
+  v0/src/bindings/module.cpp:1471-1479  TorchScriptRunner       `TorchScriptRunner`: the archive as is on the host, the fused kernel on a HIP device
   v0/src/mcts/mcts_core.cpp:181-230,703-760,815-829             root_value / get_policy / get_root_children_stats / advance_root
 
 Search semantics are the engine's variant P (one leaf per simulation, first maximum wins, sign flipped only when the mover
@@ -135,6 +137,232 @@ class InferenceEngine:
     dtype = property(lambda self: self._dtype)
     batch_size = property(lambda self: self._batch)
     graph_enabled = property(lambda self: self.fused is not None)
+
+
+_DTYPE_NAMES = {"float32": torch.float32, "fp32": torch.float32, "f32": torch.float32, "float16": torch.float16,
+                "fp16": torch.float16, "f16": torch.float16, "bfloat16": torch.bfloat16, "bf16": torch.bfloat16}
+
+
+class TorchScriptRunner:
+    """module.cpp:1471-1479 over v0/src/net/torchscript_runner.cpp:55-109: `TorchScriptRunner(path, device="cpu",
+    dtype="auto", use_inference_mode=True)`, `.forward(input)` -> (log_p1, log_p2, log_pmc, value output), `.device`,
+    `.dtype`.  On a host device the archive runs as the reference runs it (`torch.jit.load`, the module moved to `dtype`, the
+    input converted to it or left in its own dtype for "auto").  On a HIP device the archive is not interpreted: its
+    state_dict must have ChessNet's keys, the network is rebuilt from it and evaluated by the fused network kernel
+    (64 / 128 channels; fp16 operands for "auto" / "float16", fp32 operands for "float32") -- any other archive raises."""
+
+    def __init__(self, path, device: str = "cpu", dtype: str = "auto", use_inference_mode: bool = True) -> None:
+        self._device = torch.device(device)
+        name = str(dtype)
+        if name in ("", "auto", "none"):
+            self._dtype: Optional[torch.dtype] = None
+        elif name in _DTYPE_NAMES:
+            self._dtype = _DTYPE_NAMES[name]
+        else:
+            raise RuntimeError("Unsupported dtype: " + name)
+        if self._device.type == "cpu" and self._dtype == torch.float16:
+            raise RuntimeError("float16 is not supported on CPU for TorchScriptRunner.")
+        self._inference = bool(use_inference_mode)
+        self.fused: Optional[FusedNet] = None
+        self.module = None
+        if self._device.type == "cpu":
+            self.module = torch.jit.load(str(path), map_location=self._device)
+            if self._dtype is not None:
+                self.module.to(self._device, self._dtype)
+            self.module.eval()
+        else:
+            if self._dtype == torch.bfloat16:
+                raise RuntimeError("TorchScriptRunner: the fused network kernel computes in float16 or float32")
+            model = InferenceEngine._load(path).to(self._device).eval()
+            chans = int(model.stem_conv.out_channels)
+            if chans not in (64, 128):
+                raise RuntimeError(f"TorchScriptRunner: the fused network kernel is built for 64 / 128 channels, got {chans}")
+            self.fused = FusedNet(model, self._device, precision="fp32" if self._dtype == torch.float32 else "fp16")
+
+    def forward(self, input: torch.Tensor):
+        if self.fused is not None:
+            return self.fused(input.to(self._device, torch.float32))
+        x = input
+        want = self._dtype if self._dtype is not None else x.dtype
+        if x.device != self._device or x.dtype != want:
+            x = x.to(self._device, want)
+        x = x.contiguous()
+        ctx = torch.inference_mode() if self._inference else torch.no_grad()
+        with ctx:
+            out = self.module(x)
+        if not isinstance(out, (tuple, list)) or len(out) != 4:
+            raise RuntimeError("TorchScriptRunner expected 4 outputs (log_p1, log_p2, log_pmc, value).")
+        return tuple(out)
+
+    device = property(lambda self: str(self._device))
+    dtype = property(lambda self: "auto" if self._dtype is None else {torch.float32: "float32", torch.float16: "float16",
+                                                                      torch.bfloat16: "bfloat16"}[self._dtype])
+
+
+class EvalBatcher:
+    """module.cpp:1440-1469 over v0/src/mcts/eval_batcher.cpp:27-272: callers on several threads hand in small inputs,
+    one worker thread packs what is waiting into the engine's fixed batch (first come first packed, a request that does not
+    fit starts the next batch, `timeout_ms` after the first request the batch goes as it is), runs ONE `engine.forward(buffer,
+    n_valid)` and hands every caller its rows.  Same constructor checks, per-request errors, statistics
+    (`eval_calls`, `eval_leaves`, `full512_calls`, 17-bucket histogram) and shutdown behaviour; `engine` is an
+    `InferenceEngine` (anything with `forward(input, n_valid)`, `batch_size` and `device`)."""
+
+    HIST_BUCKETS = 17
+
+    def __init__(self, engine, batch_size: int = 512, input_channels: int = 11, height: int = 6, width: int = 6,
+                 timeout_ms: int = 2) -> None:
+        import collections
+        import threading
+        if engine is None:
+            raise RuntimeError("EvalBatcher requires a valid InferenceEngine.")
+        self._engine, self._batch, self._timeout = engine, int(batch_size), int(timeout_ms)
+        self._shape = (int(input_channels), int(height), int(width))
+        if self._batch <= 0:
+            raise RuntimeError("EvalBatcher batch_size must be positive.")
+        if min(self._shape) <= 0:
+            raise RuntimeError("EvalBatcher input shape must be positive.")
+        if int(engine.batch_size) != self._batch:
+            raise RuntimeError(f"EvalBatcher batch_size mismatch: engine={int(engine.batch_size)} batcher={self._batch}")
+        self._device = torch.device(engine.device)
+        self._buf: Optional[torch.Tensor] = None
+        self._queue = collections.deque()
+        self._cv = threading.Condition()
+        self._stop = False
+        self._stats_lock = threading.Lock()
+        self._zero_stats()
+        self._worker = threading.Thread(target=self._loop, name="lz-eval-batcher", daemon=True)
+        self._worker.start()
+
+    def _zero_stats(self) -> None:
+        self._calls = self._leaves = self._full = 0
+        self._hist = [0] * self.HIST_BUCKETS
+
+    def forward(self, input: torch.Tensor, n_valid: int = -1):
+        from concurrent.futures import Future
+        if self._stop:
+            raise RuntimeError("EvalBatcher is shut down.")
+        fut: Future = Future()
+        with self._cv:
+            self._queue.append([input, int(n_valid), fut])
+            self._cv.notify()
+        return fut.result()
+
+    def shutdown(self) -> None:
+        with self._cv:
+            if self._stop:
+                return
+            self._stop = True
+            self._cv.notify_all()
+        self._worker.join()
+
+    def __del__(self) -> None:
+        try:
+            self.shutdown()
+        except Exception:
+            pass
+
+    def reset_eval_stats(self) -> None:
+        with self._stats_lock:
+            self._zero_stats()
+
+    def get_eval_stats(self) -> Dict[str, object]:
+        with self._stats_lock:
+            return {"eval_calls": self._calls, "eval_leaves": self._leaves, "full512_calls": self._full,
+                    "hist": list(self._hist)}
+
+    batch_size = property(lambda self: self._batch)
+    timeout_ms = property(lambda self: self._timeout)
+
+    def _bucket(self, n: int) -> int:                                # eval_batcher.cpp:112-127
+        if n <= 0:
+            return 0
+        if n > self._batch:
+            return self.HIST_BUCKETS - 1
+        return min(self.HIST_BUCKETS - 1, max(0, (n - 1) // max(1, self._batch // (self.HIST_BUCKETS - 1))))
+
+    def _admit(self, req) -> Optional[str]:
+        """Validate one request (eval_batcher.cpp:163-196); returns the error text, or None with req[1] = its row count."""
+        x, n = req[0], req[1]
+        if n <= 0:
+            n = int(x.shape[0]) if x.dim() > 0 else 0
+        req[1] = n
+        if n <= 0 or n > self._batch:
+            return "EvalBatcher n_valid out of range."
+        if x.dim() != 4:
+            return "EvalBatcher input must be 4D."
+        if tuple(int(v) for v in x.shape[1:]) != self._shape:
+            return (f"EvalBatcher input shape mismatch, expected (B, {self._shape[0]}, {self._shape[1]}, {self._shape[2]}) "
+                    f"got {tuple(int(v) for v in x.shape)}")
+        if int(x.shape[0]) < n:
+            return "EvalBatcher input batch smaller than n_valid."
+        return None
+
+    def _loop(self) -> None:
+        import time
+        while True:
+            batch, total = [], 0
+            with self._cv:
+                self._cv.wait_for(lambda: self._stop or self._queue)
+                if self._stop and not self._queue:
+                    return
+                deadline = time.monotonic() + max(0, self._timeout) / 1e3
+                while total < self._batch:
+                    limit = False
+                    while self._queue and total < self._batch:
+                        req = self._queue.popleft()
+                        err = self._admit(req)
+                        if err is not None:
+                            req[2].set_exception(RuntimeError(err))
+                            continue
+                        if total + req[1] > self._batch:
+                            self._queue.appendleft(req)
+                            limit = True
+                            break
+                        batch.append(req)
+                        total += req[1]
+                    if total >= self._batch or limit or self._timeout <= 0:
+                        break
+                    if not self._queue:
+                        left = deadline - time.monotonic()
+                        if left > 0 and self._cv.wait_for(lambda: self._stop or self._queue, timeout=left):
+                            if self._stop and not self._queue:
+                                break
+                            continue
+                        break
+            if not batch:
+                if self._stop:
+                    return
+                continue
+            self._run(batch, total)
+
+    def _run(self, batch, total: int) -> None:
+        if self._buf is None:
+            self._buf = torch.zeros((self._batch,) + self._shape, dtype=torch.float32, device=self._device)
+        self._buf.zero_()
+        failed, off = [False] * len(batch), 0
+        for i, (x, n, fut) in enumerate(batch):
+            try:
+                self._buf[off:off + n].copy_(x[:n].to(self._device, torch.float32), non_blocking=True)
+            except Exception as exc:
+                fut.set_exception(exc)
+                failed[i] = True
+            off += n
+        try:
+            outs = self._engine.forward(self._buf, total)
+            with self._stats_lock:
+                self._calls += 1
+                self._leaves += total
+                self._full += 1 if total == self._batch else 0
+                self._hist[self._bucket(total)] += 1
+            off = 0
+            for i, (x, n, fut) in enumerate(batch):
+                if not failed[i]:
+                    fut.set_result(tuple(o[off:off + n].clone() for o in outs))
+                off += n
+        except Exception as exc:
+            for i, (_x, _n, fut) in enumerate(batch):
+                if not failed[i]:
+                    fut.set_exception(exc)
 
 
 class MCTSCore:

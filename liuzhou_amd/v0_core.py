@@ -508,9 +508,9 @@ _activate()
 
 
 def __getattr__(name: str):
-    """`MCTSConfig`, `MCTSCore`, `InferenceEngine` (module.cpp:1158-1284,1422-1438): adapters over the device tree engine,
+    """`MCTSConfig`, `MCTSCore`, `InferenceEngine`, `EvalBatcher`, `TorchScriptRunner` (module.cpp:1158-1284,1422-1479): adapters over the device tree engine,
     resolved lazily (they sit above the modules that import this one)."""
-    if name in ("MCTSConfig", "MCTSCore", "InferenceEngine"):
+    if name in ("MCTSConfig", "MCTSCore", "InferenceEngine", "EvalBatcher", "TorchScriptRunner"):
         from . import mcts_core
         return getattr(mcts_core, name)
     raise AttributeError(f"module 'v0_core' has no attribute {name!r}")

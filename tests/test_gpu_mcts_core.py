@@ -1,4 +1,5 @@
-"""GPU: the `MCTSConfig` / `MCTSCore` / `InferenceEngine` adapters (v0_core class surface)."""
+"""GPU: the `MCTSConfig` / `MCTSCore` / `InferenceEngine` / `EvalBatcher` / `TorchScriptRunner` adapters (v0_core class
+surface)."""
 import types
 
 import numpy as np
@@ -226,3 +227,49 @@ def test_mcts_core_root_noise_is_fresh_for_every_root():
     core2.set_forward_callback(forward)
     with pytest.raises(ValueError, match="65536"):
         core2.set_root_state(_state_like(st, 10))
+
+
+def test_torchscript_runner_and_eval_batcher_on_the_device(tmp_path):
+    """`TorchScriptRunner(path, device="cuda")` evaluates the archive's network with the fused kernel (no TorchScript
+    interpreter on the device), `EvalBatcher` packs four threads' requests into the engine's batch: both equal the
+    engine's direct forward bit for bit, and stay within the fused kernel's bounds of the fp32 module."""
+    import threading
+    from liuzhou_amd import v0_core
+    from liuzhou_amd.net import ChessNet, MODEL_CONFIGS
+    torch.manual_seed(20260314)
+    model = ChessNet(**MODEL_CONFIGS["b6c64"]).eval()
+    path = str(tmp_path / "b6c64.pt")
+    torch.jit.trace(model, torch.zeros(2, 11, 6, 6)).save(path)
+    z = load("g1_rules.npz")
+    st = states(z, "s")
+    planes = v0_core.states_to_model_input(*[torch.from_numpy(np.ascontiguousarray(np.asarray(st[f])[:96])).to(DEV)
+                                             for f in ("board", "marks_black", "marks_white", "phase", "current_player")])
+    runner = v0_core.TorchScriptRunner(path, DEV, "auto")
+    assert (runner.device, runner.dtype) == (DEV, "auto") and runner.fused is not None and runner.module is None
+    engine = v0_core.InferenceEngine(path, device=DEV, dtype="float16", batch_size=64)
+    direct = engine.forward(planes[:64], 64)
+    for a, b in zip(runner.forward(planes[:64]), direct):
+        assert torch.equal(a, b)
+    with torch.no_grad():
+        want = model.to(DEV)(planes[:64])
+    for k in range(3):
+        assert float((direct[k].exp() - want[k].exp()).abs().max()) < 1e-4
+    with pytest.raises(RuntimeError, match="float16 or float32"):
+        v0_core.TorchScriptRunner(path, DEV, "bfloat16")
+    batcher = v0_core.EvalBatcher(engine, 64, timeout_ms=5)
+    chunks = [(0, 10), (10, 30), (30, 37), (37, 64), (64, 96)]
+    out = [None] * len(chunks)
+
+    def call(i):
+        a, b = chunks[i]
+        out[i] = batcher.forward(planes[a:b].cpu())                 # host inputs travel to the engine's device
+    threads = [threading.Thread(target=call, args=(i,)) for i in range(len(chunks))]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    for (a, b), o in zip(chunks, out):
+        ref = engine.forward(planes[a:b], b - a)
+        for p, q in zip(o, ref):
+            assert p.shape == q.shape and float((p - q).abs().max()) < 1e-5     # a sample's result does not depend on its batch neighbours
+    stats = batcher.get_eval_stats()
+    assert stats["eval_leaves"] == 96 and 2 <= stats["eval_calls"] <= 5
+    batcher.shutdown()
