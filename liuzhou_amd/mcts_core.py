@@ -403,10 +403,30 @@ class MCTSCore:
                 return lp1, lp2, lpm, bucket_logits_to_scalar(raw.float())
             self._callback, self._fused = cb, None
 
-    def set_torchscript_runner(self, runner) -> None:
-        raise RuntimeError("TorchScript runners are not part of this build; use set_inference_engine / set_forward_callback")
+    def _value_callback(self, forward: Callable) -> Callable:
+        """A `forward(x) -> (log_p1, log_p2, log_pmc, value output)` as the search's callback (scalar values)."""
+        from .net import bucket_logits_to_scalar
 
-    set_eval_batcher = set_torchscript_runner
+        def cb(x):
+            lp1, lp2, lpm, raw = forward(x)
+            raw = raw.float()
+            return lp1.float(), lp2.float(), lpm.float(), (bucket_logits_to_scalar(raw) if raw.dim() == 2 and raw.shape[1] > 1 else raw.reshape(-1))
+        return cb
+
+    def set_torchscript_runner(self, runner) -> None:
+        """module.cpp:1196-1217: evaluations go through `runner.forward` (the fused kernel when the runner sits on a HIP device)"""
+        if runner is None:
+            raise RuntimeError("TorchScriptRunner is null")
+        if getattr(runner, "fused", None) is not None:
+            self._fused, self._callback = runner.fused, None
+        else:
+            self._callback, self._fused = self._value_callback(lambda x, _r=runner: _r.forward(x)), None
+
+    def set_eval_batcher(self, batcher) -> None:
+        """module.cpp:1218-1230: evaluations go through `batcher.forward` -- several cores on several threads share one engine"""
+        if batcher is None:
+            raise RuntimeError("EvalBatcher is null")
+        self._callback, self._fused = self._value_callback(lambda x, _b=batcher: _b.forward(x, int(x.shape[0]))), None
 
     # ---- tree ----
     NODE_LIMIT = 65536          # tree_advance_kernel marks a game's nodes in LDS: 1024 words of 64 (csrc/lz_engine.hip)

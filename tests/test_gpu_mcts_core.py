@@ -101,8 +101,8 @@ def test_mcts_core_with_a_python_forward_callback():
     assert len(calls) >= 2 and core.root_visit_count == 32
     pol = core.get_policy(1.0)
     assert pol and abs(sum(p for _, p in pol) - 1.0) < 1e-9
-    with pytest.raises(RuntimeError):
-        core.set_torchscript_runner(object())
+    with pytest.raises(RuntimeError, match="null"):
+        core.set_torchscript_runner(None)
 
 
 def test_mcts_core_against_the_oracle_tree():
@@ -273,3 +273,33 @@ def test_torchscript_runner_and_eval_batcher_on_the_device(tmp_path):
     stats = batcher.get_eval_stats()
     assert stats["eval_leaves"] == 96 and 2 <= stats["eval_calls"] <= 5
     batcher.shutdown()
+
+
+def test_mcts_core_searches_through_an_eval_batcher_and_a_torchscript_runner(tmp_path):
+    """`set_eval_batcher` / `set_torchscript_runner` (module.cpp:1196-1230): the same search as through the engine itself."""
+    from liuzhou_amd import v0_core
+    from liuzhou_amd.net import ChessNet, MODEL_CONFIGS
+    torch.manual_seed(20260314)
+    model = ChessNet(**MODEL_CONFIGS["b6c64"]).eval()
+    path = str(tmp_path / "b6c64.pt")
+    torch.jit.trace(model, torch.zeros(2, 11, 6, 6)).save(path)
+    engine = v0_core.InferenceEngine(path, device=DEV, dtype="float16", batch_size=8)
+    batcher = v0_core.EvalBatcher(engine, 8, timeout_ms=0)
+    runner = v0_core.TorchScriptRunner(path, DEV)
+    st = states(load("g1_rules.npz"), "s")
+    for i in (5, 400, 1200):
+        seen = []
+        for attach in (lambda c: c.set_inference_engine(engine), lambda c: c.set_eval_batcher(batcher),
+                       lambda c: c.set_torchscript_runner(runner)):
+            cfg = v0_core.MCTSConfig()
+            cfg.num_simulations, cfg.device = 32, DEV
+            core = v0_core.MCTSCore(cfg)
+            attach(core)
+            core.set_root_state(_state_like(st, i))
+            core.run_simulations(32)
+            seen.append([(s["action_index"], int(s["visit_count"])) for s in core.get_root_children_stats()])
+        assert seen[0] == seen[1] == seen[2] and sum(v for _, v in seen[0]) in (31, 32)
+    assert batcher.get_eval_stats()["eval_calls"] >= 32
+    batcher.shutdown()
+    with pytest.raises(RuntimeError, match="null"):
+        v0_core.MCTSCore(v0_core.MCTSConfig()).set_eval_batcher(None)
