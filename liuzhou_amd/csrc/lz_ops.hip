@@ -607,7 +607,8 @@ __global__ __launch_bounds__(kBlock) void root_puct_kernel(const float* __restri
 }
 
 // ---- the same allocation with the two IEEE divisions of a pull replaced by exact equivalents (round 4) ------------
-// A pull is VALU-issue bound (one wave per root, 8 waves per SIMD take turns): ~45 instructions, 20 of them the two
+// A pull is instruction-issue bound -- vector AND scalar instructions count (round 5, profiles/r05_pmc_sq_bandit.md) --:
+// with divisions it is ~45 vector instructions, 20 of them the two
 // correctly rounded fp32 divisions  u = (c*p*sqrt_total) / (1 + visits)  and  q = value_sum / visits, ~10 more the
 // correctly rounded sqrtf.  Here
 //   * sqrt_total comes from a table: total == sim while pulls succeed (a pull that finds no candidate changes nothing,
