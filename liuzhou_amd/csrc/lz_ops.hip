@@ -752,33 +752,33 @@ __device__ __forceinline__ float half32_max(float v) {
                  : "+v"(v), "=&v"(t));
     return v;
 }
-
-template <bool EXACT_DIV>
-__device__ __forceinline__ void puct_pulls_pair(const PuctTables T, int sims, int lane, float cp, float lv, float& vis, float& vs) {
-    uint32_t below_lo, below_hi;
-    group_below_masks(lane, 32, below_lo, below_hi);
-    PullState<EXACT_DIV> st;
-    SqrtStream sq(T, sims);
-    while (sq.more()) {
-        const float sc = st.score(cp * sq.next(), vis);          // NaN on lanes without a valid action
-        const float m = half32_max(sc > -INFINITY ? sc : -INFINITY);
-        const unsigned long long hit = __ballot(sc == m);
-        if (first_hit_of_group(sc == m, hit, below_lo, below_hi))    // the lowest maximal lane of each half
-            st.pull(T, lv, vis, vs);
-    }
+// eight roots of <= 8 actions (lanes 8k .. 8k + 7 = root k): two quad permutes (lane ^ 1, lane ^ 2) and the mirror of each
+// half row (lane <-> 7 - lane within 8) leave every lane with the maximum of its 8
+__device__ __forceinline__ float oct8_max(float v) {
+    asm volatile("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf"
+                 : "+v"(v));
+    return v;
 }
 
-template <bool EXACT_DIV>
-__device__ __forceinline__ void puct_pulls_quad(const PuctTables T, int sims, int lane, float cp, float lv, float& vis, float& vs) {
+template <int W> __device__ __forceinline__ float group_max(float v);      // every lane: the maximum of its W-lane group
+template <> __device__ __forceinline__ float group_max<32>(float v) { return half32_max(v); }
+template <> __device__ __forceinline__ float group_max<16>(float v) { return row16_max(v); }
+template <> __device__ __forceinline__ float group_max<8>(float v) { return oct8_max(v); }
+
+// the pulls of 64 / W roots packed W lanes each: one ballot serves them all
+template <int W, bool EXACT_DIV>
+__device__ __forceinline__ void puct_pulls_packed(const PuctTables T, int sims, int lane, float cp, float lv, float& vis, float& vs) {
     uint32_t below_lo, below_hi;
-    group_below_masks(lane, 16, below_lo, below_hi);
+    group_below_masks(lane, W, below_lo, below_hi);
     PullState<EXACT_DIV> st;
     SqrtStream sq(T, sims);
     while (sq.more()) {
         const float sc = st.score(cp * sq.next(), vis);          // NaN on lanes without a valid action
-        const float m = row16_max(sc > -INFINITY ? sc : -INFINITY);
+        const float m = group_max<W>(sc > -INFINITY ? sc : -INFINITY);
         const unsigned long long hit = __ballot(sc == m);
-        if (first_hit_of_group(sc == m, hit, below_lo, below_hi))    // the lowest maximal lane of each 16-lane row
+        if (first_hit_of_group(sc == m, hit, below_lo, below_hi))    // the lowest maximal lane of each group
             st.pull(T, lv, vis, vs);
     }
 }
@@ -788,7 +788,7 @@ __device__ __forceinline__ bool tiny_magnitude(bool ok, float cp, float lv) {
     return ok && ((acp != 0.f && acp < 0x1p-100f) || (alv != 0.f && alv < 0x1p-100f));
 }
 
-// G roots (2 or 4, any of them may be missing: index < 0) whose valid actions all sit below 64 / G
+// G roots (2, 4 or 8, any of them may be missing: index < 0) whose valid actions all sit below 64 / G
 template <int G>
 __device__ __forceinline__ void puct_group_job(const PuctTables T, const int64_t (&roots)[G], int lane, const float* __restrict__ priors,
                                                const float* __restrict__ leaf, const uint8_t* __restrict__ valid, int A,
@@ -805,13 +805,8 @@ __device__ __forceinline__ void puct_group_job(const PuctTables T, const int64_t
     const float lv1 = have && a < A ? leaf[r * A + a] : 0.f;
     float vis1 = 0.f, vs1 = 0.f;
     const bool exact = __ballot(tiny_magnitude(ok, cp1, lv1)) != 0ull;    // wave-uniform: the plain divisions
-    if (G == 2) {
-        if (exact) puct_pulls_pair<true>(T, sims, lane, cp1, lv1, vis1, vs1);
-        else puct_pulls_pair<false>(T, sims, lane, cp1, lv1, vis1, vs1);
-    } else {
-        if (exact) puct_pulls_quad<true>(T, sims, lane, cp1, lv1, vis1, vs1);
-        else puct_pulls_quad<false>(T, sims, lane, cp1, lv1, vis1, vs1);
-    }
+    if (exact) puct_pulls_packed<W, true>(T, sims, lane, cp1, lv1, vis1, vs1);
+    else puct_pulls_packed<W, false>(T, sims, lane, cp1, lv1, vis1, vs1);
     if (have && a < A) { visits[r * A + a] = vis1; value_sum[r * A + a] = vs1; }
     if (have)
         for (int a2 = W + a; a2 < A; a2 += W) { visits[r * A + a2] = 0.f; value_sum[r * A + a2] = 0.f; }   // never visited
@@ -881,11 +876,11 @@ __global__ __launch_bounds__(kBlock) void root_puct_fast_kernel(const float* __r
     puct_single_job<SLOTS>(T, root, lane, priors, leaf, valid, A, sims, c, visits, value_sum, root_values);
 }
 
-// ---- roots binned by width first (round 5): rows of <= 16 valid actions go four to a wave, <= 32 two to a wave, the rest
-// alone -- whichever roots happen to be neighbours.  puct_bin_kernel: one wave per root finds the row's width (index of
-// its last valid action + 1) and appends the root to its class list (atomics on three counters, once per ply: the list
+// ---- roots binned by width first (round 5): rows of <= 8 valid actions go eight to a wave (35 % of a game's positions),
+// <= 16 four to a wave (46 %), <= 32 two to a wave, the rest alone -- whichever roots happen to be neighbours.  puct_bin_kernel: one wave per root finds the row's width (index of
+// its last valid action + 1) and appends the root to its class list (atomics on four counters, once per ply: the list
 // order varies from run to run, a root's results do not depend on its companions).  The pull kernel's wave w then takes
-// quadruple w, pair w - quads, or single w - quads - pairs, from the device-side counts (no host read).
+// octet w, quadruple w - octets, pair w - octets - quads, or a single root, from the device-side counts (no host read).
 __global__ void puct_zero_counts_kernel(unsigned* counts) { if (threadIdx.x < 4) counts[threadIdx.x] = 0u; }
 
 __global__ __launch_bounds__(kBlock) void puct_bin_kernel(const uint8_t* __restrict__ valid, int64_t R, int A,
@@ -899,7 +894,7 @@ __global__ __launch_bounds__(kBlock) void puct_bin_kernel(const uint8_t* __restr
         if (b != 0ull) width = a0 + 64 - __builtin_clzll(b);
     }
     if (lane == 0) {
-        const int cls = width <= 16 ? 0 : (width <= 32 ? 1 : 2);
+        const int cls = width <= 8 ? 3 : (width <= 16 ? 0 : (width <= 32 ? 1 : 2));
         const unsigned pos = atomicAdd(&counts[cls], 1u);
         lists[(int64_t)cls * cap + pos] = (int)root;
     }
@@ -916,9 +911,18 @@ __global__ __launch_bounds__(kBlock) void root_puct_binned_kernel(const float* _
                                                                   const unsigned* __restrict__ counts, int64_t cap,
                                                                   const PuctTables T) {
     const int lane = lane_id();
-    const int64_t w = wave_item();
+    int64_t w = wave_item();
     if (w >= R) return;
-    const int64_t n0 = counts[0], n1 = counts[1], n2 = counts[2];
+    const int64_t n0 = counts[0], n1 = counts[1], n2 = counts[2], n3 = counts[3];
+    const int64_t octets = (n3 + 7) >> 3;
+    if (w < octets) {
+        int64_t r[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) r[k] = 8 * w + k < n3 ? (int64_t)lists[3 * cap + 8 * w + k] : -1;
+        puct_group_job<8>(T, r, lane, priors, leaf, valid, A, sims, c, visits, value_sum, root_values);
+        return;
+    }
+    w -= octets;
     const int64_t quads = (n0 + 3) >> 2, pairs = (n1 + 1) >> 1;
     if (w < quads) {
         int64_t r[4];
@@ -1496,6 +1500,7 @@ __global__ __launch_bounds__(kBlock) void root_force_uniform_kernel(
 // stream) so that two streams never share lists.  Allocated by the first eager call that needs it; a call on a capturing
 // stream only uses what exists already (hipMalloc is not capturable).  A block that is too small is replaced, the old one is
 // kept alive: captured graphs may still point at it.
+constexpr int kPuctLists = 4;                                  // class lists: <= 16, <= 32, wider, <= 8 (each `cap` entries)
 struct PuctScratch { int* lists; unsigned* counts; int64_t cap; };
 static bool puct_scratch(int device, hipStream_t st, int64_t R, PuctScratch* out) {
     struct Entry { int device; hipStream_t st; PuctScratch s; };
@@ -1509,9 +1514,9 @@ static bool puct_scratch(int device, hipStream_t st, int64_t R, PuctScratch* out
     PuctScratch s{};
     s.cap = R < 1024 ? 1024 : R;
     void* p = nullptr;
-    if (hipMalloc(&p, (size_t)s.cap * 3 * sizeof(int) + 4 * sizeof(unsigned)) != hipSuccess) { (void)hipGetLastError(); return false; }
+    if (hipMalloc(&p, (size_t)s.cap * kPuctLists * sizeof(int) + 4 * sizeof(unsigned)) != hipSuccess) { (void)hipGetLastError(); return false; }
     s.lists = static_cast<int*>(p);
-    s.counts = reinterpret_cast<unsigned*>(s.lists + 3 * s.cap);
+    s.counts = reinterpret_cast<unsigned*>(s.lists + kPuctLists * s.cap);
     entries.push_back({device, st, s});
     *out = s;
     return true;
@@ -1644,7 +1649,7 @@ int lz_root_pack_fill(const int32_t* counts, const int32_t* legal_index, const f
 }
 
 static int64_t puct_workspace_bytes(int64_t num_roots) {
-    return (num_roots < 0 ? 0 : num_roots) * 3 * (int64_t)sizeof(int) + 4 * (int64_t)sizeof(unsigned);
+    return (num_roots < 0 ? 0 : num_roots) * kPuctLists * (int64_t)sizeof(int) + 4 * (int64_t)sizeof(unsigned);
 }
 
 static int root_puct_impl(const float* priors, const float* leaf, const uint8_t* valid, int64_t R, int64_t A, int64_t sims,
@@ -1702,7 +1707,7 @@ static int root_puct_impl(const float* priors, const float* leaf, const uint8_t*
             if (workspace_bytes < puct_workspace_bytes(R) || !aligned(workspace, 4)) return LZ_ERR_ARG;
             sc.lists = static_cast<int*>(workspace);
             sc.cap = R;
-            sc.counts = reinterpret_cast<unsigned*>(sc.lists + 3 * sc.cap);
+            sc.counts = reinterpret_cast<unsigned*>(sc.lists + kPuctLists * sc.cap);
             have = true;
         } else {
             have = puct_scratch(device, st, R, &sc);

@@ -320,18 +320,20 @@ def test_root_puct_table_kernel_equals_division_kernel(v0, A, sims, monkeypatch)
 
 @pytest.mark.parametrize("R,A,sims", [(4, 36, 64), (5, 72, 1024), (1023, 80, 700), (6, 16, 8192), (130, 130, 300)])
 def test_root_puct_binned_by_width_equals_neighbour_pairs_and_the_division_kernel(v0, R, A, sims, monkeypatch):
-    """Round 5: rows of <= 16 valid actions go FOUR to a wave, <= 32 two to a wave, the rest alone, whichever roots they
+    """Round 5: rows of <= 8 valid actions go EIGHT to a wave, <= 16 four, <= 32 two, the rest alone, whichever roots they
     are (csrc/lz_ops.hip: puct_bin_kernel + root_puct_binned_kernel).  Byte-identical visits / value sums / root values to
     the round-4 kernel (LZ_ROOT_PUCT_BIN=0: neighbours pair up) and to the IEEE-division kernel (LZ_ROOT_PUCT_DIV=1), over
-    widths 0 / 1 / 15 / 16 / 17 / 31 / 32 / 33 / 64+, root counts that leave incomplete quadruples and pairs, ties,
+    widths 0 / 1 / 7 / 8 / 9 / 15 / 16 / 17 / 31 / 32 / 33 / 64+, root counts that leave incomplete octets, quadruples and pairs, ties,
     rows that must take the division branch, NaN scores, and the same call captured into a hipGraph and replayed."""
     if DEV == "cpu":
         pytest.skip("the host build has one loop per root: nothing to bin")
     rng = np.random.default_rng(R * 1000 + A)
-    special = [0, 1, 15, 16, 17, 31, 32, 33, min(A, 64), A, 16, 16, 16, 3, 16]
+    special = [0, 1, 15, 16, 17, 31, 32, 33, min(A, 64), A, 16, 16, 16, 3, 16, 8, 9, 7, 8, 8, 2, 8, 8, 8, 8, 5]
     n = np.minimum(np.where(np.arange(R) < len(special), np.resize(special, R), rng.integers(0, min(A, 40) + 1, R)), A)
     narrow = rng.random(R) < 0.5
     n[narrow & (np.arange(R) >= len(special))] = np.minimum(n, 16)[narrow & (np.arange(R) >= len(special))]     # most rows are narrow
+    tiny = rng.random(R) < 0.3
+    n[tiny & (np.arange(R) >= len(special))] = np.minimum(n, 8)[tiny & (np.arange(R) >= len(special))]           # ... a third of them <= 8
     valid = np.arange(A)[None, :] < n[:, None]
     holes = rng.random((R, A)) < 0.15                               # not every row is packed to the left
     valid = valid & ~holes
