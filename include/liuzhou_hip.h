@@ -148,8 +148,8 @@ LZ_API int lz_root_pack_fill(const int32_t* counts, const int32_t* legal_index, 
 /* v0_core.root_puct_allocate_visits  (module.cpp:1349-1356; root_puct_fused.cu:12-117)
  * fp32 bandit: `num_simulations` serial pulls per root, lowest index wins ties.  A <= 256.
  * The one entry point of the HIP build that owns device memory: the first eager call per (device, stream) allocates
- * 12 bytes per root of scratch for the width-binned kernel (rows of <= 16 / <= 32 valid actions share a wave four / two at
- * a time) and keeps it; a call on a capturing stream uses what exists (an eager call with the same `num_roots` first),
+ * 16 bytes per root of scratch for the width-binned kernel (rows of <= 8 / <= 16 / <= 32 valid actions share a wave eight /
+ * four / two at a time) and keeps it; a call on a capturing stream uses what exists (an eager call with the same `num_roots` first),
  * otherwise the neighbours-pair-up kernel.  Outputs do not depend on which kernel ran (bit-identical). */
 LZ_API int lz_root_puct_allocate_visits(const float* priors, const float* leaf_values,
                                         const uint8_t* valid_mask, int64_t num_roots,
