@@ -427,28 +427,38 @@ __device__ __forceinline__ void gpool64(unsigned char* lds, int tid) {
     if (tid < S * 32) {
         const int pair = tid >> 1, half = tid & 1;
         const int s = pair >> 4, cq = pair & 15;
-        float sum[4] = {0.f, 0.f, 0.f, 0.f}, sq[4] = {0.f, 0.f, 0.f, 0.f};
-        float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-#pragma unroll 6
-        for (int p = half * 18; p < half * 18 + 18; ++p) {
-            const h4 v = *reinterpret_cast<const h4*>(lds + act_addr<C, S>(s * 36 + p, cq >> 1) + (cq & 1) * 8);
+        // The lane's 18 cells are three board rows of six: consecutive cells sit STRIDE bytes apart, rows 7 * STRIDE, so
+        // every read is the lane's base + an immediate (no per-cell index arithmetic); four channels at a time as packed
+        // fp32 adds / multiplies, the maximum on the fp16 values themselves (exact).  Same additions in the same order
+        // as a scalar loop over the cells: bit-identical sums.
+        const unsigned char* bp = lds + K::ACT_OFF + (s * K::CELLS + 1 + 7 * (half * 3 + 1)) * K::STRIDE +
+                                  (chunk_pos(cq >> 1) << 4) + (cq & 1) * 8;
+        f4 sum = {0.f, 0.f, 0.f, 0.f}, sq = {0.f, 0.f, 0.f, 0.f};
+        const _Float16 ninf = (_Float16)(-INFINITY);
+        h4 mxh = {ninf, ninf, ninf, ninf};
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { const float f = (float)v[k]; sum[k] += f; sq[k] += f * f; mx[k] = fmaxf(mx[k], f); }
+        for (int dr = 0; dr < 3; ++dr) {
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                const h4 v = *reinterpret_cast<const h4*>(bp + (7 * dr + c) * K::STRIDE);
+                const f4 f = __builtin_convertvector(v, f4);
+                sum = sum + f;
+                sq = sq + f * f;
+                mxh = __builtin_elementwise_max(mxh, v);
+            }
         }
+        const f4 mxf = __builtin_convertvector(mxh, f4);
+        float mean[4], sd[4], mx[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {                              // combine with the neighbouring lane (tid ^ 1)
-            sum[k] += lzw::dpp_f32<0xB1, 0xf>(0.f, sum[k]);       // quad_perm [1,0,3,2]
-            sq[k] += lzw::dpp_f32<0xB1, 0xf>(0.f, sq[k]);
-            mx[k] = fmaxf(mx[k], lzw::dpp_f32<0xB1, 0xf>(-INFINITY, mx[k]));
+            const float su = sum[k] + lzw::dpp_f32<0xB1, 0xf>(0.f, sum[k]);       // quad_perm [1,0,3,2]
+            const float qu = sq[k] + lzw::dpp_f32<0xB1, 0xf>(0.f, sq[k]);
+            mx[k] = fmaxf(mxf[k], lzw::dpp_f32<0xB1, 0xf>(-INFINITY, mxf[k]));
+            mean[k] = su * (1.0f / 36.0f);
+            const float var = fmaxf(qu * (1.0f / 36.0f) - mean[k] * mean[k], 0.f);
+            sd[k] = sqrtf(var + 1e-6f);
         }
         if (half == 0) {
-            float mean[4], sd[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                mean[k] = sum[k] * (1.0f / 36.0f);
-                const float var = fmaxf(sq[k] * (1.0f / 36.0f) - mean[k] * mean[k], 0.f);
-                sd[k] = sqrtf(var + 1e-6f);
-            }
             unsigned char* row = lds + K::POOL_OFF + s * K::POOL_STRIDE;
             *reinterpret_cast<h4*>(row + (cq * 4) * 2) = to_h4(mean[0], mean[1], mean[2], mean[3]);
             *reinterpret_cast<h4*>(row + (kHead + cq * 4) * 2) = to_h4(mx[0], mx[1], mx[2], mx[3]);
@@ -457,20 +467,29 @@ __device__ __forceinline__ void gpool64(unsigned char* lds, int tid) {
     }
 }
 
-// small dense layer on the matrix cores: D[16 outputs of tile ct][16 samples] = W(ct) * rows, K = 32*kbn
+// small dense layer on the matrix cores: D[16 outputs of tile ct][16 samples] = W(ct) * rows, K = 32*kbn.
+// In two parts, so that the weight fragments (L2 round trips) can be issued a phase ahead of the rows they multiply.
 template <int CTN, int KBN>
-__device__ __forceinline__ f4 fc_tile(__amdgpu_buffer_rsrc_t rw, int half_off, int ct,
-                                      const unsigned char* rows, int row_stride, int lane) {
-    f4 d = (f4){0.f, 0.f, 0.f, 0.f};
-    const unsigned char* bp = rows + (lane & 15) * row_stride + (lane >> 4) * 16;
+__device__ __forceinline__ void fc_load(__amdgpu_buffer_rsrc_t rw, int half_off, int ct, int lane, h8 (&a)[KBN]) {
     const int wbyte = __builtin_amdgcn_readfirstlane(half_off * 2 + ct * 1024);
-    h8 a[KBN];
 #pragma unroll
     for (int kb = 0; kb < KBN; ++kb) a[kb] = load_wfrag(rw, lane * 16, wbyte + kb * CTN * 1024);
+}
+template <int KBN>
+__device__ __forceinline__ f4 fc_mma(const h8 (&a)[KBN], const unsigned char* rows, int row_stride, int lane) {
+    f4 d = (f4){0.f, 0.f, 0.f, 0.f};
+    const unsigned char* bp = rows + (lane & 15) * row_stride + (lane >> 4) * 16;
 #pragma unroll
     for (int kb = 0; kb < KBN; ++kb)
         d = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[kb], *reinterpret_cast<const h8*>(bp + kb * 64), d, 0, 0, 0);
     return d;
+}
+template <int CTN, int KBN>
+__device__ __forceinline__ f4 fc_tile(__amdgpu_buffer_rsrc_t rw, int half_off, int ct,
+                                      const unsigned char* rows, int row_stride, int lane) {
+    h8 a[KBN];
+    fc_load<CTN, KBN>(rw, half_off, ct, lane, a);
+    return fc_mma<KBN>(a, rows, row_stride, lane);
 }
 
 // write one head map (64 channels wide) from a wave's 2 output tiles: channel = (tile_in_map*16) + ...
@@ -625,6 +644,12 @@ __device__ __forceinline__ void net_pass(const NetParams& P, unsigned char* lds,
     }
     if (P.debug_stop == 2) { if (lane == 0 && x[0][0][0] == 123.f) lp1[0] = 1.f; return; }   // after the stem
     // ---- residual blocks: every global load (weights, parameters) is issued one phase ahead ----
+#ifdef LZ_EXP_HEAD_STAMPS   /* timing experiment: stamps of every wave at the head sub-steps (scripts/exp_head_stamps.py) */
+#define LZ_HSTAMP(k) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); hstamps[k] = __builtin_readcyclecounter(); }
+    uint64_t hstamps[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#else
+#define LZ_HSTAMP(k)
+#endif
 #ifdef LZ_EXP_STAMPS   /* timing experiment: s_memtime stamps of one wave through block 2 */
 #define LZ_STAMP(k) if (blk == 2) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); stamps[k] = __builtin_readcyclecounter(); }
     uint64_t stamps[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -665,6 +690,7 @@ __device__ __forceinline__ void net_pass(const NetParams& P, unsigned char* lds,
         for (int k = 0; k < 9; ++k) vlogits[wave * 16 + k] = (float)(stamps[k] - stamps[0]);
 #endif
     if (P.debug_stop == 3) { if (lane == 0 && x[0][0][0] == 123.f) lp1[0] = 1.f; return; }   // after the trunk
+    LZ_HSTAMP(0)
     // ---- trunk output h = relu(a*x + b) -> LDS; head 1x1 convs (8 output tiles: policy 0..3 | value 4..7) ----
     int tid_h = tid;
     asm volatile("" : "+v"(tid_h));                            // see tid_s: nothing below is live across the trunk
@@ -689,33 +715,44 @@ __device__ __forceinline__ void net_pass(const NetParams& P, unsigned char* lds,
         conv_gemm<C, S, false, false, 8, NW>(x, rw, wh, ht1, lds, base, lane, Af, mirror, row_step);
     }
     __syncthreads();
+    LZ_HSTAMP(1)
     if (P.debug_stop == 4) { if (lane == 0 && (acc[0][0][0] + x[0][0][0]) == 123.f) lp1[0] = 1.f; return; }   // after head convs
     // ---- policy head (skipped when the caller only wants values: lp1 == nullptr) ----
     if (lp1 != nullptr) {
     if (ht0 < 4) store_head<C, S, NW>(acc, lds, base, ht0, rf, P.head_bias, lane);
+    // the weights of the next two steps travel while the map is pooled (every wave loads: an unconditional array is not
+    // kept alive across the trunk, see the note on the head loads in DESIGN.md)
+    h8 gw[6];
+    fc_load<4, 6>(rw, P.hf_gw, wave & 3, lane_h, gw);
+    const h8 wo0 = load_wfrag(rw, lane_h * 16, P.hf_out * 2);
+    const h8 wo1 = load_wfrag(rw, lane_h * 16, P.hf_out * 2 + 1024);
     __syncthreads();
+    LZ_HSTAMP(2)
     gpool64<C, S>(lds, tid_h);
     __syncthreads();
+    LZ_HSTAMP(3)
     if (wave < 4) {                                            // g = gpool_linear(pooled): 4 tiles x K=192
-        const f4 d = fc_tile<4, 6>(rw, P.hf_gw, wave, lds + K::POOL_OFF, K::POOL_STRIDE, lane_h);
+        const f4 d = fc_mma<6>(gw, lds + K::POOL_OFF, K::POOL_STRIDE, lane_h);
         const int s = lane_h & 15, ch = wave * 16 + (lane_h >> 4) * 4;
         *reinterpret_cast<f4*>(gvec + s * kHead + ch) = d;
     }
     __syncthreads();
+    LZ_HSTAMP(4)
     // three 1x1 output convs on p2 = relu(bn2(p + g)): p2 is formed in registers on the B fragment
     // (every [cell][8-channel chunk] is read exactly once), 1 output tile x K=64 on the matrix cores
     {
-        float pa2[2][8], pb2[2][8];
+        // bn2's per-channel scale / shift of the lane's two 8-channel chunks, as vectors: the transform of a chunk is two
+        // packed-fp32 adds, multiplies and adds and one packed fp16 max per four channels (the same operations per element
+        // as the scalar form -- add, multiply, add, no contraction -- so the same values)
+        f4 pa2[2][2], pb2[2][2];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int ch = (kb * 4 + (lane_h >> 4)) * 8 + k;
-                pa2[kb][k] = par[ch];
-                pb2[kb][k] = par[kHead + ch];
+            for (int hf = 0; hf < 2; ++hf) {
+                const int ch = (kb * 4 + (lane_h >> 4)) * 8 + hf * 4;
+                pa2[kb][hf] = *reinterpret_cast<const f4*>(par + ch);
+                pb2[kb][hf] = *reinterpret_cast<const f4*>(par + kHead + ch);
             }
-        const h8 wo0 = load_wfrag(rw, lane_h * 16, P.hf_out * 2);
-        const h8 wo1 = load_wfrag(rw, lane_h * 16, P.hf_out * 2 + 1024);
         for (int t = wave; t < K::NT; t += K::WAVES) {
             f4 d = (f4){0.f, 0.f, 0.f, 0.f};
             const int n = t * 16 + (lane_h & 15);
@@ -723,13 +760,14 @@ __device__ __forceinline__ void net_pass(const NetParams& P, unsigned char* lds,
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
                 const int chunk = kb * 4 + (lane_h >> 4);
-                h8 v = *reinterpret_cast<const h8*>(lds + act_addr<C, S>(n, chunk));
+                const h8 v = *reinterpret_cast<const h8*>(lds + act_addr<C, S>(n, chunk));
                 const f4 g0 = *reinterpret_cast<const f4*>(gvec + s * kHead + chunk * 8);
                 const f4 g1 = *reinterpret_cast<const f4*>(gvec + s * kHead + chunk * 8 + 4);
-#pragma unroll
-                for (int k = 0; k < 8; ++k)
-                    v[k] = (_Float16)fmaxf(((float)v[k] + (k < 4 ? g0[k] : g1[k - 4])) * pa2[kb][k] + pb2[kb][k], 0.f);
-                d = __builtin_amdgcn_mfma_f32_16x16x32_f16(kb == 0 ? wo0 : wo1, v, d, 0, 0, 0);
+                const h4 lo = __builtin_shufflevector(v, v, 0, 1, 2, 3), hi = __builtin_shufflevector(v, v, 4, 5, 6, 7);
+                const h4 r0 = relu_h4((__builtin_convertvector(lo, f4) + g0) * pa2[kb][0] + pb2[kb][0]);
+                const h4 r1 = relu_h4((__builtin_convertvector(hi, f4) + g1) * pa2[kb][1] + pb2[kb][1]);
+                const h8 b = __builtin_shufflevector(r0, r1, 0, 1, 2, 3, 4, 5, 6, 7);
+                d = __builtin_amdgcn_mfma_f32_16x16x32_f16(kb == 0 ? wo0 : wo1, b, d, 0, 0, 0);
             }
             if (lane_h < 16) {
                 plog[(s * 3 + 0) * 36 + p] = d[0];
@@ -739,54 +777,125 @@ __device__ __forceinline__ void net_pass(const NetParams& P, unsigned char* lds,
         }
     }
     __syncthreads();
-    for (int row = wave; row < S * 3; row += K::WAVES) {        // log_softmax over the 36 cells, one wave per row
-        const int s = row / 3, h = row - s * 3;
-        const float v = lane_h < 36 ? plog[row * 36 + lane_h] : -INFINITY;
-        const float mx = lzw::wave_max(v);
-        const float e = lzw::wave_sum(lane_h < 36 ? expf(v - mx) : 0.f);
-        const float lse = mx + logf(e);
-        if (lane_h < 36 && s < nvalid) (h == 0 ? lp1 : h == 1 ? lp2 : lpm)[(n0 + s) * 36 + lane_h] = v - lse;
+    LZ_HSTAMP(5)
+    {   // log_softmax over the 36 cells, one wave per row; a wave's rows go through the steps together (independent
+        // reduction chains side by side instead of one row's dependent chain after the other: same arithmetic per row)
+        constexpr int RPW = (S * 3 + K::WAVES - 1) / K::WAVES;
+        float v[RPW], mx[RPW], e[RPW];
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+            const int row = wave + i * K::WAVES;
+            v[i] = (row < S * 3 && lane_h < 36) ? plog[row * 36 + lane_h] : -INFINITY;
+        }
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) mx[i] = lzw::wave_max(v[i]);
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) e[i] = lane_h < 36 ? expf(v[i] - mx[i]) : 0.f;
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) e[i] = lzw::wave_sum(e[i]);
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+            const int row = wave + i * K::WAVES;
+            const int s = row / 3, h = row - s * 3;
+            const float lse = mx[i] + logf(e[i]);
+            if (row < S * 3 && lane_h < 36 && s < nvalid) (h == 0 ? lp1 : h == 1 ? lp2 : lpm)[(n0 + s) * 36 + lane_h] = v[i] - lse;
+        }
     }
     __syncthreads();
+    LZ_HSTAMP(6)
     }
     if (P.debug_stop == 5) { if (lane_h == 0 && x[0][0][0] == 123.f) lp1[0] = 1.f; return; }   // after the policy head
     // ---- value head ----
     if (K::HP == 2) store_head<C, S, NW>(x, lds, base, ht1 - 4, rf, P.head_bias + kHead, lane);
     else if (ht0 >= 4) store_head<C, S, NW>(acc, lds, base, ht0 - 4, rf, P.head_bias + kHead, lane);
+    // fc1 / fc2 weights and biases of this wave's output tiles travel while the map is pooled (a tile index past the
+    // last one is clamped: the load stays in bounds, the result is not used)
+    constexpr int R1 = (8 + K::WAVES - 1) / K::WAVES, R2 = (7 + K::WAVES - 1) / K::WAVES;
+    h8 w1[R1][6], w2[R2][4];
+    f4 b1[R1], b2[R2];
+#pragma unroll
+    for (int r = 0; r < R1; ++r) {
+        const int ct = wave + r * K::WAVES < 8 ? wave + r * K::WAVES : 7;
+        fc_load<8, 6>(rw, P.hf_w1, ct, lane_h, w1[r]);
+        b1[r] = load_f4(rf, (lane_h >> 4) * 4, P.v_b1 + ct * 16);
+    }
+#pragma unroll
+    for (int r = 0; r < R2; ++r) {
+        const int ct = wave + r * K::WAVES < 7 ? wave + r * K::WAVES : 6;
+        fc_load<7, 4>(rw, P.hf_w2, ct, lane_h, w2[r]);
+        b2[r] = load_f4(rf, (lane_h >> 4) * 4, P.v_b2 + ct * 16);       // bins past 101: never stored
+    }
     __syncthreads();
+    LZ_HSTAMP(7)
     gpool64<C, S>(lds, tid_h);
     __syncthreads();
-    for (int ct = wave; ct < 8; ct += K::WAVES) {               // fc1 + relu: 8 tiles x K=192
-        const f4 d = fc_tile<8, 6>(rw, P.hf_w1, ct, lds + K::POOL_OFF, K::POOL_STRIDE, lane_h);
-        const int s = lane_h & 15, ch = ct * 16 + (lane_h >> 4) * 4;
-        const f4 b = load_f4(rf, (lane_h >> 4) * 4, P.v_b1 + ct * 16);
-        const f4 v = d + b;
-        *reinterpret_cast<h4*>(lds + K::HID_OFF + s * K::HID_STRIDE + ch * 2) =
-            to_h4(fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f));
-    }
-    __syncthreads();
-    float* vl = plog;                                           // [16][112] value logits
-    for (int ct = wave; ct < 7; ct += K::WAVES) {               // fc2: 7 tiles (101 bins padded to 112) x K=128
-        const f4 d = fc_tile<7, 4>(rw, P.hf_w2, ct, lds + K::HID_OFF, K::HID_STRIDE, lane_h);
-        const int s = lane_h & 15, o = ct * 16 + (lane_h >> 4) * 4;
+    LZ_HSTAMP(8)
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-            if (o + r < kBins) vl[s * K::VL_STRIDE + o + r] = d[r] + fp[P.v_b2 + o + r];
-    }
-    __syncthreads();
-    for (int s = wave; s < nvalid; s += K::WAVES) {              // bucket expectation, one wave per sample
-        const float v0 = vl[s * K::VL_STRIDE + lane_h];
-        const float v1 = lane_h + 64 < kBins ? vl[s * K::VL_STRIDE + lane_h + 64] : -INFINITY;
-        const float mx = lzw::wave_max(fmaxf(v0, v1));
-        const float e0 = expf(v0 - mx), e1 = lane_h + 64 < kBins ? expf(v1 - mx) : 0.f;
-        const float sum = lzw::wave_sum(e0 + e1);
-        const float ex = lzw::wave_sum(e0 * (-1.0f + 0.02f * (float)lane_h) + e1 * (-1.0f + 0.02f * (float)(lane_h + 64)));
-        if (lane_h == 0 && value != nullptr) value[n0 + s] = ex / sum;
-        if (vlogits != nullptr) {
-            vlogits[(n0 + s) * kBins + lane_h] = v0;
-            if (lane_h + 64 < kBins) vlogits[(n0 + s) * kBins + lane_h + 64] = v1;
+    for (int r = 0; r < R1; ++r) {                              // fc1 + relu: 8 tiles x K=192
+        const int ct = wave + r * K::WAVES;
+        if (ct < 8) {
+            const f4 v = fc_mma<6>(w1[r], lds + K::POOL_OFF, K::POOL_STRIDE, lane_h) + b1[r];
+            const int s = lane_h & 15, ch = ct * 16 + (lane_h >> 4) * 4;
+            *reinterpret_cast<h4*>(lds + K::HID_OFF + s * K::HID_STRIDE + ch * 2) =
+                to_h4(fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f));
         }
     }
+    __syncthreads();
+    LZ_HSTAMP(9)
+    float* vl = plog;                                           // [16][112] value logits
+#pragma unroll
+    for (int r = 0; r < R2; ++r) {                              // fc2: 7 tiles (101 bins padded to 112) x K=128
+        const int ct = wave + r * K::WAVES;
+        if (ct < 7) {
+            const f4 d = fc_mma<4>(w2[r], lds + K::HID_OFF, K::HID_STRIDE, lane_h);
+            const int s = lane_h & 15, o = ct * 16 + (lane_h >> 4) * 4;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (o + q < kBins) vl[s * K::VL_STRIDE + o + q] = d[q] + b2[r][q];
+        }
+    }
+    __syncthreads();
+    LZ_HSTAMP(10)
+    {   // bucket expectation, one wave per sample; a wave's samples side by side (see the log_softmax above)
+        constexpr int SPW = (S + K::WAVES - 1) / K::WAVES;
+        float v0[SPW], v1[SPW], mx[SPW], e0[SPW], e1[SPW], sum[SPW], ex[SPW];
+#pragma unroll
+        for (int i = 0; i < SPW; ++i) {
+            const int s = wave + i * K::WAVES;
+            const bool on = s < nvalid;
+            v0[i] = on ? vl[s * K::VL_STRIDE + lane_h] : 0.f;
+            v1[i] = (on && lane_h + 64 < kBins) ? vl[s * K::VL_STRIDE + lane_h + 64] : -INFINITY;
+        }
+#pragma unroll
+        for (int i = 0; i < SPW; ++i) mx[i] = lzw::wave_max(fmaxf(v0[i], v1[i]));
+#pragma unroll
+        for (int i = 0; i < SPW; ++i) {
+            e0[i] = expf(v0[i] - mx[i]);
+            e1[i] = lane_h + 64 < kBins ? expf(v1[i] - mx[i]) : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < SPW; ++i) sum[i] = lzw::wave_sum(e0[i] + e1[i]);
+#pragma unroll
+        for (int i = 0; i < SPW; ++i)
+            ex[i] = lzw::wave_sum(e0[i] * (-1.0f + 0.02f * (float)lane_h) + e1[i] * (-1.0f + 0.02f * (float)(lane_h + 64)));
+#pragma unroll
+        for (int i = 0; i < SPW; ++i) {
+            const int s = wave + i * K::WAVES;
+            if (s < nvalid) {
+                if (lane_h == 0 && value != nullptr) value[n0 + s] = ex[i] / sum[i];
+                if (vlogits != nullptr) {
+                    vlogits[(n0 + s) * kBins + lane_h] = v0[i];
+                    if (lane_h + 64 < kBins) vlogits[(n0 + s) * kBins + lane_h + 64] = v1[i];
+                }
+            }
+        }
+    }
+#ifdef LZ_EXP_HEAD_STAMPS
+    LZ_HSTAMP(11)
+    __syncthreads();
+    if (blockIdx.x == 0 && lane_h == 0 && vlogits != nullptr)          // over the block's own value logits (written above)
+        for (int k = 0; k < 12; ++k) vlogits[wave * 16 + k] = (float)(hstamps[k] - hstamps[0]);
+#endif
 }
 
 // kernel-side view of a packed network (host): offsets copied from the descriptor; n_dev / debug_stop left off
