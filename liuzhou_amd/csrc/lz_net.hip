@@ -37,7 +37,14 @@ __global__ __launch_bounds__(W * 64, (C == 128 && W == 4) ? 1 : 2) void net_forw
     if (P.n_dev != nullptr) { const long long nd = *P.n_dev; N = nd < N ? nd : N; }   // count produced on the device
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     NetCtx<C, S, W> ctx;
+#ifdef LZ_EXP_HEAD_STAMPS
+    ctx.t_entry = __builtin_readcyclecounter();
+#endif
     net_setup<C, S, W>(P, lds, ctx);
+#ifdef LZ_EXP_HEAD_STAMPS
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    ctx.t_setup = __builtin_readcyclecounter();
+#endif
     // diagnostic (LZ_NET_DEBUG_STOP=99): shader clock held by this kernel = s_memtime ticks per 100 MHz wall tick
     const uint64_t dbg_t0 = P.debug_stop == 99 ? __builtin_readcyclecounter() : 0;
     const uint64_t dbg_w0 = P.debug_stop == 99 ? wall_clock64() : 0;

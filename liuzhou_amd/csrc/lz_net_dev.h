@@ -519,6 +519,9 @@ struct NetCtx {
     int base[9];                                         // left neighbour of the lane's cell, + the lane's K chunk
     bool mirror;                                         // bottom half board: mirrored rows run upwards
     int row_step;
+#ifdef LZ_EXP_HEAD_STAMPS
+    uint64_t t_entry, t_setup;                           // timing experiment only
+#endif
 };
 
 template <int C, int S, int W>
@@ -581,6 +584,13 @@ __device__ __forceinline__ void net_pass(const NetParams& P, unsigned char* lds,
     float* plog = reinterpret_cast<float*>(lds + K::PLOG_OFF);
     float* par = reinterpret_cast<float*>(lds + K::PAR_OFF);
     __syncthreads();
+#ifdef LZ_EXP_HEAD_STAMPS
+    uint64_t fst[4] = {0, 0, 0, 0};
+#define LZ_FSTAMP(k) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); fst[k] = __builtin_readcyclecounter(); }
+#else
+#define LZ_FSTAMP(k)
+#endif
+    LZ_FSTAMP(0)
     // ---- stage the 11 input planes as fp16 rows [cell][32 ch] (ch >= 11 zero) ----
     // (opaque copy of the thread id: the staging / head index arithmetic below is recomputed per pass instead of
     //  being hoisted out of the pass loop and spilled around the trunk)
@@ -620,7 +630,9 @@ __device__ __forceinline__ void net_pass(const NetParams& P, unsigned char* lds,
             *reinterpret_cast<h8*>(lds + act_addr<C, S>(n, q)) = v;
         }
     }
+    LZ_FSTAMP(1)
     __syncthreads();
+    LZ_FSTAMP(2)
     if (P.debug_stop == 1) return;                       // after input staging
 
     Acc x, acc;
@@ -642,6 +654,7 @@ __device__ __forceinline__ void net_pass(const NetParams& P, unsigned char* lds,
             x[i][j] = (f4){fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
         }
     }
+    LZ_FSTAMP(3)
     if (P.debug_stop == 2) { if (lane == 0 && x[0][0][0] == 123.f) lp1[0] = 1.f; return; }   // after the stem
     // ---- residual blocks: every global load (weights, parameters) is issued one phase ahead ----
 #ifdef LZ_EXP_HEAD_STAMPS   /* timing experiment: stamps of every wave at the head sub-steps (scripts/exp_head_stamps.py) */
@@ -893,8 +906,15 @@ __device__ __forceinline__ void net_pass(const NetParams& P, unsigned char* lds,
 #ifdef LZ_EXP_HEAD_STAMPS
     LZ_HSTAMP(11)
     __syncthreads();
-    if (blockIdx.x == 0 && lane_h == 0 && vlogits != nullptr)          // over the block's own value logits (written above)
-        for (int k = 0; k < 12; ++k) vlogits[wave * 16 + k] = (float)(hstamps[k] - hstamps[0]);
+    if (blockIdx.x == 0 && lane_h == 0 && vlogits != nullptr) {        // over the block's own value logits (written above)
+        for (int k = 0; k < 12; ++k) vlogits[wave * 24 + k] = (float)(hstamps[k] - hstamps[0]);
+        vlogits[wave * 24 + 12] = (float)(ctx.t_setup - ctx.t_entry);   // net_setup
+        vlogits[wave * 24 + 13] = (float)(fst[0] - ctx.t_setup);        // first barrier
+        vlogits[wave * 24 + 14] = (float)(fst[1] - fst[0]);             // staging loop
+        vlogits[wave * 24 + 15] = (float)(fst[2] - fst[1]);             // barrier after staging
+        vlogits[wave * 24 + 16] = (float)(fst[3] - fst[2]);             // stem
+        vlogits[wave * 24 + 17] = (float)(hstamps[0] - fst[3]);         // residual blocks
+    }
 #endif
 }
 

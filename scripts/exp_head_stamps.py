@@ -24,8 +24,11 @@ for name, N, half in (("b6c64", 2048, True), ("b6c64", 4096, False), ("b10c128",
         out = f(x, want_logits=True)
     torch.cuda.synchronize()
     nw = 4 if half else 8
-    st = out[3].view(-1)[:nw * 16].view(nw, 16)[:, :12].cpu()
+    raw = out[3].view(-1)[:nw * 24].view(nw, 24).cpu()
+    st = raw[:, :12]
     print(name, N, "half workgroups" if half else "")
+    front = ["net_setup", "first barrier", "staging loop", "barrier", "stem", "residual blocks"]
     for w in range(0, nw, max(1, nw // 4)):
         d = (st[w, 1:] - st[w, :-1]).tolist()
-        print(f"  wave {w}: " + "  ".join(f"{n} {int(v)}" for n, v in zip(names, d)) + f"  | total {int(st[w, 11])}")
+        print(f"  wave {w}: " + "  ".join(f"{n} {int(v)}" for n, v in zip(front, raw[w, 12:18].tolist())))
+        print(f"          " + "  ".join(f"{n} {int(v)}" for n, v in zip(names, d)) + f"  | heads {int(st[w, 11])}")
