@@ -190,6 +190,24 @@ static_assert(tile_map_ok<64, 16>() && tile_map_ok<128, 8>() && tile_map_ok<64, 
 __constant__ const TileMap<64, 8> kTileMap64h = make_tile_map<64, 8>();
 __constant__ const TileMap<64, 16> kTileMap64 = make_tile_map<64, 16>();
 __constant__ const TileMap<128, 8> kTileMap128 = make_tile_map<128, 8>();
+// The same map computed instead of read (net_setup: a __constant__ read is a global round trip at the head of every launch):
+// i = tile % 9 is a compile-time constant where it is used, so the pair's two cells are immediates and `col` selects one.
+__host__ __device__ constexpr int tile_cell_calc(int pg, int i, int col) {
+    const bool is_x = col < 4 || col >= 12;
+    const int k = is_x ? (col < 4 ? col : col - 8) : col - 4;
+    const int rm = kPairCell[i][is_x ? 0 : 1][0], c = kPairCell[i][is_x ? 0 : 1][1];
+    const int r = (pg & 1) ? 5 - rm : rm;
+    return ((pg >> 1) * 8 + k) * 36 + r * 6 + c;
+}
+template <int C, int S>
+constexpr bool tile_calc_ok() {
+    const TileMap<C, S> t = make_tile_map<C, S>();
+    for (int tile = 0; tile < S * 36 / 16; ++tile)
+        for (int col = 0; col < 16; ++col)
+            if (t.cell[tile][col] != tile_cell_calc(tile / 9, tile % 9, col)) return false;
+    return true;
+}
+static_assert(tile_calc_ok<64, 16>() && tile_calc_ok<128, 8>() && tile_calc_ok<64, 8>(), "computed tile map == table");
 template <int C, int S> __device__ __forceinline__ int tile_cell(int tile, int col);
 template <> __device__ __forceinline__ int tile_cell<64, 16>(int tile, int col) { return kTileMap64.cell[tile][col]; }
 template <> __device__ __forceinline__ int tile_cell<128, 8>(int tile, int col) { return kTileMap128.cell[tile][col]; }
@@ -539,28 +557,21 @@ __device__ __forceinline__ void net_setup(const NetParams& P, unsigned char* lds
     ctx.tid = tid; ctx.lane = lane; ctx.wave = wave; ctx.pg = pg; ctx.cg = cg;
     ctx.ct0 = cg * K::CTW;                       // first output-channel tile of this wave
     ctx.chan0 = ctx.ct0 * 16;
-    const float* fp = P.fp;
     ctx.rw = make_rsrc(P.wfrag, P.wfrag_bytes);
     ctx.rf = make_rsrc(P.fp, P.fparams_bytes);
     // per-lane cell geometry of the 9 tiles
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
-        const int n = tile_cell<C, S>(tile0 + i, lane & 15);
+        const int n = tile_cell_calc(pg, i, lane & 15);
         ctx.base[i] = K::ACT_OFF + board_row(n) * K::STRIDE + (lane >> 4) * 32 - K::STRIDE;
     }
     ctx.mirror = (pg & 1) != 0;
     ctx.row_step = ctx.mirror ? -7 * K::STRIDE : 7 * K::STRIDE;
     // zero the whole activation buffer once: the board borders stay zero for every layer / pass
     for (int i = tid; i < K::ZERO_OFF / 16; i += NTHR) reinterpret_cast<uint4*>(lds + K::ACT_OFF)[i] = make_uint4(0, 0, 0, 0);
-    float* par = reinterpret_cast<float*>(lds + K::PAR_OFF);
     for (int i = tid; i < (K::PAR_OFF - K::POOL_OFF) / 4; i += NTHR) reinterpret_cast<uint32_t*>(lds + K::POOL_OFF)[i] = 0u;
-    for (int i = tid; i < 5 * kHead; i += NTHR) {
-        float v;
-        if (i < kHead) v = fp[P.p_a2 + i];
-        else if (i < 2 * kHead) v = fp[P.p_b2 + i - kHead];
-        else v = fp[P.p_out + i - 2 * kHead];
-        par[i] = v;
-    }
+    // (no global read in here: the tile map is computed, the policy head's parameters are fetched by the pass that uses
+    //  them -- a launch of one pass per workgroup starts with LDS writes only)
 }
 
 // One pass: samples n0 .. n0 + nvalid - 1 (nvalid <= S) of `packed` (32-byte bitboard records) or `planes`.
@@ -583,6 +594,19 @@ __device__ __forceinline__ void net_pass(const NetParams& P, unsigned char* lds,
     float* gvec = reinterpret_cast<float*>(lds + K::G_OFF);
     float* plog = reinterpret_cast<float*>(lds + K::PLOG_OFF);
     float* par = reinterpret_cast<float*>(lds + K::PAR_OFF);
+    // ---- stage the 11 input planes as fp16 rows [cell][32 ch] (ch >= 11 zero) ----
+    // (opaque copy of the thread id: the staging / head index arithmetic below is recomputed per pass instead of
+    //  being hoisted out of the pass loop and spilled around the trunk)
+    int tid_s = tid;
+    asm volatile("" : "+v"(tid_s));
+    // packed records: 32 threads per sample, thread k of a sample stages cells k and k + 32 -- ONE 32-byte record per
+    // thread, read before the barrier (it touches no LDS): its round trip overlaps the wait for the slowest wave
+    const int st_s = tid_s >> 5, st_p = tid_s & 31;
+    uint64_t rec0 = 0, rec1 = 0, rec2 = 0, rec3 = 0;
+    if (packed != nullptr && st_s < nvalid) {
+        const uint64_t* rec = packed + (n0 + st_s) * 4;
+        rec0 = rec[0]; rec1 = rec[1]; rec2 = rec[2]; rec3 = rec[3];
+    }
     __syncthreads();
 #ifdef LZ_EXP_HEAD_STAMPS
     uint64_t fst[4] = {0, 0, 0, 0};
@@ -591,43 +615,54 @@ __device__ __forceinline__ void net_pass(const NetParams& P, unsigned char* lds,
 #define LZ_FSTAMP(k)
 #endif
     LZ_FSTAMP(0)
-    // ---- stage the 11 input planes as fp16 rows [cell][32 ch] (ch >= 11 zero) ----
-    // (opaque copy of the thread id: the staging / head index arithmetic below is recomputed per pass instead of
-    //  being hoisted out of the pass loop and spilled around the trunk)
-    int tid_s = tid;
-    asm volatile("" : "+v"(tid_s));
-    for (int n = tid_s; n < K::NPOS; n += NTHR) {
-        const int s = n / 36, p = n - s * 36;
-        _Float16 row[32];
+    if (packed != nullptr) {
+        if (st_s < S) {
+            // 32-byte bitboard record (lz_rules.h: pack): planes = own, opp, own marks, opp marks, phase one-hot
+            const bool on = st_s < nvalid;
+            const bool white = (rec0 >> 53) & 1;
+            const int phase = on ? (int)((rec0 >> 50) & 7) : 0;
+            const uint64_t own = white ? rec1 : rec0, opp = white ? rec0 : rec1;
+            const uint64_t sm = white ? rec3 : rec2, om = white ? rec2 : rec3;
+            for (int p = st_p; p < 36; p += 32) {
+                _Float16 row[32];
 #pragma unroll
-        for (int k = 0; k < 32; ++k) row[k] = (_Float16)0.f;
-        if (s < nvalid) {
-            if (packed != nullptr) {
-                // 32-byte bitboard record (lz_rules.h: pack): planes = own, opp, own marks, opp marks, phase one-hot
-                const uint64_t* rec = packed + (n0 + s) * 4;
-                const uint64_t w0 = rec[0], w1 = rec[1], w2 = rec[2], w3 = rec[3];
-                const bool white = (w0 >> 53) & 1;
-                const int phase = (int)((w0 >> 50) & 7);
-                const uint64_t own = white ? w1 : w0, opp = white ? w0 : w1;
-                const uint64_t sm = white ? w3 : w2, om = white ? w2 : w3;
-                row[0] = (_Float16)(float)((own >> p) & 1);
-                row[1] = (_Float16)(float)((opp >> p) & 1);
-                row[2] = (_Float16)(float)((sm >> p) & 1);
-                row[3] = (_Float16)(float)((om >> p) & 1);
+                for (int k = 0; k < 32; ++k) row[k] = (_Float16)0.f;
+                if (on) {
+                    row[0] = (_Float16)(float)((own >> p) & 1);
+                    row[1] = (_Float16)(float)((opp >> p) & 1);
+                    row[2] = (_Float16)(float)((sm >> p) & 1);
+                    row[3] = (_Float16)(float)((om >> p) & 1);
 #pragma unroll
-                for (int ph = 1; ph <= 7; ++ph) row[3 + ph] = (_Float16)(phase == ph ? 1.f : 0.f);
-            } else {
+                    for (int ph = 1; ph <= 7; ++ph) row[3 + ph] = (_Float16)(phase == ph ? 1.f : 0.f);
+                }
+                const int n = st_s * 36 + p;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    h8 v;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] = row[q * 8 + k];
+                    *reinterpret_cast<h8*>(lds + act_addr<C, S>(n, q)) = v;
+                }
+            }
+        }
+    } else {
+        for (int n = tid_s; n < K::NPOS; n += NTHR) {
+            const int s = n / 36, p = n - s * 36;
+            _Float16 row[32];
+#pragma unroll
+            for (int k = 0; k < 32; ++k) row[k] = (_Float16)0.f;
+            if (s < nvalid) {
                 const float* src = planes + (n0 + s) * 396 + p;
 #pragma unroll
                 for (int ch = 0; ch < 11; ++ch) row[ch] = (_Float16)src[ch * 36];
             }
-        }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            h8 v;
+            for (int q = 0; q < 4; ++q) {
+                h8 v;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] = row[q * 8 + k];
-            *reinterpret_cast<h8*>(lds + act_addr<C, S>(n, q)) = v;
+                for (int k = 0; k < 8; ++k) v[k] = row[q * 8 + k];
+                *reinterpret_cast<h8*>(lds + act_addr<C, S>(n, q)) = v;
+            }
         }
     }
     LZ_FSTAMP(1)
@@ -714,6 +749,16 @@ __device__ __forceinline__ void net_pass(const NetParams& P, unsigned char* lds,
     load_chan_params<NW>(rf, P.trunk_a, chan0, lane, pa);
     load_chan_params<NW>(rf, P.trunk_b, chan0, lane, pb);
     load_first_frags<C, S, false, false, 8, NW>(rw, wh, ht0, lane, Af);
+    // bn2 scale / shift and the three output-conv rows of the policy head (5 x 64 floats): fetched here, parked in LDS
+    // after the head convs, first read two barriers later
+    constexpr int PPT = (5 * kHead + NTHR - 1) / NTHR;
+    float parv[PPT];
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+        const int i = tid_h + j * NTHR;
+        const int src = i < kHead ? P.p_a2 + i : i < 2 * kHead ? P.p_b2 + i - kHead : P.p_out + i - 2 * kHead;
+        parv[j] = i < 5 * kHead ? fp[src] : 0.f;
+    }
     lds_barrier();
     store_act<C, S, true, NW>(x, lds, base, chan0, pa, pb, lane);
     lds_barrier();
@@ -727,6 +772,9 @@ __device__ __forceinline__ void net_pass(const NetParams& P, unsigned char* lds,
         load_first_frags<C, S, false, false, 8, NW>(rw, wh, ht1, lane, Af);
         conv_gemm<C, S, false, false, 8, NW>(x, rw, wh, ht1, lds, base, lane, Af, mirror, row_step);
     }
+#pragma unroll
+    for (int j = 0; j < PPT; ++j)
+        if (tid_h + j * NTHR < 5 * kHead) par[tid_h + j * NTHR] = parv[j];
     __syncthreads();
     LZ_HSTAMP(1)
     if (P.debug_stop == 4) { if (lane == 0 && (acc[0][0][0] + x[0][0][0]) == 123.f) lp1[0] = 1.f; return; }   // after head convs
