@@ -182,11 +182,18 @@ __global__ __launch_bounds__(kBlock) void tree_expand_select_kernel(Tree t, cons
     RootInfo root;
     ptrdiff_t o = 0;
     if (COMPACT) o = (ptrdiff_t)(t.leaf_kind[g] == kLeafExpand ? t.live_row[g] : 0) - g;
+#ifdef LZ_EXP_TREE_STAMPS
+    const unsigned long long lz_t0 = __builtin_readcyclecounter();
+#endif
     tree_expand<IS_ROOT>(t, g, lane, lp1 + o * 36, lp2 + o * 36, lpm + o * 36, nullptr, values + o, noise, noise_stride,
-                         epsilon, sc, &root, step);
+                         epsilon, sc, &root, step LZ_TSTAMP_PASS);
     __threadfence_block();
     if (IS_ROOT) root = load_root_info(t, g);                  // the root record itself was just written
-    tree_select(t, g, lane, root);
+    LZ_TSTAMP(g, 7)                                            // fence (+ root reload)
+    tree_select(t, g, lane, root LZ_TSTAMP_PASS);
+#ifdef LZ_EXP_TREE_STAMPS
+    LZ_TADD(g, 19, 1)
+#endif
 }
 
 // ---- wave-batched leaves: the legacy search of src/mcts.py (batch_K leaves per tree and wave, no virtual loss) ------
@@ -1215,6 +1222,17 @@ static int tree_search_impl(const LzTreeDesc* d, const LzNetDesc* net, int64_t s
     }
     return st();
 }
+
+#ifdef LZ_EXP_TREE_STAMPS
+LZ_API int lz_exp_tree_stamps(unsigned long long* out32, int reset) {
+    if (out32 && hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_tree_stamps), 32 * sizeof(unsigned long long)) != hipSuccess) return LZ_ERR_LAUNCH;
+    if (reset) {
+        unsigned long long z[32] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_tree_stamps), z, sizeof(z)) != hipSuccess) return LZ_ERR_LAUNCH;
+    }
+    return LZ_OK;
+}
+#endif
 
 int lz_root_prepare(const void* root_states, int64_t B, const float* lp1, const float* lp2, const float* lpmc,
                     const float* noise, float epsilon, int64_t* legal_index_mat, float* priors_mat,

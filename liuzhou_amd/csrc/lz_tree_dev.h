@@ -104,6 +104,24 @@ __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 __device__ __forceinline__ int wave_game() {
     return blockIdx.x * kWavesPerBlock + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 }
+#ifdef LZ_EXP_TREE_STAMPS   /* timing experiment (scripts/exp_tree_stamps.py): absolute clocks summed per stamp by ONE game's wave */
+__device__ unsigned long long g_tree_stamps[32];
+#define LZ_TSTAMP_ON(g) ((g) == 5)
+#define LZ_TSTAMP(g, k) if (LZ_TSTAMP_ON(g)) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); \
+        if (lane_id() == 0) { atomicAdd(&g_tree_stamps[k], (unsigned long long)__builtin_readcyclecounter() - lz_t0); \
+                              atomicAdd(&g_tree_stamps[20 + (k)], 1ull); } }
+#define LZ_TSTAMP_ARG , unsigned long long lz_t0 = 0
+#define LZ_TSTAMP_PASS , lz_t0
+#define LZ_TCLOCK(g, var) unsigned long long var = 0; if (LZ_TSTAMP_ON(g)) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); var = __builtin_readcyclecounter(); }
+#define LZ_TADD(g, k, v) if (LZ_TSTAMP_ON(g) && lane_id() == 0) atomicAdd(&g_tree_stamps[k], (unsigned long long)(v));
+#else
+#define LZ_TSTAMP(g, k)
+#define LZ_TCLOCK(g, var)
+#define LZ_TADD(g, k, v)
+#define LZ_TSTAMP_ARG
+#define LZ_TSTAMP_PASS
+#endif
+
 __device__ __forceinline__ double terminal_value_for_mover(const State& s) {   // portable_mcts.py:141-147
     const int st = game_status(s);
     if (st == 1 || st == -1) return st == s.player ? 1.0 : -1.0;
@@ -192,7 +210,7 @@ __device__ __forceinline__ RootInfo load_root_info(const Tree& t, int g) {
     return r;
 }
 
-__device__ __forceinline__ void tree_select(const Tree& t, int g, int lane, const RootInfo& root) {
+__device__ __forceinline__ void tree_select(const Tree& t, int g, int lane, const RootInfo& root LZ_TSTAMP_ARG) {
     if (t.root_terminal[g]) { if (lane == 0) t.leaf_kind[g] = kLeafInactive; return; }
     const Node* nodes = t.nodes + (size_t)g * t.node_cap;
     const Edge* edges = t.edges;                               // pool indices
@@ -206,6 +224,7 @@ __device__ __forceinline__ void tree_select(const Tree& t, int g, int lane, cons
     float term_value = 0.f;
     int leaf_action = 0, leaf_edge = -1;
     while (ne > 0) {
+        LZ_TCLOCK(g, lv_t0)
         // the node's run: a wave-uniform base (scalar 64-bit arithmetic) + a 32-bit lane offset per load
         const Edge* run = edges + (size_t)__builtin_amdgcn_readfirstlane(e0);
         const double sq = sqrt((double)(parent_n > 1 ? parent_n : 1));
@@ -221,6 +240,9 @@ __device__ __forceinline__ void tree_select(const Tree& t, int g, int lane, cons
             const int k = r * kWave + lane;
             if (k < ne) {
                 mine[r] = load_edge(&run[k]);
+#ifdef LZ_EXP_TREE_STAMPS
+                if (r == 0 && LZ_TSTAMP_ON(g)) { LZ_TCLOCK(g, lv_t1) LZ_TADD(g, 16, lv_t1 - lv_t0) lv_t0 = lv_t1; }   // wait for the run
+#endif
                 const int n = edge_n(mine[r].n_info);
                 double q = 0.0;
                 if (n > 0) {
@@ -251,6 +273,9 @@ __device__ __forceinline__ void tree_select(const Tree& t, int g, int lane, cons
         const int c_meta = lzw::lane_bcast((int)(up ? mine[1].act : mine[0].act) | ((int)(up ? mine[1].cn : mine[0].cn) << 8), src);
         const uint8_t info = edge_info(c_ni);
         const int child_player = (info & kInfoWhite) ? -1 : 1;
+#ifdef LZ_EXP_TREE_STAMPS
+        { LZ_TCLOCK(g, lv_t2) LZ_TADD(g, 17, lv_t2 - lv_t0) LZ_TADD(g, 18, 1) }                                        // scores, maximum, broadcast
+#endif
         leaf_edge = e0 + chosen;
         if (lane == 0) path[depth] = leaf_edge | (child_player != node_player ? (int)kPathFlip : 0);
         ++depth;
@@ -268,6 +293,7 @@ __device__ __forceinline__ void tree_select(const Tree& t, int g, int lane, cons
         ne = c_meta >> 8;
         if (depth >= t.path_cap - 1) break;
     }
+    LZ_TSTAMP(g, 8)                                            // descent done
     if (lane == 0) {
         t.path_len[g] = depth;
         t.leaf_kind[g] = kind;
@@ -282,6 +308,7 @@ __device__ __forceinline__ void tree_select(const Tree& t, int g, int lane, cons
             t.leaf_state[g] = pack(leaf);
         }
     }
+    LZ_TSTAMP(g, 9)                                            // leaf state written
 }
 
 // LDS scratch of one wave's expand step: the legal actions of the leaf, compacted (value, action index)
@@ -305,7 +332,8 @@ __device__ __forceinline__ void tree_expand(const Tree& t, int g, int lane, cons
                                             const float* __restrict__ lp2, const float* __restrict__ lpm,
                                             const float* __restrict__ priors220, const float* __restrict__ values,
                                             const float* __restrict__ noise, int noise_stride, float epsilon,
-                                            ExpandScratch sc, RootInfo* root_after = nullptr, int step = -1) {
+                                            ExpandScratch sc, RootInfo* root_after = nullptr, int step = -1 LZ_TSTAMP_ARG) {
+    LZ_TSTAMP(g, 0)
     const int kind = t.leaf_kind[g];
     Node* nodes = t.nodes + (size_t)g * t.node_cap;
     Edge* edges = t.edges;                                     // pool indices
@@ -329,6 +357,7 @@ __device__ __forceinline__ void tree_expand(const Tree& t, int g, int lane, cons
     ne_ld = t.n_edges[g];
     value_ld = values[g];
     if (root_after != nullptr) *root_after = root;
+    LZ_TSTAMP(g, 1)                                            // the independent loads have arrived
     // trace slot of this step (parity tests only; wave-uniform)
     const bool tracing = t.trace_kind != nullptr && step >= 0 && step < t.trace_cap;
     const size_t tslot = tracing ? (size_t)step * (size_t)t.B + (size_t)g : 0;
@@ -448,6 +477,7 @@ __device__ __forceinline__ void tree_expand(const Tree& t, int g, int lane, cons
                 for (int it = 0; it < 4; ++it)
                     if (lg[it]) val[it] = keep * val[it] + epsilon * noise[(size_t)g * noise_stride + slot[it]];
             }
+            LZ_TSTAMP(g, 2)                                    // legal set, head gather, softmax
             // compaction: lane k (and k + 64) takes over the k-th legal action in ascending index order
 #pragma unroll
             for (int it = 0; it < 4; ++it)
@@ -468,6 +498,7 @@ __device__ __forceinline__ void tree_expand(const Tree& t, int g, int lane, cons
 #pragma unroll 4
             for (int k = 0; k < n; ++k) psum += lzw::lane_bcast(k < kWave ? cval[0] : cval[1], k & 63);
             const bool bad = !(psum > 0.f) || !isfinite(psum);
+            LZ_TSTAMP(g, 3)                                    // compaction + sequential renormalisation sum
             // node + edge allocation: the node from the game's bump counter, the run of n edges from the game's open
             // chunk of the pool, or from a new chunk when it does not fit there (runs never straddle chunks)
             int node_id = 0, e0 = 0;
@@ -495,6 +526,7 @@ __device__ __forceinline__ void tree_expand(const Tree& t, int g, int lane, cons
             // pool exhausted (counted in pool_stats[0]; the engine sizes the pool so that this does not happen): the leaf
             // stays unexpanded -- its value is still backed up, the next visit evaluates and tries again
             const int n_write = e0 >= 0 ? n : 0;
+            LZ_TSTAMP(g, 4)                                    // allocation
             // Phase B: one pass (two only when a movement position has more than 64 legal moves)
             Edge* new_run = edges + (size_t)(e0 >= 0 ? e0 : 0);      // wave-uniform base + 32-bit lane offset
             for (int r = 0; r < (n_write > kWave ? 2 : 1); ++r) {
@@ -522,6 +554,7 @@ __device__ __forceinline__ void tree_expand(const Tree& t, int g, int lane, cons
                 new_run[k] = rec;
             }
             backup_value = (double)value_ld;
+            LZ_TSTAMP(g, 5)                                    // child states, terminal tests, edge records
         }
     }
     if (IS_ROOT) return;
@@ -551,6 +584,7 @@ __device__ __forceinline__ void tree_expand(const Tree& t, int g, int lane, cons
         }
         if (root_after != nullptr) root_after->visits = root.visits;
     }
+    LZ_TSTAMP(g, 6)                                            // backup issued
 }
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
