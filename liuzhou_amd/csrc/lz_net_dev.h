@@ -839,27 +839,35 @@ __device__ __forceinline__ void net_pass(const NetParams& P, unsigned char* lds,
     }
     __syncthreads();
     LZ_HSTAMP(5)
-    {   // log_softmax over the 36 cells, one wave per row; a wave's rows go through the steps together (independent
-        // reduction chains side by side instead of one row's dependent chain after the other: same arithmetic per row)
-        constexpr int RPW = (S * 3 + K::WAVES - 1) / K::WAVES;
-        float v[RPW], mx[RPW], e[RPW];
+    {   // log_softmax over the 36 cells of every (sample, head) row.  Sixteen lanes per row, nine of them with four
+        // consecutive cells each: a wave normalises four rows at once with 4-step reductions inside the lane rows of 16
+        // (cyclic rotations: every lane ends up with its row's maximum / sum), instead of one 36-of-64-lane row after the
+        // other with 6-step whole-wave reductions -- half the instructions per wave.  (The sum of a row is now added up in
+        // a different order than the whole-wave reduction did: last-bit differences in the log-probabilities.)
+        constexpr int ROWS = S * 3, PASSES = (ROWS + 4 * K::WAVES - 1) / (4 * K::WAVES);
+        const int k4 = lane_h & 15;
 #pragma unroll
-        for (int i = 0; i < RPW; ++i) {
-            const int row = wave + i * K::WAVES;
-            v[i] = (row < S * 3 && lane_h < 36) ? plog[row * 36 + lane_h] : -INFINITY;
-        }
-#pragma unroll
-        for (int i = 0; i < RPW; ++i) mx[i] = lzw::wave_max(v[i]);
-#pragma unroll
-        for (int i = 0; i < RPW; ++i) e[i] = lane_h < 36 ? expf(v[i] - mx[i]) : 0.f;
-#pragma unroll
-        for (int i = 0; i < RPW; ++i) e[i] = lzw::wave_sum(e[i]);
-#pragma unroll
-        for (int i = 0; i < RPW; ++i) {
-            const int row = wave + i * K::WAVES;
+        for (int pass = 0; pass < PASSES; ++pass) {
+            const int row = (pass * K::WAVES + wave) * 4 + (lane_h >> 4);
+            const bool on = k4 < 9 && row < ROWS;
+            const f4 v = on ? *reinterpret_cast<const f4*>(plog + row * 36 + 4 * k4) : (f4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+            float mx = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+            mx = fmaxf(mx, lzw::dpp_f32<0x128, 0xf>(mx, mx));       // row_ror:8
+            mx = fmaxf(mx, lzw::dpp_f32<0x124, 0xf>(mx, mx));       // row_ror:4
+            mx = fmaxf(mx, lzw::dpp_f32<0x122, 0xf>(mx, mx));       // row_ror:2
+            mx = fmaxf(mx, lzw::dpp_f32<0x121, 0xf>(mx, mx));       // row_ror:1
+            float e = 0.f;
+            if (on) e = ((expf(v[0] - mx) + expf(v[1] - mx)) + expf(v[2] - mx)) + expf(v[3] - mx);
+            e += lzw::dpp_f32<0x128, 0xf>(e, e);
+            e += lzw::dpp_f32<0x124, 0xf>(e, e);
+            e += lzw::dpp_f32<0x122, 0xf>(e, e);
+            e += lzw::dpp_f32<0x121, 0xf>(e, e);
             const int s = row / 3, h = row - s * 3;
-            const float lse = mx[i] + logf(e[i]);
-            if (row < S * 3 && lane_h < 36 && s < nvalid) (h == 0 ? lp1 : h == 1 ? lp2 : lpm)[(n0 + s) * 36 + lane_h] = v[i] - lse;
+            if (on && s < nvalid) {
+                const float lse = mx + logf(e);
+                float* dst = (h == 0 ? lp1 : h == 1 ? lp2 : lpm) + (n0 + s) * 36 + 4 * k4;
+                dst[0] = v[0] - lse; dst[1] = v[1] - lse; dst[2] = v[2] - lse; dst[3] = v[3] - lse;
+            }
         }
     }
     __syncthreads();
