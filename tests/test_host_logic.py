@@ -211,3 +211,15 @@ def test_edge_pool_sizing_arithmetic():
             assert cap * (chunk - (MAX_CHILDREN - 1)) >= node_cap * MAX_CHILDREN
             assert (cap - 2) * (chunk - (MAX_CHILDREN - 1)) < node_cap * MAX_CHILDREN      # and not wastefully long
     assert EDGE_CHUNK == 1024 and EDGE_CHUNK & (EDGE_CHUNK - 1) == 0
+
+
+def test_every_script_compiles():
+    """scripts/ holds ~50 one-off experiment / profiling programs that only run on the GPU box: at least their syntax is
+    checked here, so that a refactor of the package does not leave them unparseable."""
+    import glob
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = sorted(glob.glob(os.path.join(root, "scripts", "*.py")) + glob.glob(os.path.join(root, "scripts", "micro", "*.py")) +
+                   glob.glob(os.path.join(root, "oracle", "*.py")) + [os.path.join(root, "bench.py"), os.path.join(root, "__graft_entry__.py")])
+    assert len(files) > 40
+    for f in files:
+        compile(open(f).read(), f, "exec")                       # syntax only: nothing is written, nothing is run
