@@ -607,8 +607,13 @@ __device__ __forceinline__ void net_pass(const NetParams& P, unsigned char* lds,
         const uint64_t* rec = packed + (n0 + st_s) * 4;
         rec0 = rec[0]; rec1 = rec[1]; rec2 = rec[2]; rec3 = rec[3];
     }
+#ifdef LZ_EXP_HEAD_STAMPS
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    const uint64_t t_before_barrier = __builtin_readcyclecounter();      // own loads and LDS writes have landed
+#endif
     __syncthreads();
 #ifdef LZ_EXP_HEAD_STAMPS
+    const uint64_t t_after_barrier = __builtin_readcyclecounter();
     uint64_t fst[4] = {0, 0, 0, 0};
 #define LZ_FSTAMP(k) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); fst[k] = __builtin_readcyclecounter(); }
 #else
@@ -970,6 +975,9 @@ __device__ __forceinline__ void net_pass(const NetParams& P, unsigned char* lds,
         vlogits[wave * 24 + 15] = (float)(fst[2] - fst[1]);             // barrier after staging
         vlogits[wave * 24 + 16] = (float)(fst[3] - fst[2]);             // stem
         vlogits[wave * 24 + 17] = (float)(hstamps[0] - fst[3]);         // residual blocks
+        vlogits[wave * 24 + 18] = (float)(t_before_barrier - ctx.t_setup);   // record load (hoisted before the barrier)
+        vlogits[wave * 24 + 19] = (float)(t_after_barrier - t_before_barrier);   // the barrier itself
+        vlogits[wave * 24 + 20] = (float)(ctx.t_entry & 0xFFFFFF);           // entry clock (low bits): start skew between waves
     }
 #endif
 }

@@ -32,3 +32,4 @@ for name, N, half in (("b6c64", 2048, True), ("b6c64", 4096, False), ("b10c128",
         d = (st[w, 1:] - st[w, :-1]).tolist()
         print(f"  wave {w}: " + "  ".join(f"{n} {int(v)}" for n, v in zip(front, raw[w, 12:18].tolist())))
         print(f"          " + "  ".join(f"{n} {int(v)}" for n, v in zip(names, d)) + f"  | heads {int(st[w, 11])}")
+        print(f"          record load before the barrier {int(raw[w, 18])}  first barrier alone {int(raw[w, 19])}  entry clock (low 24 bits) {int(raw[w, 20])}")
