@@ -190,3 +190,60 @@ def test_reference_move_generator_module_runs_unmodified_over_the_drop_in(tmp_pa
     r = subprocess.run([sys.executable, "-c", CHILD], env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     assert int(r.stdout.split()[-1]) > 300
+
+
+def test_status_and_shape_entry_points_against_the_oracle_and_a_direct_restatement():
+    """`lz_scalar_status` (GetWinner / IsGameOver, game_state.cpp:58-79) against the oracle's game status on the golden
+    states, and `lz_scalar_piece_in_shape` (rule_engine.cpp:194-208) against a cell-by-cell restatement of the shape
+    rules (2x2 block of own unmarked pieces; a full row / column counting the probed cell whatever its mark) on random
+    boards with marks."""
+    import ctypes as C
+    from liuzhou_amd import v0_scalar as V
+    from oracle import lz_oracle as O
+    from tests.golden_utils import states as golden_states
+    fn = V._host()
+    st = golden_states(load("g1_rules.npz"), "s")
+    n = int(st["board"].shape[0])
+    rng = np.random.default_rng(9)
+    for i in rng.integers(0, n, 400).tolist():
+        cs = O.state_from_batch(st, i)
+        c = V._CState()
+        board = np.asarray(st["board"][i]).reshape(36)
+        for j in range(36):
+            c.board[j] = int(board[j])
+        c.phase, c.current_player = int(st["phase"][i]), int(st["current_player"][i])
+        c.move_count, c.moves_since_capture = int(st["move_count"][i]), int(st["moves_since_capture"][i])
+        w, over = C.c_int32(9), C.c_int32(9)
+        assert fn["lz_scalar_status"](C.byref(c), C.byref(w), C.byref(over)) == 0
+        g = O.game_status(cs)                                        # 0 running, +1 / -1 winner, 2 draw
+        assert over.value == (1 if g != 0 else 0) and w.value == (g if g in (1, -1) else 0)
+    for trial in range(300):
+        board = rng.choice([-1, 0, 1], size=(6, 6), p=[0.45, 0.1, 0.45])
+        if trial % 5 == 0:
+            board[rng.integers(0, 6), :] = 1                         # a full row now and then
+        if trial % 7 == 0:
+            board[:, rng.integers(0, 6)] = -1
+        marks = {1: rng.random((6, 6)) < 0.15, -1: rng.random((6, 6)) < 0.15}
+        c = V._CState()
+        for j in range(36):
+            c.board[j] = int(board.reshape(36)[j])
+            c.marks_black[j], c.marks_white[j] = int(marks[1].reshape(36)[j]), int(marks[-1].reshape(36)[j])
+        for use_marks in (0, 1):
+            for player in (1, -1):
+                m = marks[player] if use_marks else np.zeros((6, 6), dtype=bool)
+                free = (board == player) & ~m
+                for r in range(6):
+                    for col in range(6):
+                        want = 0
+                        if board[r, col] == player:
+                            sq = any(0 <= rr < 5 and 0 <= cc < 5 and free[rr:rr + 2, cc:cc + 2].all()
+                                     for rr in (r, r - 1) for cc in (col, col - 1))
+                            row = all(free[r, k] or k == col for k in range(6))
+                            line = all(free[k, col] or k == r for k in range(6))
+                            want = int(sq or row or line)
+                        got = C.c_int32(7)
+                        assert fn["lz_scalar_piece_in_shape"](C.byref(c), r * 6 + col, player, use_marks, C.byref(got)) == 0
+                        assert got.value == want, (trial, use_marks, player, r, col)
+    got = C.c_int32(7)
+    assert fn["lz_scalar_piece_in_shape"](C.byref(c), 36, 1, 0, C.byref(got)) == 0 and got.value == 0       # off the board
+    assert fn["lz_scalar_piece_in_shape"](C.byref(c), 0, 2, 0, C.byref(got)) == -1                         # LZ_ERR_ARG
