@@ -286,16 +286,17 @@ LZ_API int lz_wave_log_finished(const uint8_t* done, int64_t* step_counts, int64
 /* Packed network description (built by liuzhou_amd/net_pack.py from a ChessNet state_dict:
  * BatchNorm folded, conv weights in v_mfma_f32_16x16x32_f16 operand order).  All offsets into
  * `fparams` are in floats, `layer_offsets` (stem, conv1/conv2 per block, stacked head convs) in halfs. */
+#define LZ_NET_MAX_LAYERS 96     /* stem + 2 convs per block + the stacked head convs: up to 47 residual blocks */
 typedef struct LzNetDesc {
     int32_t channels;            /* trunk channels: 64 or 128 */
-    int32_t blocks;              /* residual blocks (<= 15) */
+    int32_t blocks;              /* residual blocks (<= (LZ_NET_MAX_LAYERS - 2) / 2 = 47) */
     int32_t num_layers;          /* 2 + 2*blocks */
     int32_t max_blocks;          /* persistent grid size (0 = 256, one workgroup per CU) */
     const void* wfrag;           /* device, fp16 */
     const float* fparams;        /* device, fp32 */
     int64_t wfrag_bytes;         /* sizes of the two buffers (bounds of the kernel's buffer descriptors) */
     int64_t fparams_bytes;
-    int32_t layer_offsets[32];
+    int32_t layer_offsets[LZ_NET_MAX_LAYERS];
     int32_t head_frag_offsets[4]; /* halfs: gpool_linear [64x192], fc1 [128x192], fc2 [112x128], out convs [16x64] */
     int32_t off_stem_bias, off_block0 /* a1|b1|bias1 per block, 3*C floats each */, off_trunk_a, off_trunk_b,
             off_head_bias, off_p_gwT, off_p_a2, off_p_b2, off_p_out, off_v_w1T, off_v_b1, off_v_w2T, off_v_b2;
@@ -333,6 +334,8 @@ LZ_API int lz_net_forward_packed_counted_f16(const LzNetDesc* net, const void* p
                                              float* value_logits, float* value, void* stream);
 /* one-time kernel attribute setup (dynamic LDS size); call once per process before graph capture */
 LZ_API int lz_net_configure(void);
+/* sizeof(LzNetDesc) as the library was compiled: a binding that lays the struct out itself (ctypes) compares */
+LZ_API int64_t lz_net_desc_bytes(void);
 /* measurement aid (bench.py): when enabled every lz_net_forward_f16 launch is bracketed by HIP events on
  * its own stream; after synchronising, lz_prof_net_summary returns the summed kernel time. */
 LZ_API int lz_prof_enable(int on);

@@ -213,6 +213,8 @@ int lz_prof_aux_summary(int kind, double* total_ms, int64_t* launches, int64_t* 
     return LZ_OK;
 }
 
+int64_t lz_net_desc_bytes(void) { return (int64_t)sizeof(LzNetDesc); }
+
 int lz_net_configure(void) {
     const int a = configure_net<64, 16, 8>(), b = configure_net<128, 8, 8>(), c = configure_net<64, 8, 4>(),
               e = configure_net<128, 8, 4>();
@@ -232,7 +234,7 @@ static int net_forward_impl(const LzNetDesc* d, const float* planes, const uint6
     if (!d->wfrag || !d->fparams || (!planes && !packed)) return LZ_ERR_ARG;
     const bool heads = lp1 && lp2 && lpmc;
     if (!heads && (lp1 || lp2 || lpmc || !value)) return LZ_ERR_ARG;     // all three policy outputs, or values only
-    if (d->blocks < 0 || d->blocks > 15 || d->num_layers != 2 + 2 * d->blocks) return LZ_ERR_ARG;
+    if (d->blocks < 0 || d->blocks > (LZ_NET_MAX_LAYERS - 2) / 2 || d->num_layers != 2 + 2 * d->blocks) return LZ_ERR_ARG;
     if ((reinterpret_cast<uintptr_t>(d->wfrag) & 15) || (reinterpret_cast<uintptr_t>(d->fparams) & 15)) return LZ_ERR_ALIGN;
     if (d->flags & 4)
         return lz_net_forward_f32_dispatch(d, planes, packed, N, lp1, lp2, lpmc, value_logits, value, n_dev, stream);

@@ -42,7 +42,7 @@ constexpr int kPool = 3 * kHead;
 struct NetParams {
     const _Float16* wfrag;
     const float* fp;
-    int layer_off[32];          // offsets in halfs: stem, (conv1, conv2) x blocks, heads
+    int layer_off[LZ_NET_MAX_LAYERS];   // offsets in halfs: stem, (conv1, conv2) x blocks, heads
     int hf_gw, hf_w1, hf_w2, hf_out;   // offsets in halfs of the head FC fragments (gpool_linear, fc1, fc2, 3 out convs)
     int wfrag_bytes, fparams_bytes;
     int debug_stop;             // diagnostic builds only: leave the pass after phase k (0 = run everything)
@@ -987,7 +987,7 @@ inline NetParams make_net_params(const LzNetDesc* d) {
     NetParams P;
     P.wfrag = reinterpret_cast<const _Float16*>(d->wfrag);
     P.fp = d->fparams;
-    for (int i = 0; i < 32; ++i) P.layer_off[i] = i < d->num_layers ? d->layer_offsets[i] : 0;
+    for (int i = 0; i < LZ_NET_MAX_LAYERS; ++i) P.layer_off[i] = i < d->num_layers ? d->layer_offsets[i] : 0;
     P.blocks = d->blocks;
     P.n_dev = nullptr;
     P.wfrag_bytes = (int)d->wfrag_bytes; P.fparams_bytes = (int)d->fparams_bytes;

@@ -30,7 +30,7 @@ constexpr int kThreads = 256, kWaves = 4, kWave = 64;
 struct Params {
     const float* w;             // fp32 conv fragments
     const float* fp;            // per-channel parameters + dense head matrices (the fp16 kernel's fparams)
-    int layer_off[32];          // element offsets of stem, (conv1, conv2) x blocks, stacked head convs
+    int layer_off[LZ_NET_MAX_LAYERS];   // element offsets of stem, (conv1, conv2) x blocks, stacked head convs
     int blocks;
     int stem_bias, blk0, trunk_a, trunk_b, head_bias, p_gwT, p_a2, p_b2, p_out, v_w1T, v_b1, v_w2T, v_b2;
     const long long* n_dev;

@@ -152,10 +152,19 @@ __device__ __forceinline__ void release_chunks_wave(const Tree& t, int g, int ke
         if (lane == 0) t.n_chunks[g] = keep;
     }
 }
+// Is game g's root a live fresh root that has not expanded yet?  pool_stats[2] counts exactly the games in this state
+// (zero-filled arenas: n_nodes == 0, not pending), so every transition is booked as a difference: a second begin of a
+// pending root, a begin after an advance that left a fresh root, a callback that failed before the root expansion or
+// a refused root take leave the count where it is instead of leaking a chunk per event.
+__device__ __forceinline__ bool root_pending(const Tree& t, int g) {
+    return t.n_nodes[g] == 1 && t.nodes[(size_t)g * t.node_cap].nedges < 0 && t.root_terminal[g] == 0;
+}
+
 // one thread takes a chunk from the pool for game g: its first pool index, or -1 (pool empty / list full; counted).
-// A chunk stays reserved for every fresh root that has not expanded yet (pool_stats[2]; begin kernels count them up, the
-// root's own take counts down): games progress independently, and a root whose expansion found the pool drained by the
-// other games' deeper nodes would stay unexpanded for the whole search and end with an all-zero policy.
+// A chunk stays reserved for every fresh root that has not expanded yet (pool_stats[2] = the number of games whose root
+// is in the root_pending state: begin kernels and the root's own take book the transitions): games progress
+// independently, and a root whose expansion found the pool drained by the other games' deeper nodes would stay
+// unexpanded for the whole search and end with an all-zero policy.
 // Inside an expand launch the count only falls, so a stale read is conservative.
 __device__ __forceinline__ int take_chunk(const Tree& t, int g, bool for_root = false) {
     const int nc = t.n_chunks[g];
@@ -163,7 +172,7 @@ __device__ __forceinline__ int take_chunk(const Tree& t, int g, bool for_root = 
     const int top = atomicSub(t.pool_top, 1) - 1;            // free chunks left after this take
     const int reserved = for_root ? 0 : __atomic_load_n(t.pool_stats + 2, __ATOMIC_RELAXED);
     if (top < reserved) { atomicAdd(t.pool_top, 1); atomicAdd(t.pool_stats, 1); return -1; }
-    if (for_root) atomicSub(t.pool_stats + 2, 1);
+    if (for_root && root_pending(t, g)) atomicSub(t.pool_stats + 2, 1);
     atomicMin(t.pool_stats + 1, top);
     const int cid = t.free_chunks[top];
     t.chunk_list[(size_t)g * t.chunk_cap + nc] = cid;
@@ -172,6 +181,7 @@ __device__ __forceinline__ int take_chunk(const Tree& t, int g, bool for_root = 
 }
 
 __device__ __forceinline__ void begin_game(const Tree& t, int g, bool release = true) {
+    const bool was_pending = root_pending(t, g);
     if (release) release_chunks(t, g, 0);
     const Packed rs = t.root_state[g];
     Node& root = t.nodes[(size_t)g * t.node_cap];
@@ -190,7 +200,8 @@ __device__ __forceinline__ void begin_game(const Tree& t, int g, bool release = 
     const bool term = game_status(s) != 0;                // portable_mcts.py:601-603
     t.root_terminal[g] = (term || !act) ? 1 : 0;
     t.leaf_kind[g] = (term || !act) ? kLeafInactive : kLeafExpand;
-    if (!(term || !act)) atomicAdd(t.pool_stats + 2, 1);   // this root will need the chunk of its first expansion
+    const bool pending = !(term || !act);                  // this root will need the chunk of its first expansion
+    if (pending != was_pending) atomicAdd(t.pool_stats + 2, pending ? 1 : -1);
     t.leaf_state[g] = rs;                                  // the root is the first pending evaluation
     t.leaf_value[g] = 0.f;
 }
@@ -412,7 +423,11 @@ __device__ __forceinline__ void tree_expand(const Tree& t, int g, int lane, cons
             // portable_mcts.py:433-441: no legal move on a non-finished state => terminal, value -1
             backup_value = -1.0;
             if (lane == 0) {
-                if (IS_ROOT) { nodes[0].nedges = 0; t.root_terminal[g] = 1; t.root_init_value[g] = -1.f; }
+                if (IS_ROOT) {
+                    // (a live fresh root that turns out to have no move takes no chunk: its reservation ends here)
+                    if (root_pending(t, g)) atomicSub(t.pool_stats + 2, 1);
+                    nodes[0].nedges = 0; t.root_terminal[g] = 1; t.root_init_value[g] = -1.f;
+                }
                 else atomicOr(&edges[(size_t)leaf_edge].n_info, (uint32_t)kInfoTerminal << 24);   // value bits stay 0 (= -1)
             }
         } else {

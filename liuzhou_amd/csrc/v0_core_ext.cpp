@@ -157,6 +157,33 @@ std::vector<Tensor> batch_apply_moves(const Tensor& board, const Tensor& mb, con
     return std::vector<Tensor>(out.t.begin(), out.t.end());
 }
 
+// The in-place operators hand the caller's storages straight to the kernels (nothing is converted: a copy would not be
+// mutated), so what the non-in-place operators get from as() has to be CHECKED here: dtype (int8 board, bool marks,
+// int64 scalars), one device, contiguity, one batch size -- as module.cpp's TORCH_CHECKs do; an int32 `phase` or a CPU
+// tensor among HIP ones would otherwise be an out-of-bounds or garbage device access.
+void check_inplace_states(const Tensor* const (&all)[12], const char* op) {
+    static const char* names[12] = {"board", "marks_black", "marks_white", "phase", "current_player",
+                                    "pending_marks_required", "pending_marks_remaining", "pending_captures_required",
+                                    "pending_captures_remaining", "forced_removals_done", "move_count",
+                                    "moves_since_capture"};
+    const Tensor& board = *all[0];
+    if (board.dim() < 1) throw std::runtime_error(std::string(op) + ": board must be [B, 6, 6]");
+    const int64_t B = board.size(0);
+    for (int i = 0; i < 12; ++i) {
+        const Tensor& t = *all[i];
+        const at::ScalarType want = i == 0 ? at::kChar : i < 3 ? at::kBool : at::kLong;
+        if (!t.defined() || t.scalar_type() != want)
+            throw std::runtime_error(std::string(op) + ": " + names[i] + " must be " +
+                                     (i == 0 ? "int8" : i < 3 ? "bool" : "int64") + " (it is mutated in place)");
+        if (t.device() != board.device())
+            throw std::runtime_error(std::string(op) + ": " + names[i] + " is not on the board's device");
+        if (!t.is_contiguous())
+            throw std::runtime_error(std::string(op) + ": state tensors must be contiguous (they are mutated)");
+        if (t.numel() != (i < 3 ? B * 36 : B))
+            throw std::runtime_error(std::string(op) + ": " + names[i] + " does not hold " + std::to_string(B) + " states");
+    }
+}
+
 // ---- fast_apply_moves_cuda.cu:746-917 -------------------------------------------------------------------------------
 void batch_apply_moves_inplace(const Tensor& board, const Tensor& mb, const Tensor& mw, const Tensor& phase,
                                const Tensor& player, const Tensor& pmr, const Tensor& pmm, const Tensor& pcr,
@@ -164,12 +191,12 @@ void batch_apply_moves_inplace(const Tensor& board, const Tensor& mb, const Tens
                                const Tensor& action_codes, const Tensor& slot_indices) {
     States st;
     const Tensor* all[12] = {&board, &mb, &mw, &phase, &player, &pmr, &pmm, &pcr, &pcm, &forced, &move_count, &msc};
-    for (int i = 0; i < 12; ++i) {
-        if (!all[i]->is_contiguous()) throw std::runtime_error("in-place state tensors must be contiguous");
-        st.t[i] = *all[i];
-    }
+    check_inplace_states(all, "batch_apply_moves_inplace");
+    for (int i = 0; i < 12; ++i) st.t[i] = *all[i];
     const Tensor codes = as(action_codes.to(board.device()), at::kInt);
     const Tensor slots = as(slot_indices.to(board.device()), at::kLong).view({-1});
+    if (codes.dim() != 2 || codes.size(1) != 4 || codes.size(0) != slots.numel())
+        throw std::runtime_error("batch_apply_moves_inplace: action_codes must be [N, 4] with one row per slot index");
     const LzStateSoA s = st.soa();
     DeviceScope scope(board);
     check(LZ_FN(board, lz_batch_apply_moves_inplace)(&s, board.size(0), ptr<int32_t>(codes), ptr<int64_t>(slots),
@@ -318,13 +345,13 @@ std::tuple<Tensor, Tensor, Tensor> self_play_step_inplace(
         throw std::runtime_error("plies must be int64 and done must be bool");
     States st;
     const Tensor* all[12] = {&board, &mb, &mw, &phase, &player, &pmr, &pmm, &pcr, &pcm, &forced, &move_count, &msc};
-    for (int i = 0; i < 12; ++i) {
-        if (!all[i]->is_contiguous())
-            throw std::runtime_error("self_play_step_inplace: state tensors must be contiguous (they are mutated)");
-        st.t[i] = *all[i];
-    }
+    check_inplace_states(all, "self_play_step_inplace");
+    for (int i = 0; i < 12; ++i) st.t[i] = *all[i];
     if (!plies.is_contiguous() || !done.is_contiguous())
         throw std::runtime_error("self_play_step_inplace: state tensors must be contiguous (they are mutated)");
+    if (plies.device() != board.device() || done.device() != board.device() || plies.numel() != board.size(0) ||
+        done.numel() != board.size(0))
+        throw std::runtime_error("self_play_step_inplace: plies / done must hold one entry per state on the board's device");
     const Tensor act = as(active_idx.to(board.device()), at::kLong).view({-1});
     const Tensor codes = as(chosen_action_codes.to(board.device()), at::kInt);
     const Tensor term = as(terminal_mask.to(board.device()), at::kBool).view({-1});

@@ -90,8 +90,9 @@ class RootSearchAgent:
 
     def __init__(self, model, device, mcts_simulations: int, temperature: float = 0.1, sample_moves: bool = False) -> None:
         dev = torch.device(device)
-        trunk = int(model.stem_conv.weight.shape[0]) if hasattr(model, "stem_conv") else 0
-        net = FusedNet(model.to(dev).eval(), dev) if trunk in (64, 128) else model.to(dev).eval()
+        from .net_hip import fused_supported
+        net = FusedNet(model.to(dev).eval(), dev) if fused_supported(model) else model.to(dev).eval()
+        self.evaluator = "fused_f16" if isinstance(net, FusedNet) else "torch"
         cfg = V1RootMCTSConfig(num_simulations=max(1, int(mcts_simulations)), exploration_weight=1.0,
                                temperature=float(temperature), add_dirichlet_noise=False, sample_moves=bool(sample_moves))
         self.mcts = V1RootMCTS(model=net, config=cfg, device=dev)

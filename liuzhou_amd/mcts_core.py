@@ -100,9 +100,9 @@ class InferenceEngine:
         self._dtype, self._batch = str(dtype), int(batch_size)
         model = path if isinstance(path, torch.nn.Module) else self._load(path)
         self.model = model.to(self._device).eval()
-        chans = int(self.model.stem_conv.out_channels)
+        from .net_hip import fused_supported
         self.fused: Optional[FusedNet] = None
-        if chans in (64, 128) and self._dtype in ("float16", "half", "fp16", "float32", "fp32"):
+        if fused_supported(self.model) and self._dtype in ("float16", "half", "fp16", "float32", "fp32"):
             self.fused = FusedNet(self.model, self._device,
                                   precision="fp32" if self._dtype in ("float32", "fp32") else "fp16")
 
@@ -174,9 +174,10 @@ class TorchScriptRunner:
             if self._dtype == torch.bfloat16:
                 raise RuntimeError("TorchScriptRunner: the fused network kernel computes in float16 or float32")
             model = InferenceEngine._load(path).to(self._device).eval()
-            chans = int(model.stem_conv.out_channels)
-            if chans not in (64, 128):
-                raise RuntimeError(f"TorchScriptRunner: the fused network kernel is built for 64 / 128 channels, got {chans}")
+            from .net_hip import fused_unsupported_reason
+            why = fused_unsupported_reason(model)
+            if why is not None:
+                raise RuntimeError(f"TorchScriptRunner: the fused network kernel does not cover this model: {why}")
             self.fused = FusedNet(model, self._device, precision="fp32" if self._dtype == torch.float32 else "fp16")
 
     def forward(self, input: torch.Tensor):

@@ -18,10 +18,14 @@ from . import _lib as L
 from .net_pack import NetPack, pack_model, BINS
 
 
+MAX_LAYERS = 96                 # include/liuzhou_hip.h: LZ_NET_MAX_LAYERS (stem + 2 per block + head convs)
+MAX_BLOCKS = (MAX_LAYERS - 2) // 2
+
+
 class LzNetDesc(C.Structure):
     _fields_ = [("channels", C.c_int32), ("blocks", C.c_int32), ("num_layers", C.c_int32), ("max_blocks", C.c_int32),
                 ("wfrag", C.c_void_p), ("fparams", C.c_void_p), ("wfrag_bytes", C.c_int64), ("fparams_bytes", C.c_int64),
-                ("layer_offsets", C.c_int32 * 32),
+                ("layer_offsets", C.c_int32 * MAX_LAYERS),
                 ("head_frag_offsets", C.c_int32 * 4)] + \
                [(n, C.c_int32) for n in ("off_stem_bias", "off_block0", "off_trunk_a", "off_trunk_b", "off_head_bias",
                                          "off_p_gwT", "off_p_a2", "off_p_b2", "off_p_out", "off_v_w1T", "off_v_b1",
@@ -30,6 +34,37 @@ class LzNetDesc(C.Structure):
 
 
 _configured = False
+
+
+def fused_unsupported_reason(model) -> Optional[str]:
+    """None when the fused kernel (csrc/lz_net.hip) is built for `model`'s shape, else what it is not built for.  The
+    reference's ChessNet is generic in every one of these (src/neural_network.py:213-246); a worker or stage must ask
+    before it constructs a `FusedNet` and otherwise evaluate with the module itself (`self_play_worker.pick_evaluator`)."""
+    from .net_pack import HEAD_CH, MLP_CH
+    try:
+        c = int(model.stem_conv.weight.shape[0])
+        nb = len(model.blocks)
+        ph, vh = model.policy_head, model.value_head
+        pc, vc = int(ph.conv1.weight.shape[0]), int(vh.conv1.weight.shape[0])
+        mlp, bins = int(vh.fc1.weight.shape[0]), int(vh.fc2.weight.shape[0])
+        planes = int(model.stem_conv.weight.shape[1])
+    except AttributeError as exc:
+        return f"not a ChessNet-shaped module ({exc})"
+    if c not in (64, 128):
+        return f"trunk channels {c} (kernels are instantiated for 64 and 128)"
+    if nb > MAX_BLOCKS:
+        return f"{nb} residual blocks (descriptor holds {MAX_BLOCKS})"
+    if (pc, vc) != (HEAD_CH, HEAD_CH):
+        return f"policy / value head channels {pc} / {vc} (kernel heads are {HEAD_CH} wide)"
+    if mlp != MLP_CH or bins != BINS:
+        return f"value MLP {mlp} / {bins} bins (kernel: {MLP_CH} / {BINS})"
+    if planes != 11:
+        return f"{planes} input planes (kernel stages 11)"
+    return None
+
+
+def fused_supported(model) -> bool:
+    return fused_unsupported_reason(model) is None
 
 
 class FusedNet:
@@ -49,9 +84,10 @@ class FusedNet:
         if precision not in ("fp16", "fp32"):
             raise ValueError(f"precision must be fp16 or fp32, got {precision!r}")
         self.precision = precision
+        why = fused_unsupported_reason(model)
+        if why is not None:
+            raise RuntimeError(f"fused network kernel does not cover this model: {why}")
         self.pack: NetPack = pack_model(model, fp32_fragments=precision == "fp32").to(dev)
-        if self.pack.channels not in (64, 128):
-            raise RuntimeError(f"fused kernel is built for 64 / 128 trunk channels, got {self.pack.channels}")
         d = LzNetDesc()
         d.channels, d.blocks = self.pack.channels, self.pack.blocks
         d.num_layers = len(self.pack.layer_offsets)
@@ -82,6 +118,9 @@ class FusedNet:
         if not _configured:
             with torch.cuda.device(dev):
                 L.check(L.lib().lz_net_configure(), "net_configure")
+            if int(L.lib().lz_net_desc_bytes()) != C.sizeof(LzNetDesc):
+                raise RuntimeError(f"LzNetDesc layout mismatch: library {int(L.lib().lz_net_desc_bytes())} B, "
+                                   f"binding {C.sizeof(LzNetDesc)} B (stale libliuzhou_hip.so?)")
             _configured = True
 
     def eval(self):

@@ -476,6 +476,49 @@ def stream_worker_shard(play, *, device: torch.device, worker_idx: int, games: i
     return shard.finish(stats, int(log.segments_cut))
 
 
+def streaming_footprint(num_slots: int, max_game_plies: int, *, segment_games: Optional[int] = None, action_dim: int = 220,
+                        writers: int = 3, log_rows: Optional[int] = None) -> Dict[str, int]:
+    """Bytes the pipelined worker (`stream_worker_shard`) allocates, whatever the game lengths turn out to be: the
+    slot-major live arena holds `num_slots x max_game_plies` rows (the chunk loop's cursor arena only the ~130 rows a game
+    really has), two log arenas on the device and `writers + 1` pinned staging buffers of one log arena each on the
+    host.  16 384 slots x 512 plies: 22.6 GB + 2 x 1.0 GB on the device, 4 x 1.0 GB pinned."""
+    row = _ROW_BYTES(int(action_dim)) + 1                      # + the player-sign byte of the live arena
+    seg = max(1, int(num_slots) // 8) if segment_games is None else max(1, int(segment_games))
+    cap = int(log_rows) if log_rows else max(seg * 160 + 2 * int(num_slots), 2 * int(max_game_plies))
+    return {"live_arena_bytes": int(num_slots) * int(max_game_plies) * row, "log_arena_bytes": 2 * cap * row,
+            "pinned_host_bytes": (int(writers) + 1) * cap * row,
+            "device_bytes": int(num_slots) * int(max_game_plies) * row + 2 * cap * row}
+
+
+def streaming_fits(dev: torch.device, num_slots: int, max_game_plies: int, share: float = 0.5, **kw) -> Optional[str]:
+    """None when the streaming worker's device footprint is at most `share` of the memory the device can still give
+    (the tree engine sizes its arenas from what is left afterwards), else the reason to fall back to the chunk loop --
+    which keeps ~130 rows per game instead of `max_game_plies` (a shard that fitted before round 5 must not
+    fail inside its first ply).  LZ_WORKER_STREAM_SHARE overrides `share`."""
+    from .distributed import _free_device_bytes
+    share = float(os.environ.get("LZ_WORKER_STREAM_SHARE", share))
+    need = streaming_footprint(num_slots, max_game_plies, **kw)["device_bytes"]
+    free = _free_device_bytes(dev)
+    if free >= 0 and need > share * free:
+        return (f"streaming worker needs {need / 2**30:.1f} GiB on the device ({num_slots} slots x {max_game_plies} plies, "
+                f"slot-major) and {share:.0%} of the free {free / 2**30:.1f} GiB is less: chunk loop instead")
+    return None
+
+
+def pick_evaluator(model, dev: torch.device):
+    """(evaluator, "fused_f16" | "torch", reason or None) for a worker / stage: the fused kernel when it is built for the
+    checkpoint's shape (`net_hip.fused_supported`: trunk width, block count AND head sizes -- the reference's ChessNet is
+    generic in all of them, src/neural_network.py:213-246), else the module itself on `dev`, as the reference's worker
+    evaluates (v1/python/self_play_worker.py:335-338).  Never raises for a shape: a worker must not die, or silently
+    change what it computes, on a checkpoint the trainer was able to produce."""
+    from .net_hip import FusedNet, fused_unsupported_reason
+    why = fused_unsupported_reason(model)
+    if why is None:
+        return FusedNet(model, dev), "fused_f16", None       # packed from the host copy: the module never visits the device
+    model.to(dev)             # the module is the (external fp32) evaluator of the tree engine / the root search's `model`
+    return model, "torch", why
+
+
 def _drop_engines() -> None:
     """The worker's network dies with the call, so the tree engines cached on it (tens of GB of arenas) go too."""
     try:
@@ -518,12 +561,7 @@ def run_self_play_worker(*, worker_idx: int, shard_device: str, shard_games: int
         model.load_state_dict(state, strict=True)
         model.eval()
         backend = str(search_backend).strip().lower()
-        evaluator: Any = model
-        if int(model.stem_conv.weight.shape[0]) in (64, 128):
-            from .net_hip import FusedNet
-            evaluator = FusedNet(model, dev)                  # packed from the host copy: the module never visits the device
-        else:
-            model.to(dev)   # other widths: the module itself is the (external fp32) evaluator of the tree engine / root search
+        evaluator, evaluator_name, evaluator_why = pick_evaluator(model, dev)
         chunk_dir, prefix = str(chunk_output_dir or "").strip(), str(chunk_file_prefix or "").strip()
         if not chunk_dir or not prefix:
             raise ValueError("run_self_play_worker requires chunk_output_dir and chunk_file_prefix to emit worker "
@@ -535,6 +573,17 @@ def run_self_play_worker(*, worker_idx: int, shard_device: str, shard_games: int
         if stream and not tree:
             from .self_play_gpu_runner import streaming_supported
             stream = streaming_supported(evaluator, opening_random_moves=int(opening_random_moves), sparse_ply=int(sparse_ply))
+
+        stream_fallback = None
+        if stream:
+            env = os.environ
+            stream_fallback = streaming_fits(
+                dev, concurrent, int(max_game_plies), writers=int(env.get("LZ_WORKER_WRITERS", "3") or 3),
+                segment_games=int(env["LZ_WORKER_SEGMENT_GAMES"]) if env.get("LZ_WORKER_SEGMENT_GAMES", "").strip() else None,
+                log_rows=int(env["LZ_WORKER_LOG_ROWS"]) if env.get("LZ_WORKER_LOG_ROWS", "").strip() else None)
+            if stream_fallback is not None:
+                print(f"[liuzhou_amd] worker {int(worker_idx)}: {stream_fallback}", flush=True)
+                stream = False
 
         def run_once(n: int, row_log=None):
             chunk_no[0] += 1                  # every chunk plays NEW games: its own RNG key (game ids restart per chunk)
@@ -562,7 +611,11 @@ def run_self_play_worker(*, worker_idx: int, shard_device: str, shard_games: int
                        "portable_mcts_backend": str(portable_mcts_backend),
                        "portable_cpp_threads": int(portable_cpp_threads),
                        "policy_target_temperature": policy_target_temperature,
-                       "policy_target_prior_pseudocount": float(policy_target_prior_pseudocount)}
+                       "policy_target_prior_pseudocount": float(policy_target_prior_pseudocount),
+                       # which network evaluator played this shard: the hand-written kernel or the module through
+                       # PyTorch (a shape the kernel is not built for; `evaluator_reason` says which)
+                       "evaluator": evaluator_name, **({"evaluator_reason": evaluator_why} if evaluator_why else {}),
+                       "streamed": bool(stream), **({"stream_fallback": stream_fallback} if stream_fallback else {})}
         if stream:
             os.makedirs(chunk_dir, exist_ok=True)
             return stream_worker_shard(lambda log: run_once(games, row_log=log)[1], device=dev, worker_idx=int(worker_idx),
@@ -578,6 +631,9 @@ def run_self_play_worker(*, worker_idx: int, shard_device: str, shard_games: int
                                    output_path=str(output_path), target_samples_per_shard=int(target_samples_per_shard),
                                    chunk_target_bytes=int(chunk_target_bytes), meta_common=meta_common)
     except Exception as exc:
-        _drop_engines()
         raise RuntimeError(f"v1 self-play process worker failed: worker={int(worker_idx)}, device={shard_device}, "
                            f"games={int(shard_games)}\n{traceback.format_exc()}") from exc
+    finally:
+        # the per-call FusedNet is the cache key of the tree engines built on it: it can never hit again, and its arenas
+        # (several GB at C2, tens of GB at C3) would outlive the worker next to an in-process trainer
+        _drop_engines()

@@ -636,6 +636,7 @@ class PortableTreeMCTS:
         key = (add_noise, continue_trees, lists)
         g = self._graphs.get(key)
         if g is None:
+            self.captures = getattr(self, "captures", 0) + 1        # this search synchronises the host (warm-up, capture)
             if not continue_trees:
                 # warm-up launch outside capture: every kernel of the search must be loaded before a stream capture
                 # starts.  Two simulations reach all of them (root expand + select, expand + select, last expand), and a
@@ -733,7 +734,8 @@ class PortableTreeMCTS:
         self.engine.live_total.zero_()
         self.engine.reuse_dropped.zero_()
         # refused expansions / fewest free chunks are per run too (a cached engine must not report an earlier run's)
-        self.engine.buf["pool_stats"].copy_(torch.tensor([0, self.engine.pool_chunks, 0], dtype=torch.int32))
+        # (pool_stats[2], the chunks reserved for fresh roots, follows the trees' state and is NOT a per-run statistic)
+        self.engine.buf["pool_stats"][:2].copy_(torch.tensor([0, self.engine.pool_chunks], dtype=torch.int32))
         self.get_timing(reset=True)
         if self.batch_k > 1:
             self.engine.wbuf["eval_total"].zero_(); self.engine.wbuf["eval_count"].zero_()
@@ -969,6 +971,7 @@ class DualStreamTreeMCTS:
         watch = None
         if not self.serialize and len(self.parts) == 2 and self._watch_left > 0:
             watch = [torch.cuda.Event(enable_timing=True) for _ in range(4)]           # start / end of the two searches
+        captures = sum(getattr(p, "captures", 0) for p in self.parts)
         for i, ((a, b), part, st, sub) in enumerate(zip(self.bounds, self.parts, streams, subs)):     # launch every part first ...
             st.wait_stream(main)
             with torch.cuda.stream(st):
@@ -979,7 +982,10 @@ class DualStreamTreeMCTS:
                                    rng_game_ids=cut(rng_game_ids, a, b), rng_plies=cut(rng_plies, a, b), compact=compact)
                 if watch is not None:
                     watch[2 * i + 1].record(st)
-        if watch is not None:
+        # A search in which a part captured its graph (warm-up, host synchronisation, capture) finishes part 0 on the host
+        # before part 1 starts: its bracket says "serial" whatever the streams do -- with subtree reuse the first two
+        # searches of every run capture (fresh key, continued key) and drew a spurious new pair at the third
+        if watch is not None and sum(getattr(p, "captures", 0) for p in self.parts) == captures:
             self._watch.append(watch)
         todo = list(zip(self.parts, streams))                  # leftover rounds (batch_k > 1): the parts take turns,
         while todo:                                            # so that their small rounds overlap on the device
@@ -1118,8 +1124,8 @@ def self_play_tree_gpu(model, num_games: int, mcts_simulations: int, temperature
     elif isinstance(model, PriorEvaluator):
         net, use_fused = model, False
     else:
-        chans = int(model.stem_conv.out_channels) if hasattr(model, "stem_conv") else -1
-        use_fused = evaluator == "fused" or (evaluator == "auto" and chans in (64, 128))
+        from .net_hip import fused_supported
+        use_fused = evaluator == "fused" or (evaluator == "auto" and fused_supported(model))
         net = FusedNet(model, dev) if use_fused else model.eval()
     wave = max(1, min(int(concurrent_games), int(num_games)))
     # two half-batches on two streams (see DualStreamTreeMCTS) once a wave is large enough to fill the chip twice over

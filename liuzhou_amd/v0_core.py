@@ -112,6 +112,30 @@ def batch_apply_moves(board, marks_black, marks_white, phase, current_player, pe
     return tuple(out)
 
 
+_STATE_NAMES = ("board", "marks_black", "marks_white", "phase", "current_player", "pending_marks_required",
+                "pending_marks_remaining", "pending_captures_required", "pending_captures_remaining",
+                "forced_removals_done", "move_count", "moves_since_capture")
+
+
+def _check_inplace_states(ts, op: str) -> None:
+    """The in-place operators pass the caller's storages to the kernels as they are (a converted copy would not be
+    mutated): dtype, device, contiguity and batch size are checked instead, as module.cpp's TORCH_CHECKs do."""
+    board = ts[0]
+    if board.dim() < 1:
+        raise RuntimeError(f"{op}: board must be [B, 6, 6]")
+    B = int(board.shape[0])
+    for i, (name, t) in enumerate(zip(_STATE_NAMES, ts)):
+        want = torch.int8 if i == 0 else torch.bool if i < 3 else torch.int64
+        if t.dtype != want:
+            raise RuntimeError(f"{op}: {name} must be {str(want).replace('torch.', '')} (it is mutated in place)")
+        if t.device != board.device:
+            raise RuntimeError(f"{op}: {name} is not on the board's device")
+        if not t.is_contiguous():
+            raise RuntimeError(f"{op}: state tensors must be contiguous (they are mutated)")
+        if int(t.numel()) != (B * 36 if i < 3 else B):
+            raise RuntimeError(f"{op}: {name} does not hold {B} states")
+
+
 def batch_apply_moves_inplace(board, marks_black, marks_white, phase, current_player, pending_marks_required,
                               pending_marks_remaining, pending_captures_required, pending_captures_remaining,
                               forced_removals_done, move_count, moves_since_capture, action_codes, slot_indices):
@@ -119,11 +143,11 @@ def batch_apply_moves_inplace(board, marks_black, marks_white, phase, current_pl
     ts = [board, marks_black, marks_white, phase, current_player, pending_marks_required, pending_marks_remaining,
           pending_captures_required, pending_captures_remaining, forced_removals_done, move_count,
           moves_since_capture]
-    for t in ts:
-        if not t.is_contiguous():
-            raise RuntimeError("in-place state tensors must be contiguous")
+    _check_inplace_states(ts, "batch_apply_moves_inplace")
     codes = _c(action_codes.to(board.device), torch.int32)
     slots = _c(slot_indices.to(board.device), torch.int64).view(-1)
+    if codes.dim() != 2 or int(codes.shape[1]) != 4 or int(codes.shape[0]) != int(slots.numel()):
+        raise RuntimeError("batch_apply_moves_inplace: action_codes must be [N, 4] with one row per slot index")
     s = L.soa(ts)
     with L.device_ctx(board.device):
         st = L.lib_for(board).lz_batch_apply_moves_inplace(C.byref(s), L.i64(board.shape[0]), L.ptr(codes), L.ptr(slots),
@@ -297,9 +321,12 @@ def self_play_step_raw(state12, plies, done, active_idx, chosen_action_codes, te
     """Sync-free core of self_play_step_inplace -> (fin_kind i32[A], result f32[A], soft f32[A])."""
     board = state12[0]
     dev = board.device
-    for t in list(state12) + [plies, done]:
+    _check_inplace_states(list(state12), "self_play_step_inplace")
+    for t in (plies, done):
         if not t.is_contiguous():
             raise RuntimeError("self_play_step_inplace: state tensors must be contiguous (they are mutated)")
+        if t.device != dev or int(t.numel()) != int(board.shape[0]):
+            raise RuntimeError("self_play_step_inplace: plies / done must hold one entry per state on the board's device")
     act = _c(active_idx.to(dev), torch.int64).view(-1)
     codes = _c(chosen_action_codes.to(dev), torch.int32)
     term = _c(terminal_mask.to(dev), torch.bool).view(-1)

@@ -74,6 +74,33 @@ def test_fused_net_matches_fp32_model(name, n, half):
     assert e_val < VALUE_TOL, e_val
 
 
+@pytest.mark.parametrize("channels,blocks", [(64, 20), (128, 17)])
+def test_deeper_nets_than_15_blocks_run_the_fused_kernels(channels, blocks):
+    """The descriptor holds 96 layer offsets (47 residual blocks; 15 until round 5): a 20-block checkpoint takes the
+    hand-written kernels like any other -- fp32-operand mode within 1e-5 of the fp32 module on every output, the fp16
+    production mode within twice the 10-block bounds (the rounding of 2 x blocks more fp16 activations)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from liuzhou_amd.net import ChessNet, bucket_logits_to_scalar
+    from liuzhou_amd.net_hip import FusedNet, fused_supported
+    torch.manual_seed(11)
+    m = ChessNet(trunk_channels=channels, num_blocks=blocks).eval().to(DEV)
+    assert fused_supported(m)
+    x = _planes(300, seed=blocks)
+    with torch.inference_mode():
+        r1, r2, rm, rv = m(x)
+        rval = bucket_logits_to_scalar(rv)
+    for precision, ptol, ltol, vtol in (("fp32", 1e-5, 1e-5, 1e-5), ("fp16", 2 * PROB_TOL, 2 * VLOGIT_TOL, 2 * VALUE_TOL)):
+        f = FusedNet(m, precision=precision)
+        lp1, lp2, lpm, vl = f(x)
+        for got, want in ((lp1, r1), (lp2, r2), (lpm, rm)):
+            assert (got.exp() - want.exp()).abs().max().item() < ptol, precision
+            if precision == "fp32":
+                assert (got - want).abs().max().item() < 1e-5
+        assert (vl - rv).abs().max().item() < ltol, precision
+        assert (f.last_value - rval).abs().max().item() < vtol, precision
+
+
 def test_values_only_mode_equals_full_forward():
     """Skipping the policy head (log-prob outputs NULL) must not change the value output."""
     if not torch.cuda.is_available():

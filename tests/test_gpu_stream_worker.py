@@ -177,3 +177,30 @@ def test_streamed_root_shard_invariants_and_classic_loop_still_works(tmp_path, m
     assert out["0"]["num_shards"] == 3 and "stream_segments" not in out["0"]["stats"]["mcts_counters"]
     assert out["1"]["num_shards"] >= 3 and out["1"]["stats"]["mcts_counters"]["stream_segments"] >= out["1"]["num_shards"]
     assert set(out["0"]["metadata"]) == set(out["1"]["metadata"]) and set(out["0"]) == set(out["1"])
+
+
+def test_worker_falls_back_to_the_chunk_loop_when_the_slot_major_arena_does_not_fit(tmp_path, monkeypatch):
+    """The streamed worker's live arena is slots x max_game_plies rows whatever the game lengths (22.6 GB at 16 384 x 512);
+    when that is more than its share of the free device memory the worker plays the reference's chunk loop instead of
+    failing in its first ply, and says so in the manifest."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from liuzhou_amd.net import ChessNet, MODEL_CONFIGS
+    from liuzhou_amd.self_play_worker import run_self_play_worker, streaming_footprint
+    fp = streaming_footprint(16384, 512)
+    assert 22.5e9 < fp["live_arena_bytes"] < 22.7e9 and fp["device_bytes"] == fp["live_arena_bytes"] + fp["log_arena_bytes"]
+    assert fp["pinned_host_bytes"] == 2 * fp["log_arena_bytes"]
+    torch.manual_seed(12)
+    state_path = tmp_path / "model_state.pt"
+    torch.save(ChessNet(**MODEL_CONFIGS["b6c64"]).state_dict(), state_path)
+    monkeypatch.setenv("LZ_WORKER_STREAM", "1")
+    monkeypatch.setenv("LZ_WORKER_STREAM_SHARE", "1e-9")
+    run_self_play_worker(worker_idx=0, shard_device="cuda:0", shard_games=6, seed=3, model_state_path=str(state_path),
+                         output_path=str(tmp_path / "worker.pt"), mcts_simulations=4, temperature_init=1.0,
+                         temperature_final=0.1, temperature_threshold=6, exploration_weight=1.0, dirichlet_alpha=0.3,
+                         dirichlet_epsilon=0.25, soft_value_k=2.0, opening_random_moves=0, max_game_plies=24,
+                         concurrent_games_per_device=3, chunk_output_dir=str(tmp_path), chunk_file_prefix="w",
+                         search_backend="cuda_root")
+    m = torch.load(tmp_path / "worker.pt", map_location="cpu")
+    assert m["metadata"]["streamed"] is False and "chunk loop" in m["metadata"]["stream_fallback"]
+    assert m["num_shards"] == 2 and "stream_segments" not in m["stats"]["mcts_counters"] and m["stats"]["num_games"] == 6

@@ -62,8 +62,10 @@ def test_two_stream_search_notices_serialised_halves_and_draws_new_streams():
     dual.streams = (one, one)                                       # serialised, as on one hardware queue
     temps = torch.ones((2048,), device=DEV)
     outs = []
-    for _ in range(10):
+    for k in range(10):
         outs.append(dual.search_batch(batch, temperatures=temps).chosen_action_indices.clone())
+        if k == 0:      # the search that captured the graphs is not a witness: its halves are serial on the HOST
+            assert dual.use_graph and not dual._watch and dual._serial_seen == 0 and dual._watch_left == 6
         torch.cuda.synchronize()
     assert dual.stream_redraws >= 1 and dual.streams[0] is not dual.streams[1] and one not in dual.streams
     single = PortableTreeMCTS(net, 2048, 48, DEV, **kw)

@@ -539,6 +539,52 @@ def test_a_chunk_is_reserved_for_every_fresh_root():
         assert L.lib().lz_tree_begin(C.byref(small.desc), L.stream_ptr(torch.device(DEV))) == -1      # LZ_ERR_ARG
 
 
+def test_root_chunk_reservation_follows_the_tree_state():
+    """pool_stats[2] is the number of live fresh roots that have not expanded: a second begin of pending
+    roots, a begin over expanded trees, inactive games and a root without a legal move leave no chunk reserved for
+    nobody; reset_run keeps it."""
+    _need_gpu()
+    from liuzhou_amd.tree_engine import TreeEngine
+    from tests.tree_parity import hash_evaluator, unpack_packed
+    B, sims = 16, 8
+    eng = TreeEngine(B, sims, DEV, 1.0, edge_chunk=128, pool_chunks=4 * B)
+    res = lambda: int(eng.buf["pool_stats"][2])
+
+    def expand_root():
+        leaf = unpack_packed(eng.buf["leaf_state"].cpu().numpy())
+        pri, val = hash_evaluator(leaf)
+        eng.expand(is_root=True, values=torch.from_numpy(val).to(DEV), priors220=torch.from_numpy(pri).to(DEV))
+
+    eng.set_roots(to_gpu_batch(O.initial_states(B), DEV))
+    eng.begin(); eng.begin()
+    assert res() == B                                              # counted once, not twice
+    expand_root()
+    assert res() == 0
+    eng.begin()                                                    # over expanded trees: fresh roots again
+    assert res() == B
+    eng.buf["active"][: B // 2] = 0
+    eng.begin()                                                    # half of the pending roots become inactive
+    assert res() == B // 2
+    eng.buf["active"].fill_(1)
+    eng.begin(); eng.begin()
+    assert res() == B
+    expand_root()
+    assert res() == 0 and int(eng.buf["pool_top"]) == 4 * B - B
+    # roots that are not finished but have no legal move (g2) take no chunk and hold no reservation afterwards
+    z = load("g2_edges.npz")
+    st = states(z, "s")
+    mask, _ = O.encode_actions(st)
+    stuck = np.flatnonzero(mask.sum(axis=1) == 0)
+    if stuck.size:
+        pick = np.resize(stuck, B)
+        sub = {f: np.ascontiguousarray(np.asarray(st[f])[pick]) for f in FIELDS}
+        eng.set_roots(to_gpu_batch(sub, DEV))
+        eng.begin()
+        pending = res()
+        expand_root()
+        assert res() == 0, (pending, res())
+
+
 @pytest.mark.parametrize("batch_k,sims", [(16, 50), (4, 30), (16, 200)])
 def test_gpu_wave_batched_search_matches_oracle(batch_k, sims):
     """The legacy search's waves (src/mcts.py `batch_K` leaves per tree and wave, no virtual loss; oracle pinned by

@@ -50,6 +50,42 @@ def test_worker_emits_chunk_manifest(tmp_path, backend, chunk_target_bytes):
     assert payload["stats"]["num_games"] == 3.0
 
 
+@pytest.mark.parametrize("arch,want", [
+    (dict(trunk_channels=64, num_blocks=2, policy_channels=32, value_channels=32), "torch"),
+    (dict(trunk_channels=64, num_blocks=20), "fused_f16"),
+    (dict(trunk_channels=32, num_blocks=2), "torch"),
+    (dict(trunk_channels=128, num_blocks=1, value_mlp_channels=64), "torch")])
+@pytest.mark.parametrize("backend", ["cuda_root", "portable"])
+def test_worker_names_its_evaluator_and_never_dies_on_a_shape(tmp_path, backend, arch, want):
+    """A checkpoint the trainer can produce must play: shapes the fused kernel is not built for (other head sizes, other
+    widths -- src/neural_network.py:213-246 is generic in all of them) are evaluated by the module itself, deeper
+    64 / 128-channel nets by the kernel, and the manifest says which evaluator ran (`metadata.evaluator`)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from liuzhou_amd.net import ChessNet
+    from liuzhou_amd.self_play_worker import run_self_play_worker
+    torch.manual_seed(5)
+    state_path = tmp_path / "model_state.pt"
+    torch.save(ChessNet(**arch).state_dict(), state_path)
+    manifest_path = tmp_path / "worker_manifest.pt"
+    row = run_self_play_worker(
+        worker_idx=0, shard_device="cuda:0", shard_games=3, seed=7, model_state_path=str(state_path),
+        output_path=str(manifest_path), mcts_simulations=4, temperature_init=1.0, temperature_final=0.1,
+        temperature_threshold=4, exploration_weight=1.0, dirichlet_alpha=0.3, dirichlet_epsilon=0.25, soft_value_k=2.0,
+        opening_random_moves=2, max_game_plies=20, concurrent_games_per_device=3, soft_label_alpha=0.0,
+        chunk_output_dir=str(tmp_path), chunk_file_prefix="w", search_backend=backend)
+    payload = torch.load(manifest_path, map_location="cpu")
+    meta = payload["metadata"]
+    assert meta["evaluator"] == want and (("evaluator_reason" in meta) == (want == "torch"))
+    assert row["num_samples"] == payload["num_samples"] > 0
+    for name in payload["shard_files"]:
+        shard = torch.load(tmp_path / str(name), map_location="cpu")
+        assert shard["metadata"]["evaluator"] == want
+        pol = shard["policy_targets"]
+        assert torch.allclose(pol.sum(1), torch.ones(pol.shape[0]), atol=1e-4)
+        assert torch.isfinite(shard["value_targets"]).all()
+
+
 @pytest.mark.parametrize("backend", ["cuda_root", "portable"])
 def test_selfplay_stage_cli_two_worker_processes(tmp_path, backend):
     """scripts/selfplay_stage.py end to end: two spawned worker processes (both on cuda:0 here), chunk files, the

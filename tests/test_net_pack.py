@@ -46,3 +46,21 @@ def test_pack_layout_sizes():
     assert int(pack.wfrag.numel()) == want
     assert pack.wfrag.dtype == torch.float16 and pack.fparams.dtype == torch.float32
     assert len(pack.layer_offsets) == 2 + 2 * NB
+
+
+def test_fused_supported_names_what_the_kernel_is_not_built_for():
+    """`net_hip.fused_supported`: the dispatch predicate of the worker / stage / arena (no GPU needed: shapes only)."""
+    from liuzhou_amd.net import ChessNet, MODEL_CONFIGS
+    from liuzhou_amd.net_hip import fused_supported, fused_unsupported_reason, MAX_BLOCKS
+    for name in ("b6c64", "b10c128"):
+        assert fused_supported(ChessNet(**MODEL_CONFIGS[name]))
+    assert fused_supported(ChessNet(trunk_channels=64, num_blocks=20)) and MAX_BLOCKS == 47
+    cases = {"trunk channels": dict(trunk_channels=32, num_blocks=1),
+             "head channels": dict(trunk_channels=64, num_blocks=1, policy_channels=32),
+             "value MLP": dict(trunk_channels=64, num_blocks=1, value_mlp_channels=64),
+             "bins": dict(trunk_channels=64, num_blocks=1, value_bucket_bins=51),
+             "residual blocks": dict(trunk_channels=64, num_blocks=48)}
+    for what, arch in cases.items():
+        why = fused_unsupported_reason(ChessNet(**arch))
+        assert why is not None and what in why, (what, why)
+    assert fused_unsupported_reason(object()) is not None
