@@ -5,7 +5,7 @@ import ctypes as C
 import os
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from liuzhou_amd import _lib as L
 from liuzhou_amd.net import ChessNet, MODEL_CONFIGS

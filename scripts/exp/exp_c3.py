@@ -5,7 +5,7 @@
     results, never the shipped build -- `LZ_EXP_SAME_LAYER=1` in the environment only labels the run): the weight set
     then fits the 4 MB XCD L2, which bounds what the L2 misses on the real 5.9 MB set cost."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from liuzhou_amd.net import ChessNet, MODEL_CONFIGS
 from liuzhou_amd.net_hip import FusedNet

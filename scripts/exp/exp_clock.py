@@ -1,7 +1,7 @@
 """Experiment: shader clock held inside the network kernel (LZ_NET_DEBUG_STOP=99 writes s_memtime / wall-clock deltas)."""
 import os, sys
 os.environ["LZ_NET_DEBUG_STOP"] = "99"
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from liuzhou_amd.net import ChessNet, MODEL_CONFIGS
 from liuzhou_amd.net_hip import FusedNet

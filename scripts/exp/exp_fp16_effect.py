@@ -8,13 +8,13 @@
      fraction of roots with identical visit counts, identical most-visited move, max / mean L1 distance of the visit
      policies.  The tree arithmetic is the same double-precision code in both runs; only the evaluations differ.
 
-    python scripts/exp_fp16_effect.py [b6c64|b10c128] [games] [sims]      -> one JSON line
+    python scripts/exp/exp_fp16_effect.py [b6c64|b10c128] [games] [sims]      -> one JSON line
 """
 import json
 import os
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
 

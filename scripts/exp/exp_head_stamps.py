@@ -1,7 +1,7 @@
 """Experiment: s_memtime stamps of every wave of one workgroup at the head sub-steps of the network kernel
 (build_exp/lib_head_stamps.so, -DLZ_EXP_HEAD_STAMPS)."""
 import os, subprocess, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 LIB = os.path.join(ROOT, "build_exp", "lib_head_stamps.so")
 if not os.path.exists(LIB):
     os.makedirs(os.path.dirname(LIB), exist_ok=True)

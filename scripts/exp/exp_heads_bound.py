@@ -1,7 +1,7 @@
 """Upper bound of taking the head phases out of the persistent network kernel: sustained evaluations/s with the pass cut
 short after the trunk (LZ_NET_DEBUG_STOP=3) / after the head convs (=4) against the full pass (wrong results, timing only)."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from liuzhou_amd.net import ChessNet, MODEL_CONFIGS
 from liuzhou_amd.net_hip import FusedNet

@@ -2,7 +2,7 @@
 kind 1 = evaluate, 2 = terminal leaf, 0 = inactive game, 3 = kept root.)  Decides whether compacting terminal leaves
 out of the network batch would pay."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from liuzhou_amd.net import ChessNet, MODEL_CONFIGS
 from liuzhou_amd.net_hip import FusedNet

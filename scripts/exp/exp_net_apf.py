@@ -5,7 +5,7 @@ bit, one child process per build of the library (LZ_HIP_LIB).  Build the other v
   cd liuzhou_amd/csrc && hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -fvisibility=hidden \
       -DLZ_NET_APF=<1|2> -o ../_exp/liblz_APF<1|2>.so lz_ops.hip lz_engine.hip lz_net.hip lz_net_f32.hip lz_train.hip lz_search.hip"""
 import os, subprocess, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 CHILD = r'''
 import os, sys, time, hashlib
 sys.path.insert(0, %r)

@@ -3,7 +3,7 @@ per build: the regular build and the timing-experiment builds that drop one kind
 (-DLZ_EXP_NO_BRELOAD: no LDS activation-operand reloads, -DLZ_EXP_NO_ALOAD: no weight-fragment loads; wrong results).
 Under the package power limit this bounds what restructuring the operand delivery could gain."""
 import os, subprocess, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 CHILD = r'''
 import os, sys, time
 sys.path.insert(0, %r)

@@ -1,9 +1,9 @@
 """Persistent search kernel (csrc/lz_search.hip) against the per-simulation launch pair, same box, same workload.
 
-    python scripts/exp_persistent.py [games] [sims] [steps] [model]
+    python scripts/exp/exp_persistent.py [games] [sims] [steps] [model]
 
 The `stagger:mode` settings (timing modes that skip / replace the tree step) need an experiment build of the library:
-    hipcc ... -DLZ_EXP_SEARCH_MODES -o /tmp/libexp.so ...   and   LZ_HIP_LIB=/tmp/libexp.so python scripts/exp_persistent.py
+    hipcc ... -DLZ_EXP_SEARCH_MODES -o /tmp/libexp.so ...   and   LZ_HIP_LIB=/tmp/libexp.so python scripts/exp/exp_persistent.py
 (the shipped library ignores LZ_EXP_SEARCH_MODE).
 For each setting (LZ_TREE_PERSISTENT off = two streams of per-simulation launches; on with several staggers) the
 steady-state self-play harness runs `steps` timed steps after a 2 s soak; with the persistent kernel the in-kernel
@@ -13,7 +13,7 @@ import os
 import sys
 import time
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 
 from liuzhou_amd.net import ChessNet, MODEL_CONFIGS

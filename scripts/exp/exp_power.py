@@ -1,7 +1,7 @@
 """Power / clock held while the network kernel runs back to back (evidence for the power-limited regime).
 Samples `rocm-smi` (average package power, sclk) from a thread while the fused network evaluates large batches."""
 import os, subprocess, sys, threading, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from liuzhou_amd.net import ChessNet, MODEL_CONFIGS
 from liuzhou_amd.net_hip import FusedNet

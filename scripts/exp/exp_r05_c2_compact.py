@@ -1,7 +1,7 @@
 """Round 5: does the compact evaluation list pay at C2 (one network pass per CU per half)?  Product runner, 16 384 games on
 4 096 slots, 200 sims, 6x64, with LZ_TREE_COMPACT = 0 / 1."""
 import json, os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from liuzhou_amd.net import ChessNet, MODEL_CONFIGS
 from liuzhou_amd.net_hip import FusedNet

@@ -2,7 +2,7 @@
 10x128, from the empty board to the end of the last game (the drain included) -- with and without the compact evaluation
 lists.  Prints one JSON line per run; a progress line per ~60 s keeps the box from being taken for hung."""
 import json, os, sys, threading, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from liuzhou_amd.net import ChessNet, MODEL_CONFIGS
 from liuzhou_amd.net_hip import FusedNet

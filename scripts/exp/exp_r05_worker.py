@@ -1,6 +1,6 @@
 """Round-5 experiment: where the worker's wall time goes (streamed vs the reference-style chunk loop, tree / root)."""
 import json, os, shutil, sys, tempfile, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from liuzhou_amd.net import ChessNet, MODEL_CONFIGS
 from liuzhou_amd.self_play_worker import run_self_play_worker

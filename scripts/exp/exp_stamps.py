@@ -1,6 +1,6 @@
 """Experiment: per-phase s_memtime stamps of the network kernel's residual block 2 (build_exp/lib_stamps.so)."""
 import os, subprocess, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 LIB = os.path.join(ROOT, "build_exp", "lib_stamps.so")
 if not os.path.exists(LIB):                      # the production library is built without the stamps
     os.makedirs(os.path.dirname(LIB), exist_ok=True)

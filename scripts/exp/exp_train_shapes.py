@@ -2,9 +2,9 @@
 remainder batch has a shape MIOpen has not seen) with PyTorch's default MIOpen find path and with
 `torch.backends.miopen.immediate = True`, and the steady-state samples/s either way.
 
-    python scripts/exp_train_shapes.py [b6c64|b10c128]"""
+    python scripts/exp/exp_train_shapes.py [b6c64|b10c128]"""
 import json, os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from liuzhou_amd.net import ChessNet, MODEL_CONFIGS, stable_resnet_init
 from liuzhou_amd.train_bridge import train_network_from_tensors

@@ -1,9 +1,9 @@
 """Experiment: where a wave of `tree_expand_select_kernel` spends its time (build_exp/lib_tree_stamps.so,
 -DLZ_EXP_TREE_STAMPS): one game's wave adds its clock to a global accumulator at every stamp (waiting for outstanding
 memory operations first, so a wait is charged to the step that caused it); averages per simulation over a steady-state run.
-usage: python scripts/exp_tree_stamps.py [C2|C3]"""
+usage: python scripts/exp/exp_tree_stamps.py [C2|C3]"""
 import ctypes as C, os, subprocess, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 LIB = os.path.join(ROOT, "build_exp", "lib_tree_stamps.so")
 if not os.path.exists(LIB):
     os.makedirs(os.path.dirname(LIB), exist_ok=True)

@@ -3,7 +3,7 @@
 #   1. rocprofv3 --kernel-trace --stats of the headline workload C3 and of C2 (bench.py itself, short)
 #   2. PMC passes (one counter per pass, --kernel-trace only) of the network kernel at the three launch shapes of
 #      the bench: <128,8,8> x 16384 evaluations (C3), <64,16,8> x 4096 and <64,8,4> x 2048 (C2, one / two streams)
-# Summaries are post-processed into profiles/ by scripts/summarize_profiles_r02.py.
+# Summaries are post-processed into profiles/ by scripts/exp/summarize_profiles_r02.py.
 set -e
 TAG=${1:-r02}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}

@@ -1,13 +1,13 @@
 #!/bin/bash
 # Round-3 profiles (run on the GPU box from the repo root):
-#   1. everything scripts/prof_r02.sh collects, under tag r03 (kernel stats of the C3 / C2 bench runs, PMC traffic of the
-#      network kernel at the three launch shapes) -> scripts/summarize_profiles_r02.py r03
+#   1. everything scripts/exp/prof_r02.sh collects, under tag r03 (kernel stats of the C3 / C2 bench runs, PMC traffic of the
+#      network kernel at the three launch shapes) -> scripts/exp/summarize_profiles_r02.py r03
 #   2. the persistent search kernel (opt-in, csrc/lz_search.hip): kernel stats of the C2 bench with LZ_TREE_PERSISTENT=1,
 #      and SQ counters (MFMA pipe busy, wave / wait cycles, instruction mix) of tree_search_persistent_kernel in their
 #      own --pmc passes with --kernel-trace only
 set -e
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-bash "$ROOT/scripts/prof_r02.sh" r03
+bash "$ROOT/scripts/exp/prof_r02.sh" r03
 OUT=$ROOT/gpurun_out/prof_r03
 cd /tmp && export TMPDIR=/tmp
 LZ_TREE_PERSISTENT=1 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/bench_c2_persistent" -- python3 "$ROOT/bench.py" --workload C2 --steps 8 --warmup 2 --soak-seconds 0 --also none --no-cpu-baseline > "$OUT/bench_c2_persistent.log" 2>&1
@@ -32,8 +32,8 @@ for d in sorted(glob.glob("$OUT/sq*_*/")):
 PY
 # summaries are made HERE (gpurun copies back at most 64 MiB of gpurun_out/): tracked files land in profiles/ of this
 # copy of the repo and are mirrored under $OUT/summary; raw traces above 2 MiB are dropped afterwards
-python3 "$ROOT/scripts/summarize_profiles_r02.py" r03 > "$OUT/summary.log" 2>&1 || tail -5 "$OUT/summary.log"
-python3 "$ROOT/scripts/summarize_profiles_r03.py" > "$OUT/summary_r03.log" 2>&1 || tail -5 "$OUT/summary_r03.log"
+python3 "$ROOT/scripts/exp/summarize_profiles_r02.py" r03 > "$OUT/summary.log" 2>&1 || tail -5 "$OUT/summary.log"
+python3 "$ROOT/scripts/exp/summarize_profiles_r03.py" > "$OUT/summary_r03.log" 2>&1 || tail -5 "$OUT/summary_r03.log"
 mkdir -p "$OUT/summary" && cp "$ROOT"/profiles/r03_* "$ROOT/profiles/traffic.json" "$OUT/summary/" 2>/dev/null
 find "$OUT" -type f -size +2M -delete
 find "$OUT" -name "*.csv" | wc -l; du -sh "$OUT"

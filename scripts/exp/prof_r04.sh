@@ -1,14 +1,14 @@
 #!/bin/bash
-# Round-5 profiles (run on the GPU box from the repo root): the kernel traces are taken UNDER THE BENCH PROTOCOL -- soak on,
+# Round-4 profiles (run on the GPU box from the repo root): the kernel traces are taken UNDER THE BENCH PROTOCOL -- soak on,
 # >= 10 timed steps, the in-process clock sampler running (bench.py keeps it on under rocprofv3 since round 4) -- so that
 # (sims + 1) x AverageNs of the network kernel can be set against the SAME run's ms_per_step, power and sclk.
 #   1. rocprofv3 --kernel-trace --stats of C3 (10 timed steps) and C2 (100 timed steps)
 #   2. PMC traffic of the network kernel at the three launch shapes (one counter per pass, --kernel-trace only)
 #   3. SQ counters of the two production shapes (<128,8,8> x 16384, <64,8,4> x 2048)
-# Summaries: scripts/summarize_profiles_r04.py r05 -> profiles/r05_*.
+# Summaries: scripts/exp/summarize_profiles_r04.py -> profiles/r04_*.
 set -e
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-OUT=$ROOT/gpurun_out/prof_r05
+OUT=$ROOT/gpurun_out/prof_r04
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/bench_c3" -- python3 "$ROOT/bench.py" --steps 10 --warmup 5 --also none --no-cpu-baseline > "$OUT/bench_c3.log" 2>&1
@@ -33,8 +33,8 @@ for shape in "b10c128 16384 full" "b6c64 2048 half"; do
       --kernel-trace --output-format csv -d "$OUT/sq2_$name" -- python3 "$ROOT/scripts/prof_net_once.py" $1 $2 $3 > "$OUT/sq2_$name.log" 2>&1
   echo "sq $name done"
 done
-python3 "$ROOT/scripts/summarize_profiles_r04.py" r05 > "$OUT/summary.log" 2>&1 || tail -5 "$OUT/summary.log"
+python3 "$ROOT/scripts/exp/summarize_profiles_r04.py" > "$OUT/summary.log" 2>&1 || tail -5 "$OUT/summary.log"
 cat "$OUT/summary.log" | tail -12
-mkdir -p "$OUT/summary" && cp "$ROOT"/profiles/r05_* "$ROOT/profiles/traffic.json" "$OUT/summary/" 2>/dev/null
+mkdir -p "$OUT/summary" && cp "$ROOT"/profiles/r04_* "$ROOT/profiles/traffic.json" "$OUT/summary/" 2>/dev/null
 find "$OUT" -type f -size +2M -delete
 find "$OUT" -name "*.csv" | wc -l; du -sh "$OUT"

@@ -20,7 +20,7 @@ for shape in "b6c64 2048 200 3" "b10c128 16384 800 2"; do
       --kernel-trace --output-format csv -d "$OUT/pmc3_$tag" -- python3 "$ROOT/scripts/prof_tree_once.py" $1 $2 $3 $4 > "$OUT/pmc3_$tag.log" 2>&1
   echo "pmc3 $tag done (optional counters; a refused name leaves this pass empty)"
 done
-python3 "$ROOT/scripts/summarize_profiles_r05.py" "$OUT" > "$OUT/summary.md" 2>&1
+python3 "$ROOT/scripts/exp/summarize_profiles_r05.py" "$OUT" > "$OUT/summary.md" 2>&1
 cat "$OUT/summary.md"
 # the raw traces are tens of MB: keep the summary, the logs and the kernel-stats tables only
 find "$OUT" -name "*counter_collection.csv" -delete; find "$OUT" -name "*kernel_trace.csv" -delete; find "$OUT" -name "*agent_info.csv" -delete

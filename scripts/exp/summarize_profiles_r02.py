@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Turn the raw rocprofv3 output of scripts/prof_r02.sh (gpurun_out/prof_<tag>/) into the tracked summaries under
+"""Turn the raw rocprofv3 output of scripts/exp/prof_r02.sh (gpurun_out/prof_<tag>/) into the tracked summaries under
 profiles/: kernel-stats tables of the C3 and C2 bench runs, the PMC traffic note, and profiles/traffic.json (read by
 bench.py for `roofline.traffic`)."""
 import csv
@@ -8,7 +8,7 @@ import json
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
 out = os.path.join(ROOT, "profiles")
@@ -67,7 +67,7 @@ for model, n, shape in (("b10c128", 16384, "full"), ("b6c64", 4096, "full"), ("b
                  f"{traffic / algo:.2f}x | {scratch} B/lane, {vgpr} VGPR + {agpr} AGPR, LDS {lds} B |")
 with open(os.path.join(out, f"{tag}_pmc_net_forward.md"), "w") as f:
     f.write(f"# {tag} PMC passes of `net_forward_kernel` at the three launch shapes of bench.py\n\n"
-            "One counter per pass with `--kernel-trace` only (HBM section of MI355X_MICROARCH.md), `scripts/prof_r02.sh`:\n\n"
+            "One counter per pass with `--kernel-trace` only (HBM section of MI355X_MICROARCH.md), `scripts/exp/prof_r02.sh`:\n\n"
             "    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -- python3 scripts/prof_net_once.py <model> <batch> <full|half>\n"
             "    rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -- python3 scripts/prof_net_once.py <model> <batch> <full|half>\n\n"
             "Launch = one network evaluation of the whole batch from 32-byte packed states (the search loop's shape), mean "

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Round-3 additions to the tracked profile summaries (raw input: gpurun_out/prof_r03/, scripts/prof_r03.sh):
+"""Round-3 additions to the tracked profile summaries (raw input: gpurun_out/prof_r03/, scripts/exp/prof_r03.sh):
   profiles/r03_bench_c2_persistent_kernel_stats.md   rocprofv3 --kernel-trace --stats of the C2 bench with the opt-in
                                                       persistent search kernel (LZ_TREE_PERSISTENT=1)
   profiles/r03_pmc_sq_persistent.md                   SQ counters of tree_search_persistent_kernel next to the stand-alone
@@ -10,7 +10,7 @@ import glob
 import json
 import os
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 src = os.path.join(ROOT, "gpurun_out", "prof_r03")
 out = os.path.join(ROOT, "profiles")
 
@@ -60,7 +60,7 @@ def sq_table():
     p = dict(p1, **p2)
     with open(os.path.join(out, "r03_pmc_sq_persistent.md"), "w") as g:
         g.write("# r03: SQ counters of the persistent search kernel (`tree_search_persistent_kernel<64,8,4>`, opt-in)\n\n"
-                "`scripts/prof_r03.sh`: separate `rocprofv3 --pmc ... --kernel-trace` passes (no other trace domain) of "
+                "`scripts/exp/prof_r03.sh`: separate `rocprofv3 --pmc ... --kernel-trace` passes (no other trace domain) of "
                 "`scripts/prof_persistent_once.py` (C2: 4 096 games, 200 simulations, direct launches; mean over "
                 f"{n1} launches = searched moves) and, beside it, of the stand-alone network kernel at the C2 half-batch shape "
                 f"(`prof_net_once.py b6c64 2048 half`, {n2} launches).\n\n"

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Round-4 tracked profile summaries from gpurun_out/prof_r04/ (scripts/prof_r04.sh):
+"""Round-4 tracked profile summaries from gpurun_out/prof_r04/ (scripts/exp/prof_r04.sh):
   profiles/r04_bench_c3_kernel_stats.md, r04_bench_c2_kernel_stats.md   kernel-stats tables of bench runs taken under the
        bench protocol, each with the bench line, package power / sclk of THE SAME run, and the reconciliation
        (sims + 1) x AverageNs(network kernel) vs ms_per_step
@@ -11,7 +11,7 @@ import glob
 import json
 import os
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import sys
 tag = sys.argv[1] if len(sys.argv) > 1 else "r04"        # `summarize_profiles_r04.py r05`: the same tables for round 5
 src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")

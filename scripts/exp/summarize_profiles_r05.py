@@ -1,4 +1,4 @@
-"""Summaries of scripts/prof_r05_tree.sh: per kernel, mean counter values per launch and the derived ratios."""
+"""Summaries of scripts/exp/prof_r05_tree.sh: per kernel, mean counter values per launch and the derived ratios."""
 import collections, csv, glob, os, sys
 out = sys.argv[1]
 KEEP = ("tree_expand_select_kernel", "tree_advance_kernel", "tree_expand_kernel", "net_forward_kernel", "tree_finish_kernel")

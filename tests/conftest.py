@@ -10,3 +10,4 @@ if ROOT not in sys.path:
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "slow: longer-running CPU test")
+    config.addinivalue_line("markers", "perf: timing guard, needs an idle MI355X (pytest -m perf); not part of -m gpu")

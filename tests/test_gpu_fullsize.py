@@ -154,10 +154,11 @@ def test_c2_full_size_three_moves_and_same_seed_same_games():
         pop = _population("b6c64", 4096, 200, 3, seed=9973, reuse_factor=8.0)
         assert pop.dual_stream and all(e.B == 2048 for e in _engines(pop))
         steps = [_checked_step(pop, 200, first_move=True), _checked_step(pop, 200, first_move=False)]
-        # timing guard of the subtree compaction at scale: 65 - 180 us per half-batch launch measured
+        # (the timing guard on the subtree compaction lives in tests/test_perf_guards.py, marker `perf`: a throttled or
+        #  shared box must not turn a parity run red)
         last, adv_us = _advance_launch_us(lambda: _checked_step(pop, 200, first_move=False))
         steps.append(last)
-        assert adv_us < 600.0, f"tree_advance_kernel took {adv_us:.0f} us per launch at C2"
+        print(f"C2 full size: tree_advance_kernel {adv_us:.0f} us per half-batch launch")
         kept_any = any(int((e.buf["root_visits"] > 200).sum()) > 0 for e in _engines(pop))
         assert kept_any, "no game kept a subtree over three moves"
         assert _dropped(pop) == [0, 0]
@@ -185,7 +186,6 @@ def test_c3_full_size_one_move_and_one_continued_move():
     assert not pop.dual_stream and pop.mcts.use_graph
     _checked_step(pop, 800, first_move=True)
     _, adv_us = _advance_launch_us(lambda: _checked_step(pop, 800, first_move=False))
-    assert adv_us < 6000.0, f"tree_advance_kernel took {adv_us:.0f} us per launch at C3"      # 0.8 - 2.0 ms measured
     e = _engines(pop)[0]
     assert int((e.buf["root_visits"] > 800).sum()) > 0, "no game continued a kept subtree"
     assert not pop.mcts.graph_retry_off

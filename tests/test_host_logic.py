@@ -214,11 +214,13 @@ def test_edge_pool_sizing_arithmetic():
 
 
 def test_every_script_compiles():
-    """scripts/ holds ~50 one-off experiment / profiling programs that only run on the GPU box: at least their syntax is
+    """scripts/ holds the CLIs and measurement programs, scripts/exp the one-off experiment / profiling programs of
+    earlier rounds (they only run on the GPU box): at least their syntax is
     checked here, so that a refactor of the package does not leave them unparseable."""
     import glob
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     files = sorted(glob.glob(os.path.join(root, "scripts", "*.py")) + glob.glob(os.path.join(root, "scripts", "micro", "*.py")) +
+                   glob.glob(os.path.join(root, "scripts", "exp", "*.py")) +
                    glob.glob(os.path.join(root, "oracle", "*.py")) + [os.path.join(root, "bench.py"), os.path.join(root, "__graft_entry__.py")])
     assert len(files) > 40
     for f in files:
