@@ -64,6 +64,23 @@ def build_hip(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+def build_variant(tag: str, defs, force: bool = True, verbose: bool = False) -> str:
+    """An experiment build of the HIP library with extra preprocessor definitions (`-DLZ_EXP_...`, `-DLZ_NET_APF=2`):
+    liuzhou_amd/_exp/liblz_<tag>.so, selected at run time with LZ_HIP_LIB.  Measurement aid (scripts/micro/*_ab.py run
+    one child process per library); never loaded by default, git- ignored like every built object."""
+    out = os.path.join(PKG, "_exp", f"liblz_{tag}.so")
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    if not force and os.path.exists(out) and os.path.getmtime(out) >= os.path.getmtime(LIB):
+        return out
+    srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+           "-fvisibility=hidden", *[d if d.startswith("-") else "-D" + d for d in defs], "-o", out] + srcs
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return out
+
+
 EXT_SOURCE = os.path.join(CSRC, "v0_core_ext.cpp")
 EXT_NAME = "_v0_core_native"
 
@@ -102,6 +119,10 @@ def build_ext(force: bool = False, verbose: bool = False) -> str:
 
 
 if __name__ == "__main__":
+    import sys
+    if len(sys.argv) >= 3 and sys.argv[1] == "variant":          # python -m liuzhou_amd.build variant TAG DEF [DEF ...]
+        print(build_variant(sys.argv[2], sys.argv[3:], verbose=True))
+        sys.exit(0)
     print(build_hip(force=True, verbose=True))
     print(build_host(force=True, verbose=True))
     print(build_ext(force=True, verbose=True))

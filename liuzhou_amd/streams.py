@@ -10,6 +10,7 @@ per stream, take ~0.3 ms together if the queues differ and ~0.6 ms if not; candi
 the pool moves on) until a set that overlaps pairwise is found, then released."""
 from __future__ import annotations
 
+import os
 import time
 from typing import List, Tuple
 
@@ -56,6 +57,14 @@ def _overlap(dev: torch.device, s1: torch.cuda.Stream, s2: torch.cuda.Stream) ->
     return sorted(ratios)[1] < 1.5                               # median: ~1.05 on two queues, ~1.95 on one
 
 
+def stream_pair_mode() -> str:
+    """LZ_STREAM_PAIR: "priority" = the k streams get DISTINCT priorities, which the runtime serves from
+    distinct hardware-queue pools -- the mapping is then a property of how the streams were created, not of what else
+    the process has alive (round 6: controlled instead of probed-and-watched); "probe" (default until the A/B of
+    scripts/micro/stream_control.py says otherwise) = equal priorities, probed."""
+    return os.environ.get("LZ_STREAM_PAIR", "probe").strip().lower()
+
+
 def overlapping_streams(device, k: int = 2, max_tries: int = 12) -> Tuple[torch.cuda.Stream, ...]:
     """`k` streams on `device` whose kernels overlap pairwise (see the module docstring).  Falls back to the last
     candidates after `max_tries` collisions (results never depend on the overlap, only the speed does)."""
@@ -64,6 +73,16 @@ def overlapping_streams(device, k: int = 2, max_tries: int = 12) -> Tuple[torch.
     rejected: List[torch.cuda.Stream] = []
     with torch.cuda.device(dev):
         _spin_cycles(dev)
+        if stream_pair_mode() == "priority" and int(k) <= 3:
+            # priorities on this runtime: -1 (high), 0 (normal), 1 (low) where the range allows; k = 2 -> (high, normal)
+            prios = [-1, 0, 1][: int(k)]
+            cand = [torch.cuda.Stream(dev, priority=p) for p in prios]
+            if all(_overlap(dev, a, b) for i, a in enumerate(cand) for b in cand[i + 1:]):
+                overlapping_streams.last_rejected = 0
+                overlapping_streams.last_mode = "priority"
+                return tuple(cand)
+            rejected.extend(cand)                                # not expected; fall through to the probed draw
+        overlapping_streams.last_mode = "probe"
         while len(chosen) < int(k):
             cand = torch.cuda.Stream(dev)
             if all(_overlap(dev, c, cand) for c in chosen) or len(rejected) >= int(max_tries):
@@ -76,6 +95,7 @@ def overlapping_streams(device, k: int = 2, max_tries: int = 12) -> Tuple[torch.
 
 
 overlapping_streams.last_rejected = 0
+overlapping_streams.last_mode = "probe"
 
 
 # Stream capture mode of every hipGraph this package records.  "thread_local": only the CAPTURING thread is held to the
