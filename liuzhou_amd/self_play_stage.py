@@ -169,6 +169,9 @@ def run_self_play_stage(*, model_state: Dict[str, torch.Tensor], num_games: int,
     rows: List[Dict[str, Any]] = []
     failed = True
     try:
+        # the workers share this node's cores and disk: each sizes its writer pool from its share (self_play_worker.
+        # default_writer_threads); spawned children inherit the variable
+        os.environ.setdefault("LZ_WORKERS_ON_NODE", str(max(1, len(active))))
         if in_process:
             rows = [worker_fn(**kwargs_for(*a)) for a in active]
         else:

@@ -217,6 +217,46 @@ def write_worker_chunks(run_once, *, worker_idx: int, device: str, games: int, g
             "num_samples": int(sum(sizes)), "saved_chunks": len(files)}
 
 
+def workers_on_node() -> int:
+    """Self-play workers that share this node's cores, page cache and disk: LZ_WORKERS_ON_NODE (set by
+    `run_self_play_stage` for the processes it spawns), else torchrun's LOCAL_WORLD_SIZE / WORLD_SIZE, else 1."""
+    for key in ("LZ_WORKERS_ON_NODE", "LOCAL_WORLD_SIZE", "WORLD_SIZE"):
+        v = str(os.environ.get(key, "")).strip()
+        if v.isdigit() and int(v) > 0:
+            return int(v)
+    return 1
+
+
+def default_writer_threads() -> int:
+    """Writer threads of one streaming worker when LZ_WORKER_WRITERS is not set: three (what one R worker's drain burst
+    needs, round 5) while the node has the cores -- each worker also runs its playing thread and its copier, so a worker's
+    share of the cores this process may use, minus those two, caps it: 8 workers on a 128-core node keep 3 writers each
+    (40 host threads), 8 workers on 16 cores get 1 (24 threads) instead of oversubscribing the cores 2.5x.  Measured by
+    scripts/rehearse_host_io.py (profiles/r06_host_io_rehearsal.md)."""
+    env = str(os.environ.get("LZ_WORKER_WRITERS", "")).strip()
+    if env.isdigit() and int(env) > 0:
+        return int(env)
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        cores = os.cpu_count() or 1
+    return max(1, min(3, cores // workers_on_node() - 2))
+
+
+def configure_save(crc32: Optional[bool] = None) -> bool:
+    """`torch.save` computes a crc32 of every record: about half of a writer thread's time on a payload that is one big
+    memcpy otherwise.  LZ_SAVE_CRC32=0 (or crc32=False) turns it off for this process -- `torch.load`, and so the
+    reference's loader, reads such files unchanged; external unzip tools may warn.  Default: on (the reference's files
+    carry checksums).  Returns the setting in force."""
+    if crc32 is None:
+        crc32 = os.environ.get("LZ_SAVE_CRC32", "1") != "0"
+    try:
+        torch.serialization.set_crc32_options(bool(crc32))
+        return bool(torch.serialization.get_crc32_options())
+    except AttributeError:                                      # older torch: always on
+        return True
+
+
 class ShardStreamer:
     """Host half of the streaming worker: takes the segments the finished-row log cuts (`on_segment`, called on the playing
     thread: a queue put), copies each to pinned staging on its own stream (copier thread; the log arena goes back to the
@@ -450,8 +490,9 @@ def stream_worker_shard(play, *, device: torch.device, worker_idx: int, games: i
     env_rows = str(os.environ.get("LZ_WORKER_LOG_ROWS", "")).strip()      # rows per log arena (tests: force back-pressure)
     log = FinishedRowLog(device, segment_games=int(segment_games), num_slots=wave, max_steps=int(max_game_plies),
                          action_dim=int(action_dim), capacity_rows=int(env_rows) if env_rows else None)
+    configure_save()
     streamer = ShardStreamer(device, log.capacity, int(action_dim), shard.plan_segment, shard.write_segment,
-                             writers=int(os.environ.get("LZ_WORKER_WRITERS", "3") or 3))
+                             writers=default_writer_threads())
     log.on_segment = streamer.on_segment
     log.on_blocked = streamer.raise_if_failed
     started = time.perf_counter()
@@ -578,7 +619,7 @@ def run_self_play_worker(*, worker_idx: int, shard_device: str, shard_games: int
         if stream:
             env = os.environ
             stream_fallback = streaming_fits(
-                dev, concurrent, int(max_game_plies), writers=int(env.get("LZ_WORKER_WRITERS", "3") or 3),
+                dev, concurrent, int(max_game_plies), writers=default_writer_threads(),
                 segment_games=int(env["LZ_WORKER_SEGMENT_GAMES"]) if env.get("LZ_WORKER_SEGMENT_GAMES", "").strip() else None,
                 log_rows=int(env["LZ_WORKER_LOG_ROWS"]) if env.get("LZ_WORKER_LOG_ROWS", "").strip() else None)
             if stream_fallback is not None:

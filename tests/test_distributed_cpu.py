@@ -115,3 +115,46 @@ def test_bench_spawns_its_own_ranks_and_relays_rank0_line():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 5 and out["dry_run"] is True
     assert out["ms_per_step"] >= 2.0                      # rank 1 sleeps 2 ms per step: the MAX over ranks was taken
+
+
+def test_gather_world4_with_an_empty_and_an_oversized_rank_gloo():
+    """Four ranks, one without a row and one with 300x the others' (a rank whose games ran long / a straggler's backlog):
+    rank 0 ends with every rank's rows in rank order, bit for bit."""
+    world, counts = 4, [3, 0, 2000, 7]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, counts, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    items = [q.get(timeout=180) for _ in range(2 * world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    flags = [(k, v) for k, v in items if k != "digest"]
+    assert ("gather", True) in flags and sum(1 for k, v in flags if k == "none" and v) == world - 1
+    digests = [v for k, v in items if k == "digest"]
+    assert len(digests) == world and max(digests) - min(digests) < 1e-9
+
+
+def test_bench_dry_run_with_eight_ranks_rehearses_the_scale_run():
+    """`bench.py --gpus 8 --dry-run`: the shape of the driver's 8-GPU SCALE run (spawned ranks, barrier, MAX over ranks, the
+    C4 gather to rank 0 with one empty rank, per-rank rows in the line) over gloo on the CPU -- no GPU, no RCCL."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    env["LZ_BENCH_PORT"] = str(_free_port())
+    env["OMP_NUM_THREADS"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "4", "--warmup", "1",
+                        "--dry-run"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["dry_run"] is True and out["ms_per_step"] >= 8.0      # rank 7 sleeps 8 ms per step
+    assert [p["rank"] for p in out["per_rank"]] == list(range(8)) and out["per_rank"][7]["rows"] == 0
+    assert out["gather"]["rows"] == sum(p["rows"] for p in out["per_rank"]) == 7 * 16 * 4
+    assert out["gather"]["source_ranks"] == list(range(7))
