@@ -1281,7 +1281,7 @@ def self_play_tree_gpu(model, num_games: int, mcts_simulations: int, temperature
         mcts_counters={"leaf_eval_count": int(mcts.leaf_evals) - (
                            wasted_plies * wave * (int(mcts_simulations) + 1)
                            if int(batch_k) <= 1 and not (compact_lists and getattr(mcts, "last_search_lists", False)) else 0),
-                       "compact_eval_lists": int(compact_lists),
+                       "compact_eval_lists": int(compact_lists), "search_parts": len(engines),
                        "list_searches": int(sum(getattr(p, "list_searches", 0) for p in (getattr(mcts, "parts", None) or [mcts]))),
                        "masked_extra_plies": wasted_plies, "graph_retry_off": int(bool(mcts.graph_retry_off)),
                        # where the wall time outside `elapsed_sec` (the plies) goes: engine construction or cache hit,

@@ -138,7 +138,7 @@ def test_bench_two_ranks_with_gather_in_the_timed_region():
     assert abs(out["value"] - 2 * 256 * 4 / (out["ms_per_step"] * 4e-3)) < 2e-3 * out["value"]      # ms_per_step is rounded
     g = out["gather"]
     assert g["rows_on_rank0"] == 2 * 256 * 4 and g["record_bytes"] == 360 and g["bytes_received"] == 256 * 4 * 360
-    assert "gathered to rank 0" in out["config"]["workload"] and out["config"]["workload"].startswith("C4")
+    assert "gathered to rank 0" in out["config"]["workload"] and out["config"]["workload"].startswith("steady-state harness, C4")
     # per-rank rows (all-gathered): a SCALE run can attribute a loss to a straggler, the gather or a power-capped package
     pr = out["per_rank"]
     assert [d["rank"] for d in pr] == [0, 1] and out["backend"] == "gloo" and out["rccl_ranks"] == 2
