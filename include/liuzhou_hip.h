@@ -447,6 +447,10 @@ typedef struct LzTreeWaveDesc {
     void*    eval_state;           /* [batch_k * B] packed: the leaves of the wave that need the network, compacted */
     int64_t* eval_count;           /* [1] length of that list (device-side batch size of the network launch) */
     int64_t* eval_total;           /* [1] sum of eval_count over the previous waves (statistics) */
+    int32_t  max_backtrack_steps;  /* the reference's MAX_BACKTRACK_STEPS (src/mcts.py:337): a walk gives up after this many
+                                      upward moves; every walk of a wave restarts at the root and replays the earlier
+                                      ones, so the count is cumulative over the wave and the wave ends there.  0 = 128 */
+    int32_t  reserved_;
 } LzTreeWaveDesc;
 /* SelectLeaves for a wave: up to min(batch_k, sims - sims_done) distinct leaves per game, in the order the reference
  * collects them (src/mcts.py:333-425); sims_done += leaves found.  reset_budget != 0 starts a new search. */
@@ -533,6 +537,23 @@ LZ_API int lz_root_prepare(const void* root_states, int64_t batch, const float* 
 LZ_API int lz_root_collect(const void* root_states, const void* child_states, const int32_t* child_ref,
                            const float* child_values, const uint64_t* n_children, int64_t capacity,
                            float soft_value_k, float* leaf_mat, void* stream);
+/* Top-K lookahead of the root search (`sparse_ply` > 1: V1RootMCTS._refine_via_topk_lookahead,
+ * v1/python/mcts_gpu.py:976-1046, driven from :1150-1160), as two fixed-shape stages around one more round of
+ * network + lz_root_prepare + network + lz_root_collect on the batch * top_k L2 positions:
+ *   lz_root_topk_children: per root the top_k VALID children by leaf value (highest first, lowest slot among equals)
+ *     -> top_slot int32[batch, top_k] (-1: fewer legal actions than that) and l2_states (packed records,
+ *     batch * top_k; the position after that action; an all-zero record -- phase 0, no legal action, so that
+ *     lz_root_prepare gives it no children -- for the empty picks).
+ *   lz_root_refine_topk: leaf_mat[b][top_slot[b][k]] = max(itself, max over the valid entries of row b*top_k + k of
+ *     the L2 leaf matrix (0 when that row has no valid entry or a non-finite maximum)).
+ * A picked child without a legal reply has no grandchildren: its lookahead value is 0, as for a row whose maximum is
+ * not finite (the reference's reshape at mcts_gpu.py:1030 fails on a batch that holds such a child; the operator chain
+ * of liuzhou_amd/mcts_gpu.py defines it this way and the two agree). */
+LZ_API int lz_root_topk_children(const void* root_states, int64_t batch, const float* leaf_mat,
+                                 const uint8_t* valid_mask, const int32_t* action_code_mat, int64_t top_k,
+                                 int32_t* top_slot, void* l2_states, void* stream);
+LZ_API int lz_root_refine_topk(int64_t batch, int64_t top_k, const int32_t* top_slot, const float* l2_leaf_mat,
+                               const uint8_t* l2_valid_mask, float* leaf_mat, void* stream);
 
 /* AdvanceRoots (src/mcts.py:577-592, portable_mcts.py:74-87, portable_mcts.cpp:739-769): after the host has
  * played `played_action[g]` (220-d index, -1: none) and refreshed root_state, promote that child to root and keep

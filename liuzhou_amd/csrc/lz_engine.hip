@@ -212,6 +212,7 @@ struct WaveArrays {
     int* sims_done; int* unfinished;
     int* eval_row; Packed* eval_state; unsigned long long* eval_count;   // compact list of the leaves to evaluate
     unsigned long long* eval_total;                                      // running sum of eval_count (statistics)
+    int max_back;                                                        // MAX_BACKTRACK_STEPS of the reference (128)
 };
 struct Level { int e0, ne_pl, parent_n, node; double last_sc; int last_k, in_edge; };
 static_assert(sizeof(Level) == 32, "level record is 32 bytes");
@@ -244,6 +245,14 @@ __device__ __forceinline__ void tree_select_wave(const Tree& t, const WaveArrays
         Edge mine[2];
         double sc[2] = {0.0, 0.0};
         bool loaded = false;
+        // The reference restarts every walk at the root and gives it up after MAX_BACKTRACK_STEPS = 128 upward moves
+        // (src/mcts.py:337,371-391,404-414).  Within a wave nothing changes, so the walk for leaf j + 1 replays, move for
+        // move, the traversal that found leaves 1..j before it goes on: its count is the traversal's CUMULATIVE number of
+        // upward moves, and once it passes the limit this walk and -- being identical -- every further attempt of the
+        // wave fails: the wave ends with the leaves found so far.  An upward move = leaving an exhausted internal node
+        // for its parent, plus the step from a reserved leaf back to its parent when that parent has no other child left.
+        int ups = 0;
+        bool last_leaf = false;                                          // the current node's last consumed child was a leaf
         while (found < to_collect) {
             if (!loaded) {
                 const double sq = sqrt((double)(parent_n > 1 ? parent_n : 1));
@@ -284,7 +293,10 @@ __device__ __forceinline__ void tree_select_wave(const Tree& t, const WaveArrays
                 if (hi) chosen = kWave + __ffsll((unsigned long long)hi) - 1;
             }
             if (chosen < 0) {                                           // nothing left below this node
+                if (last_leaf && ++ups > w.max_back) break;             // reserved leaf -> this node (which has no alternative)
                 if (d == 0) break;
+                if (++ups > w.max_back) break;                          // this node -> its parent
+                last_leaf = false;
                 --d;
                 const Level up = stack[d];
                 e0 = up.e0; ne = up.ne_pl & 0xFF; node_player = (up.ne_pl & 0x100) ? -1 : 1; parent_n = up.parent_n;
@@ -320,8 +332,10 @@ __device__ __forceinline__ void tree_select_wave(const Tree& t, const WaveArrays
                     leaf_act[found] = terminal ? -1 : (c_meta & 0xFF);
                 }
                 ++found;
+                last_leaf = true;
                 continue;
             }
+            last_leaf = false;
             if (d + 1 >= kWaveDepth) continue;                          // too deep: not followed
             if (lane == 0) {
                 Level here;
@@ -1021,6 +1035,70 @@ __global__ __launch_bounds__(kBlock) void root_collect_kernel(const Packed* __re
     }
 }
 
+// ---- top-K lookahead of the root search (sparse_ply > 1; v1/python/mcts_gpu.py:976-1046, :1150-1160) ----------------
+// root_topk_kernel: one wave per root.  The K best VALID children of the root by their current leaf value (highest first,
+// lowest slot among equals) -> top_slot[g][k] (-1: the root has fewer than k + 1 legal actions) and the L2 position
+// reached by that action (an all-zero record, phase 0 = no legal action, for the empty picks: lz_root_prepare then
+// appends no children for it).  Rows of 72 slots: lane l holds slots l and l + 64.
+__global__ __launch_bounds__(kBlock) void root_topk_kernel(const Packed* __restrict__ roots, int64_t B,
+                                                           const float* __restrict__ leaf, const uint8_t* __restrict__ valid,
+                                                           const int4* __restrict__ codes, int K,
+                                                           int32_t* __restrict__ top_slot, Packed* __restrict__ l2_states) {
+    const int lane = lane_id();
+    const int64_t g = (int64_t)blockIdx.x * kWavesPerBlock + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (g >= B) return;
+    const int64_t row = g * kRootCap;
+    const bool has1 = lane + kWave < kRootCap;
+    float v0 = valid[row + lane] ? leaf[row + lane] : -INFINITY;
+    float v1 = (has1 && valid[row + kWave + lane]) ? leaf[row + kWave + lane] : -INFINITY;
+    const State s = unpack(roots[g]);
+    for (int k = 0; k < K; ++k) {
+        const float m = lzw::wave_max(fmaxf(v0, v1));
+        int slot = -1;
+        if (m > -INFINITY) {
+            const uint64_t lo = __ballot(v0 == m);
+            if (lo) slot = __ffsll((unsigned long long)lo) - 1;
+            else { const uint64_t hi = __ballot(v1 == m); if (hi) slot = kWave + __ffsll((unsigned long long)hi) - 1; }
+        }
+        slot = __builtin_amdgcn_readfirstlane(slot);
+        Packed out; out.w0 = out.w1 = out.w2 = out.w3 = 0ull;
+        if (slot >= 0) {
+            if (lane == (slot & 63)) {
+                const int4 c = codes[row + slot];
+                State child = s;
+                apply(child, c.x, c.y, c.z);
+                l2_states[g * K + k] = pack(child);
+                if (slot < kWave) v0 = -INFINITY; else v1 = -INFINITY;
+            }
+        } else if (lane == 0) {
+            l2_states[g * K + k] = out;
+        }
+        if (lane == 0) top_slot[g * K + k] = slot;
+    }
+}
+
+// root_refine_kernel: one wave per root.  For every picked child: best value among ITS children as its own mover sees
+// them (row g*K + k of the L2 leaf matrix; 0 when it has none or the maximum is not finite), and
+// leaf[g][slot] = max(leaf[g][slot], that) -- the reference's refinement, kept for the picked slots only.
+__global__ __launch_bounds__(kBlock) void root_refine_kernel(int64_t B, int K, const int32_t* __restrict__ top_slot,
+                                                             const float* __restrict__ l2_leaf,
+                                                             const uint8_t* __restrict__ l2_valid, float* __restrict__ leaf) {
+    const int lane = lane_id();
+    const int64_t g = (int64_t)blockIdx.x * kWavesPerBlock + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (g >= B) return;
+    const bool has1 = lane + kWave < kRootCap;
+    for (int k = 0; k < K; ++k) {
+        const int slot = top_slot[g * K + k];
+        if (slot < 0) continue;                                    // wave-uniform
+        const int64_t r2 = (g * K + k) * kRootCap;
+        const float a = l2_valid[r2 + lane] ? l2_leaf[r2 + lane] : -INFINITY;
+        const float b = (has1 && l2_valid[r2 + kWave + lane]) ? l2_leaf[r2 + kWave + lane] : -INFINITY;
+        float best = lzw::wave_max(fmaxf(a, b));
+        if (!isfinite(best)) best = 0.f;
+        if (lane == 0) leaf[g * kRootCap + slot] = fmaxf(leaf[g * kRootCap + slot], best);
+    }
+}
+
 // ---- per-game counter RNG (lz_rng.h): root noise Gammas and pick uniforms as pure functions of (seed, game, ply) ----
 __global__ __launch_bounds__(kBlock) void rng_gamma_kernel(uint64_t seed, const int64_t* __restrict__ game,
                                                            const int64_t* __restrict__ ply, int64_t B, float alpha,
@@ -1048,6 +1126,7 @@ WaveArrays make_wave(const LzTreeWaveDesc* w) {
     a.eval_row = w->eval_row; a.eval_state = reinterpret_cast<Packed*>(w->eval_state);
     a.eval_count = reinterpret_cast<unsigned long long*>(w->eval_count);
     a.eval_total = reinterpret_cast<unsigned long long*>(w->eval_total);
+    a.max_back = w->max_backtrack_steps > 0 ? w->max_backtrack_steps : 128;
     return a;
 }
 bool wave_ok(const LzTreeWaveDesc* w) {
@@ -1266,6 +1345,29 @@ int lz_root_collect(const void* root_states, const void* child_states, const int
                        reinterpret_cast<const Packed*>(root_states), reinterpret_cast<const Packed*>(child_states),
                        child_ref, child_values, reinterpret_cast<const unsigned long long*>(n_children), capacity,
                        soft_value_k, leaf_mat);
+    return st();
+}
+
+int lz_root_topk_children(const void* root_states, int64_t B, const float* leaf_mat, const uint8_t* valid_mask,
+                          const int32_t* action_code_mat, int64_t top_k, int32_t* top_slot, void* l2_states, void* stream) {
+    if (B < 0 || top_k < 0 || top_k > kRootCap) return LZ_ERR_ARG;
+    if (B == 0 || top_k == 0) return LZ_OK;
+    if (!root_states || !leaf_mat || !valid_mask || !action_code_mat || !top_slot || !l2_states) return LZ_ERR_ARG;
+    if (reinterpret_cast<uintptr_t>(action_code_mat) & 15) return LZ_ERR_ALIGN;
+    hipLaunchKernelGGL(root_topk_kernel, dim3(gw(B)), dim3(kBlock), 0, as_stream(stream),
+                       reinterpret_cast<const Packed*>(root_states), B, leaf_mat, valid_mask,
+                       reinterpret_cast<const int4*>(action_code_mat), (int)top_k, top_slot,
+                       reinterpret_cast<Packed*>(l2_states));
+    return st();
+}
+
+int lz_root_refine_topk(int64_t B, int64_t top_k, const int32_t* top_slot, const float* l2_leaf_mat,
+                        const uint8_t* l2_valid_mask, float* leaf_mat, void* stream) {
+    if (B < 0 || top_k < 0 || top_k > kRootCap) return LZ_ERR_ARG;
+    if (B == 0 || top_k == 0) return LZ_OK;
+    if (!top_slot || !l2_leaf_mat || !l2_valid_mask || !leaf_mat) return LZ_ERR_ARG;
+    hipLaunchKernelGGL(root_refine_kernel, dim3(gw(B)), dim3(kBlock), 0, as_stream(stream), B, (int)top_k, top_slot,
+                       l2_leaf_mat, l2_valid_mask, leaf_mat);
     return st();
 }
 

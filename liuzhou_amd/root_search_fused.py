@@ -23,14 +23,26 @@ class FusedRootSearch:
     def __init__(self, net: FusedNet, num_games: int, num_simulations: int, device, exploration_weight: float = 1.0,
                  add_dirichlet_noise: bool = True, dirichlet_alpha: float = 0.3, dirichlet_epsilon: float = 0.25,
                  sample_moves: bool = True, soft_value_k: float = 2.0, use_graph: bool = True, out=None,
-                 seed: int = 12345, game_offset: int = 0, game_stride: Optional[int] = None) -> None:
+                 seed: int = 12345, game_offset: int = 0, game_stride: Optional[int] = None,
+                 sparse_ply: int = 1, sparse_top_k: int = 8, child_eval_mode: str = "value_only") -> None:
         """`out`: optional dict of preallocated output tensors (rows of a larger batch: DualStreamRootSearch).
+        `sparse_ply` > 1 / `sparse_top_k`: the reference's top-K lookahead (v1/python/mcts_gpu.py:976-1046, :1150-1160) as
+        `sparse_ply - 1` extra fixed-shape rounds over B x top_k L2 positions -- lz_root_topk_children, network (full),
+        lz_root_prepare, network (children, counted), lz_root_collect, lz_root_refine_topk -- inside the same captured
+        launch sequence (round 6; before, these options dropped to the host-synced operator chain).
+        `child_eval_mode` "full" (:1342-1345): the children go through the whole network instead of the value head only;
+        the values are the same bits (tests/test_gpu_net.py::test_values_only_mode_equals_full_forward), the policy rows
+        are computed and dropped as the reference does.
         `seed` / `game_offset` / `game_stride`: keys of the per-game counter RNG (game_rng.GameRng) that replaces the
         reference's draws from the device generator (v1/python/mcts_gpu.py:1329-1339,1410-1424)."""
         dev = torch.device(device)
         if dev.type != "cuda":
             raise RuntimeError("FusedRootSearch needs a HIP device (no CPU path)")
         self.net, self.B, self.sims, self.device = net, int(num_games), max(1, int(num_simulations)), dev
+        self.sparse_ply, self.top_k = max(1, int(sparse_ply)), max(1, min(int(sparse_top_k), CAP))
+        self.child_eval_mode = str(child_eval_mode).strip().lower()
+        if self.child_eval_mode not in ("value_only", "full"):
+            raise ValueError(f"Unsupported child_eval_mode={child_eval_mode!r}; expected one of ('value_only', 'full').")
         self.c, self.add_noise = float(exploration_weight), bool(add_dirichlet_noise)
         self.alpha, self.eps, self.sample_moves, self.soft_k = float(dirichlet_alpha), float(dirichlet_epsilon), bool(sample_moves), float(soft_value_k)
         self.use_graph = bool(use_graph) and os.environ.get("LZ_ROOT_GRAPH", "on").strip().lower() not in ("off", "0", "false")
@@ -69,6 +81,28 @@ class FusedRootSearch:
         self.root_value_vec = o("root_value_vec", (B,), torch.float32)
         self._graphs = {}
         self._evals_dev = z((1,), torch.int64)              # network evaluations so far, kept on the device
+        full = self.child_eval_mode == "full"
+        # policy rows of the children (child_eval_mode "full": computed, never read)
+        self.child_lp = tuple(z((B * CAP, 36), torch.float32) for _ in range(3)) if full else None
+        if self.sparse_ply > 1:
+            K = self.top_k
+            N2 = B * K                                                       # L2 positions per lookahead round
+            self.top_slot = z((B, K), torch.int32)
+            self.l2_states = z((N2, 4), torch.int64)
+            self.l2_lp = tuple(z((N2, 36), torch.float32) for _ in range(3))
+            self.l2_values = z((N2,), torch.float32)
+            self.l2_legal_index = z((N2, CAP), torch.int64)
+            self.l2_priors = z((N2, CAP), torch.float32)
+            self.l2_codes = z((N2, CAP, 4), torch.int32)
+            self.l2_valid = z((N2, CAP), torch.uint8)
+            self.l2_counts, self.l2_terminal = z((N2,), torch.int32), z((N2,), torch.uint8)
+            self.l2_leaf = z((N2, CAP), torch.float32)
+            self.l3_states = z((N2 * CAP, 4), torch.int64)
+            self.l3_ref = z((N2 * CAP,), torch.int32)
+            self.l3_values = z((N2 * CAP,), torch.float32)
+            self.n_l3 = z((1,), torch.int64)
+            self.l3_total = z((1,), torch.int64)                             # grandchildren evaluated by the last search
+            self.l3_lp = tuple(z((N2 * CAP, 36), torch.float32) for _ in range(3)) if full else None
         # lists of the width-binned bandit (rows of <= 16 / <= 32 actions share a wave four / two at a time): caller-owned,
         # so that the launch is allocation-free and can be captured on whatever stream torch captures on
         ws_bytes = C.c_int64(0)
@@ -85,11 +119,35 @@ class FusedRootSearch:
                                p(self.codes), p(self.valid), p(self.counts), p(self.terminal), p(self.leaf),
                                p(self.child_states), p(self.child_ref), p(self.n_children), L.i64(B * CAP),
                                p(self.overflow), st), "root_prepare")
+        clp = [p(t) for t in self.child_lp] if self.child_lp is not None else [None, None, None]
         ck(lib.lz_net_forward_packed_counted_f16(C.byref(self.net.desc), p(self.child_states), L.i64(B * CAP),
-                                                 p(self.n_children), None, None, None, None, p(self.child_values), st),
+                                                 p(self.n_children), clp[0], clp[1], clp[2], None, p(self.child_values), st),
            "net_forward_packed_counted")
         ck(lib.lz_root_collect(p(self.root_packed), p(self.child_states), p(self.child_ref), p(self.child_values),
                                p(self.n_children), L.i64(B * CAP), C.c_float(self.soft_k), p(self.leaf), st), "root_collect")
+        if self.sparse_ply > 1:
+            self.l3_total.mul_(0)
+        for _ply in range(2, self.sparse_ply + 1):          # top-K lookahead (mcts_gpu.py:1150-1160): fixed shapes, no sync
+            K, N2 = self.top_k, B * self.top_k
+            ck(lib.lz_root_topk_children(p(self.root_packed), L.i64(B), p(self.leaf), p(self.valid), p(self.codes), L.i64(K),
+                                         p(self.top_slot), p(self.l2_states), st), "root_topk_children")
+            ck(lib.lz_net_forward_packed_f16(C.byref(self.net.desc), p(self.l2_states), L.i64(N2), p(self.l2_lp[0]),
+                                             p(self.l2_lp[1]), p(self.l2_lp[2]), None, p(self.l2_values), st),
+               "net_forward_packed(L2)")
+            ck(lib.lz_root_prepare(p(self.l2_states), L.i64(N2), p(self.l2_lp[0]), p(self.l2_lp[1]), p(self.l2_lp[2]), None,
+                                   C.c_float(0.0), p(self.l2_legal_index), p(self.l2_priors), p(self.l2_codes),
+                                   p(self.l2_valid), p(self.l2_counts), p(self.l2_terminal), p(self.l2_leaf),
+                                   p(self.l3_states), p(self.l3_ref), p(self.n_l3), L.i64(N2 * CAP), p(self.overflow), st),
+               "root_prepare(L2)")
+            l3lp = [p(t) for t in self.l3_lp] if self.l3_lp is not None else [None, None, None]
+            ck(lib.lz_net_forward_packed_counted_f16(C.byref(self.net.desc), p(self.l3_states), L.i64(N2 * CAP), p(self.n_l3),
+                                                     l3lp[0], l3lp[1], l3lp[2], None, p(self.l3_values), st),
+               "net_forward_packed_counted(L3)")
+            ck(lib.lz_root_collect(p(self.l2_states), p(self.l3_states), p(self.l3_ref), p(self.l3_values), p(self.n_l3),
+                                   L.i64(N2 * CAP), C.c_float(self.soft_k), p(self.l2_leaf), st), "root_collect(L2)")
+            ck(lib.lz_root_refine_topk(L.i64(B), L.i64(K), p(self.top_slot), p(self.l2_leaf), p(self.l2_valid), p(self.leaf),
+                                       st), "root_refine_topk")
+            self.l3_total.add_(self.n_l3)                    # (an elementwise kernel node: no memset / memcpy nodes in the graph)
         ck(lib.lz_root_puct_allocate_visits_ws(p(self.priors), p(self.leaf), p(self.valid), L.i64(B), L.i64(CAP),
                                                L.i64(self.sims), C.c_float(self.c), p(self.visits), p(self.value_sum),
                                                p(self.puct_root_values), p(self.puct_ws), L.i64(int(self.puct_ws.numel())),
@@ -160,6 +218,8 @@ class FusedRootSearch:
                     self._graphs[key] = g
                 g.replay()
         self._evals_dev.add_(self.n_children).add_(B)
+        if self.sparse_ply > 1:
+            self._evals_dev.add_(self.l3_total).add_((self.sparse_ply - 1) * B * self.top_k)
         if not want_output:
             return None
         has_root = self.counts > 0

@@ -25,10 +25,11 @@ def streaming_supported(model, *, opening_random_moves: int = 0, child_eval_mode
                         inference_engine=None, collect_step_timing: bool = False) -> bool:
     """True when `self_play_v1_gpu` would take the fused search + device tail for these options, i.e. when it can feed a
     finished-row log (`row_log`).  (`opening_random_moves` is covered by the fused search since round 5 -- the reference's
-    training script starts with 6, scripts/big_train_v1.sh:42.)"""
+    training script starts with 6, scripts/big_train_v1.sh:42; `sparse_ply` > 1 and `child_eval_mode="full"` since round 6:
+    extra fixed-shape stages of the fused search, so no reference option leaves the sync-free path any more.)"""
     return (hasattr(model, "desc") and inference_engine is None and
-            str(child_eval_mode) == "value_only" and int(sparse_ply) <= 1 and not collect_step_timing and
-            os.environ.get("LZ_WAVE_TAIL", "1") != "0")
+            str(child_eval_mode).strip().lower() in ("value_only", "full") and int(sparse_ply) >= 1 and
+            not collect_step_timing and os.environ.get("LZ_WAVE_TAIL", "1") != "0")
 
 
 def self_play_v1_gpu(model, num_games: int, mcts_simulations: int, temperature_init: float,
@@ -63,7 +64,7 @@ def self_play_v1_gpu(model, num_games: int, mcts_simulations: int, temperature_i
     # the options only the operator chain implements.
     fused = None
     if (fused_search and hasattr(model, "desc") and inference_engine is None and
-            str(child_eval_mode) == "value_only" and int(sparse_ply) <= 1 and not collect_step_timing and
+            str(child_eval_mode).strip().lower() in ("value_only", "full") and not collect_step_timing and
             (int(num_games) % wave == 0 or continuous_waves)):
         from .root_search_fused import FusedRootSearch
         # The reference draws noise and moves from the process's torch generator, which its worker seeds per shard
@@ -73,7 +74,8 @@ def self_play_v1_gpu(model, num_games: int, mcts_simulations: int, temperature_i
         fused = FusedRootSearch(model, wave, cfg.num_simulations, dev, seed=rng_seed, exploration_weight=cfg.exploration_weight,
                                 add_dirichlet_noise=cfg.add_dirichlet_noise, dirichlet_alpha=cfg.dirichlet_alpha,
                                 dirichlet_epsilon=cfg.dirichlet_epsilon, sample_moves=cfg.sample_moves,
-                                soft_value_k=cfg.soft_value_k)
+                                soft_value_k=cfg.soft_value_k, sparse_ply=cfg.sparse_ply, sparse_top_k=cfg.sparse_top_k,
+                                child_eval_mode=cfg.child_eval_mode)
 
     outcome = torch.zeros((3,), dtype=torch.int64, device=dev)
     delta_hist = torch.zeros((_DELTA_MAX - _DELTA_MIN + 1,), dtype=torch.int64, device=dev)
@@ -84,7 +86,7 @@ def self_play_v1_gpu(model, num_games: int, mcts_simulations: int, temperature_i
         outcome, delta_hist = tail.outcome, tail.delta_hist
     if row_log is not None and not (tail is not None and bool(continuous_waves)):
         raise RuntimeError("self_play_v1_gpu: a finished-row log needs the fused search, the device tail and continuous "
-                           "waves (fused network, value_only children, sparse_ply 1, no opening moves, no step timing)")
+                           "waves (fused network, no external inference engine, no step timing)")
     lengths = torch.zeros((int(num_games),), dtype=torch.int64, device=dev)
     timing_ms: Dict[str, float] = {k: 0.0 for k in _TRACKED}
     timing_calls: Dict[str, int] = {k: 0 for k in _TRACKED}

@@ -614,6 +614,8 @@ def run_self_play_worker(*, worker_idx: int, shard_device: str, shard_games: int
         if stream and not tree:
             from .self_play_gpu_runner import streaming_supported
             stream = streaming_supported(evaluator, opening_random_moves=int(opening_random_moves), sparse_ply=int(sparse_ply))
+            # (every reference option of the R backend -- sparse_ply, child_eval_mode, opening moves -- now stays on the fused,
+            #  sync-free search: streaming is only off for a network the fused kernel is not built for)
 
         stream_fallback = None
         if stream:

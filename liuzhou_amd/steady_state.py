@@ -24,7 +24,7 @@ class SteadyStateRootSelfPlay:
         self.mcts = V1RootMCTS(model, config, self.dev)
         # fixed population + fused network: the whole search as one captured, sync-free launch sequence
         self.fused = None
-        if fused_search and hasattr(model, "desc") and config.child_eval_mode == "value_only" and int(config.sparse_ply) <= 1:
+        if fused_search and hasattr(model, "desc"):
             from .root_search_fused import DualStreamRootSearch, FusedRootSearch
             # dual_stream: two halves on two streams, so that the bandit / prepare kernels of one half overlap the network
             # launches of the other -- measured 4 % SLOWER than one stream at C2 (two graphs, twice the small launches), so
@@ -37,7 +37,9 @@ class SteadyStateRootSelfPlay:
                                          add_dirichlet_noise=config.add_dirichlet_noise,
                                          dirichlet_alpha=config.dirichlet_alpha,
                                          dirichlet_epsilon=config.dirichlet_epsilon, sample_moves=config.sample_moves,
-                                         soft_value_k=config.soft_value_k, seed=int(seed))
+                                         soft_value_k=config.soft_value_k, seed=int(seed),
+                                         sparse_ply=int(config.sparse_ply), sparse_top_k=int(config.sparse_top_k),
+                                         child_eval_mode=str(config.child_eval_mode))
         self.t_init, self.t_final, self.t_thr = float(temperature_init), float(temperature_final), int(temperature_threshold)
         self.max_plies = int(max_game_plies)
         self.states = GpuStateBatch.initial(self.dev, self.B)

@@ -58,11 +58,14 @@ def _overlap(dev: torch.device, s1: torch.cuda.Stream, s2: torch.cuda.Stream) ->
 
 
 def stream_pair_mode() -> str:
-    """LZ_STREAM_PAIR: "priority" = the k streams get DISTINCT priorities, which the runtime serves from
-    distinct hardware-queue pools -- the mapping is then a property of how the streams were created, not of what else
-    the process has alive (round 6: controlled instead of probed-and-watched); "probe" (default until the A/B of
-    scripts/micro/stream_control.py says otherwise) = equal priorities, probed."""
-    return os.environ.get("LZ_STREAM_PAIR", "probe").strip().lower()
+    """LZ_STREAM_PAIR: "priority" (default since round 6) = the k streams get DISTINCT priorities (-1, 0[, 1]), which the
+    runtime serves from distinct hardware-queue pools -- the mapping is then a property of how the streams were created,
+    not of what else the process has alive: controlled instead of probed-and-watched.  Same-box A/B inside bench.py at C2
+    (profiles/r06_experiments.md): 196.4 / 196.6 k positions/s against 196.8 / 196.3 k for a probed equal-priority pair,
+    0 re-draws either way -- the asymmetry costs nothing (each half is one serial chain of kernels; the priority only
+    decides who goes first when both have a kernel ready).  "probe" = equal priorities, probed (rounds 5's default).
+    The pair is still probed once when it is created and watched by DualStreamTreeMCTS, as a safety net."""
+    return os.environ.get("LZ_STREAM_PAIR", "priority").strip().lower()
 
 
 def overlapping_streams(device, k: int = 2, max_tries: int = 12) -> Tuple[torch.cuda.Stream, ...]:

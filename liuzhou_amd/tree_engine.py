@@ -52,7 +52,8 @@ class LzTreeWaveDesc(C.Structure):
     _fields_ = [("batch_k", C.c_int32), ("path_cap", C.c_int32)] + \
                [(n, C.c_void_p) for n in ("path", "path_len", "leaf_kind", "leaf_state", "leaf_value", "leaf_edge",
                                           "leaf_parent", "sims_done", "unfinished", "eval_row", "eval_state",
-                                          "eval_count", "eval_total")]
+                                          "eval_count", "eval_total")] + \
+               [("max_backtrack_steps", C.c_int32), ("reserved_", C.c_int32)]
 
 
 WAVE_PATH_CAP = 64             # entries per leaf path of a wave (the kernel follows descents up to 48 levels)
@@ -114,8 +115,9 @@ def samples_per_launch_pass(net) -> int:
 class TreeEngine:
     def __init__(self, num_games: int, max_sims: int, device, exploration_weight: float = 1.0,
                  reuse_factor: float = 0.0, batch_k: int = 1, edge_chunk: int = EDGE_CHUNK,
-                 pool_chunks: Optional[int] = None, compact_evals: bool = False) -> None:
-        """`compact_evals`: the fused search evaluates, per simulation, only the leaves that need the network (compact
+                 pool_chunks: Optional[int] = None, compact_evals: bool = False, max_backtrack_steps: int = 0) -> None:
+        """`max_backtrack_steps` (batch_k > 1): the reference's MAX_BACKTRACK_STEPS (src/mcts.py:337; 0 = its 128).
+        `compact_evals`: the fused search evaluates, per simulation, only the leaves that need the network (compact
         device-side list, `LzTreeDesc.live_*`) -- a launch then costs ceil(live / samples per pass) network passes instead
         of one per slot, so a draining wave gets cheaper as its games end; bit-identical results.
         `reuse_factor` > 0 reserves room for kept subtrees of up to reuse_factor * max_sims nodes in every game's node
@@ -187,6 +189,7 @@ class TreeEngine:
             }
             wd = LzTreeWaveDesc()
             wd.batch_k, wd.path_cap = K, WAVE_PATH_CAP
+            wd.max_backtrack_steps = max(0, int(max_backtrack_steps))
             for name, t in self.wbuf.items():
                 setattr(wd, name, t.data_ptr())
             self.wdesc = wd

@@ -850,6 +850,10 @@ static int best_child_excluding(const lzo_tree* t, int ni, const int* banned, in
 /* Collect up to `to_collect` distinct leaves (:333-425), then the terminal fast paths in leaf order (:432-459).
  * Returns the number of simulations consumed (= leaves collected); the leaves that need the network are left in
  * wave_eval[0..wave_n). */
+/* MAX_BACKTRACK_STEPS of src/mcts.py:337 (128); adjustable so that a test can make the limit bite on small trees */
+static int g_max_backtrack = 128;
+void lzo_set_max_backtrack(int n) { g_max_backtrack = n > 0 ? n : 128; }
+
 int lzo_tree_select_wave(lzo_tree* t, int to_collect) {
     t->wave_n = 0;
     if (to_collect > LZO_WAVE_MAX) to_collect = LZO_WAVE_MAX;
@@ -870,7 +874,7 @@ int lzo_tree_select_wave(lzo_tree* t, int to_collect) {
                     const int parent = n->parent;
                     if (nb < 4096) banned[nb++] = node;
                     const int alt = best_child_excluding(t, parent, banned, nb);
-                    if (alt < 0) { node = parent; if (++backtrack > 128) break; continue; }
+                    if (alt < 0) { node = parent; if (++backtrack > g_max_backtrack) break; continue; }
                     node = alt;
                     continue;
                 }
@@ -882,7 +886,7 @@ int lzo_tree_select_wave(lzo_tree* t, int to_collect) {
                 if (node == t->root) break;
                 if (nb < 4096) banned[nb++] = node;
                 node = n->parent;
-                if (++backtrack > 128) break;
+                if (++backtrack > g_max_backtrack) break;
                 continue;
             }
             node = child;

@@ -77,6 +77,7 @@ def lib():
         L.lzo_tree_complete.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_float]
         L.lzo_tree_root_noise.argtypes = [C.c_void_p, C.c_void_p, C.c_float]
         L.lzo_tree_select_wave.argtypes = [C.c_void_p, C.c_int]
+        L.lzo_set_max_backtrack.argtypes = [C.c_int]
         L.lzo_tree_wave_count.argtypes = [C.c_void_p]
         L.lzo_tree_wave_state.argtypes = [C.c_void_p, C.c_int, C.POINTER(CState)]
         L.lzo_tree_complete_wave.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]

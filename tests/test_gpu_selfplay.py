@@ -206,6 +206,63 @@ def test_fused_root_search_equals_operator_chain(sims, use_graph):
     assert fused.children_evaluated() == int(a.legal_mask.sum().item())
 
 
+@pytest.mark.parametrize("ply,top_k,mode", [(2, 4, "value_only"), (3, 3, "value_only"), (2, 8, "full"), (1, 8, "full")])
+def test_fused_root_search_with_topk_lookahead_equals_operator_chain(ply, top_k, mode):
+    """`sparse_ply` 2 / 3 and `child_eval_mode="full"` inside the fused root search (round 6: lz_root_topk_children /
+    lz_root_refine_topk around one more prepare / collect round, all in the captured launch sequence) == the operator
+    chain of V1RootMCTS, which reproduces the reference runner's own sparse traces (g12, test above): same visits-derived
+    policy, picks, values -- with injected root noise, on mid-game positions, positions whose best children end the
+    game or have no reply, and roots with fewer legal actions than top_k."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from liuzhou_amd.mcts_gpu import V1RootMCTS, V1RootMCTSConfig
+    from liuzhou_amd.net import ChessNet, MODEL_CONFIGS
+    from liuzhou_amd.net_hip import FusedNet
+    from liuzhou_amd.root_search_fused import FusedRootSearch, CAP
+    from tests.golden_utils import states, FIELDS
+    from tests.tree_parity import to_gpu_batch
+    dev = "cuda:0"
+    torch.manual_seed(20260314)
+    net = FusedNet(ChessNet(**MODEL_CONFIGS["b6c64"]).eval().to(dev))
+    st = states(load("g1_rules.npz"), "s")
+    st2 = states(load("g2_edges.npz"), "s")
+    B = 400
+    idx = np.random.default_rng(ply * 10 + top_k).integers(0, st["board"].shape[0], B - 40)
+    sub = {f: np.concatenate([np.asarray(st[f])[idx], np.resize(np.asarray(st2[f]), (40,) + np.asarray(st2[f]).shape[1:])])
+           for f in FIELDS}
+    batch = to_gpu_batch({f: np.ascontiguousarray(v) for f, v in sub.items()}, dev)
+    sims = 64
+    cfg = V1RootMCTSConfig(num_simulations=sims, exploration_weight=1.1, add_dirichlet_noise=True, sample_moves=False,
+                           sparse_ply=ply, sparse_top_k=top_k, child_eval_mode=mode)
+    ref = V1RootMCTS(model=net, config=cfg, device=torch.device(dev))
+    temps = torch.where(torch.arange(B, device=dev) % 2 == 0, 1.0, 0.1)
+    # the same Gamma draws for both: left-packed rows of the operator chain = the first `count` slots of the fused rows
+    g = torch.Generator(device="cpu").manual_seed(3)
+    noise72 = torch._standard_gamma(torch.full((B, CAP), 0.3), generator=g).to(dev)
+    first = ref.search_batch(batch, temperatures=temps, add_dirichlet_noise=False)        # row layout of this batch
+    roots = torch.nonzero(~first.terminal_mask).view(-1)
+    M = int(first.legal_mask.sum(1).max().item())
+    ref.injected_noise = noise72.index_select(0, roots)[:, :M]
+    a = ref.search_batch(batch, temperatures=temps)
+    fused = FusedRootSearch(net, B, sims, dev, exploration_weight=1.1, add_dirichlet_noise=True, sample_moves=False,
+                            sparse_ply=ply, sparse_top_k=top_k, child_eval_mode=mode)
+    for rep in range(2):                                   # second call replays the graph
+        b = fused.search_batch(batch, temperatures=temps, injected_noise=noise72)
+        assert torch.equal(a.terminal_mask, b.terminal_mask)
+        assert torch.equal(a.chosen_valid_mask, b.chosen_valid_mask)
+        assert torch.equal(a.chosen_action_indices, b.chosen_action_indices)
+        assert torch.equal(a.policy_dense, b.policy_dense)
+        assert torch.allclose(a.root_value, b.root_value, atol=1e-6)
+    if ply > 1:
+        picked = int((fused.top_slot >= 0).sum().item())
+        assert 0 < picked < B * top_k                               # some roots have fewer legal actions than top_k
+        if ply == 2:
+            assert int(fused.l3_total.item()) == int(fused.l2_counts.sum().item()) > 0
+    # network evaluations of the two searches: roots, children, and per lookahead round the L2 positions + their children
+    l3 = int(fused.l3_total.item()) if ply > 1 else 0
+    assert fused.leaf_evals == 2 * (B + fused.children_evaluated() + (ply - 1) * B * top_k + l3)
+
+
 def test_steady_state_root_population_fused_equals_operator_chain():
     """The steady-state root-PUCT driver gives the same trajectory rows with the fused search as with the operator chain."""
     if not torch.cuda.is_available():

@@ -599,6 +599,30 @@ def test_gpu_wave_batched_search_matches_oracle(batch_k, sims):
     assert waves >= 3 * -(-sims // batch_k)
 
 
+@pytest.mark.parametrize("limit", [3, 9])
+def test_gpu_wave_walks_give_up_after_the_references_backtrack_limit(limit):
+    """src/mcts.py:337,371-414: a walk gives up after MAX_BACKTRACK_STEPS (128) upward moves, and since every walk of a wave
+    restarts at the root and replays the earlier ones, the wave ends there.  With the limit lowered to 3 / 9 on narrow
+    trees (roots with at most three legal actions, 32 leaves per wave) it bites in most waves: the kernel, which continues
+    one traversal and counts its upward moves cumulatively, still collects leaf for leaf what the oracle's literal
+    restart-and-ban walks collect -- fewer leaves per wave than an unlimited traversal finds."""
+    _need_gpu()
+    from tests.tree_parity import run_injected_wave_parity
+    z = load("g1_rules.npz")
+    st = states(z, "s")
+    mask, _ = O.encode_actions(st)
+    narrow = np.flatnonzero((mask.sum(axis=1) >= 1) & (mask.sum(axis=1) <= 3))
+    pick = narrow[np.random.default_rng(limit).permutation(narrow.size)[:40]]
+    sub = {f: np.ascontiguousarray(np.asarray(st[f])[pick]) for f in FIELDS}
+    try:
+        eng, waves, short = run_injected_wave_parity("cuda:0", sims=120, batch_k=32, moves=2, seed=limit, states=sub,
+                                                     max_backtrack=limit)
+        _, waves_free, short_free = run_injected_wave_parity("cuda:0", sims=120, batch_k=32, moves=2, seed=limit, states=sub)
+    finally:
+        O.lib().lzo_set_max_backtrack(128)
+    assert short > short_free and waves > waves_free, (short, short_free, waves, waves_free)
+
+
 def test_gpu_wave_batched_search_on_narrow_trees_needs_extra_rounds():
     """Roots with at most three legal actions: a wave often finds fewer open leaves than batch_k, so the budget is used
     up over more rounds than ceil(sims / batch_k) -- still leaf for leaf the oracle's waves."""

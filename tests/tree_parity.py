@@ -230,7 +230,7 @@ def run_injected_reuse_parity(device, num_games=48, sims=48, moves=4, seed=3, c=
 
 
 def run_injected_wave_parity(device, num_games=48, sims=50, batch_k=16, moves=3, seed=5, c=1.0, with_noise=True, eps=0.25,
-                             reuse_factor=4.0, states=None):
+                             reuse_factor=4.0, states=None, max_backtrack=None):
     """The legacy search's waves (src/mcts.py batch_K, oracle: lzo_tree_select_wave / complete_wave, pinned by g13) on
     the GPU engine: `moves` consecutive searches with subtree reuse, both sides driven by `hash_evaluator`.  Every wave
     must collect the same leaves in the same order (the leaf states are compared), and after every search the root
@@ -245,7 +245,8 @@ def run_injected_wave_parity(device, num_games=48, sims=50, batch_k=16, moves=3,
         idx0 = rng.integers(0, st_all["board"].shape[0], num_games)
         states = {f: np.ascontiguousarray(np.asarray(st_all[f])[idx0]) for f in FIELDS}
     B, K = states["board"].shape[0], int(batch_k)
-    eng = TreeEngine(B, sims, device, c, reuse_factor=reuse_factor, batch_k=K)
+    eng = TreeEngine(B, sims, device, c, reuse_factor=reuse_factor, batch_k=K, max_backtrack_steps=max_backtrack or 0)
+    O.lib().lzo_set_max_backtrack(int(max_backtrack or 128))      # (the caller restores 128: tests/test_gpu_tree.py)
     cur = [O.state_from_batch(states, i) for i in range(B)]
     trees = [O.OracleTree(cur[i], c) for i in range(B)]
     waves_total = short_waves = 0
