@@ -307,10 +307,16 @@ typedef struct LzNetDesc {
                                     SIMD, half the LDS operand reads; measured 2 % slower, off by default);
                                     bit 2: fp32 OPERANDS (parity mode, csrc/lz_net_f32.hip: v_mfma_f32_16x16x4_f32 on
                                     `wfrag_f32`): the reference's fp32 forward within 1e-5, at a fraction of the speed;
-                                    every lz_net_forward_* entry point and the search loops honour it */
+                                    every lz_net_forward_* entry point and the search loops honour it;
+                                    bit 3: SPLIT fp16 operands (round 6, same file): every conv operand as hi + lo * 2^-11
+                                    (two fp16 numbers, 22 bits), every product as three v_mfma_f32_16x16x32_f16 -- the
+                                    fp32 forward within 1e-5 like bit 2, at 3/16 of its matrix-pipe time; needs `wfrag_lo` */
     const float* wfrag_f32;      /* device, fp32 conv fragments [layer][tap][K/4][Cout/16][64 lanes] at the same element
                                     offsets as `wfrag` (layer_offsets); NULL unless flags bit 2 is used */
     int64_t wfrag_f32_bytes;
+    const void* wfrag_lo;        /* device, fp16: the LOW halves of the conv weights, fp16((w - fp16(w)) * 2^11), in the
+                                    order and at the offsets of `wfrag` (conv layers only); NULL unless flags bit 3 is used */
+    int64_t wfrag_lo_bytes;
 } LzNetDesc;
 
 /* ChessNet.forward (src/neural_network.py:213-259) + bucket_logits_to_scalar (:201-210), fused:

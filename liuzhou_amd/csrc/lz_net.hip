@@ -236,7 +236,7 @@ static int net_forward_impl(const LzNetDesc* d, const float* planes, const uint6
     if (!heads && (lp1 || lp2 || lpmc || !value)) return LZ_ERR_ARG;     // all three policy outputs, or values only
     if (d->blocks < 0 || d->blocks > (LZ_NET_MAX_LAYERS - 2) / 2 || d->num_layers != 2 + 2 * d->blocks) return LZ_ERR_ARG;
     if ((reinterpret_cast<uintptr_t>(d->wfrag) & 15) || (reinterpret_cast<uintptr_t>(d->fparams) & 15)) return LZ_ERR_ALIGN;
-    if (d->flags & 4)
+    if (d->flags & (4 | 8))
         return lz_net_forward_f32_dispatch(d, planes, packed, N, lp1, lp2, lpmc, value_logits, value, n_dev, stream);
     NetParams P = make_net_params(d);
 #ifdef LZ_EXP_SAME_LAYER    /* compile-time only, like the other LZ_EXP_* experiments: never in the shipped library.  Timing

@@ -13,6 +13,16 @@
 //     D has the cell on the lane and 4 consecutive channels in registers -> float4 LDS stores for the next layer;
 //   * the fp32 residual stream lives in accumulator registers; heads (global pooling, dense layers, log-softmax,
 //     bucket expectation) are plain fp32 loops over LDS.
+//
+// SPLIT-OPERAND MODE (round 6, LzNetDesc.flags bit 3, template flag X3): the same kernel with every conv operand held as
+// TWO fp16 numbers, v = hi + lo * 2^-11 (hi = fp16(v), lo = fp16((v - hi) * 2^11): 22 significant bits, the low half
+// scaled so that it stays a normal fp16 number), and every product as THREE v_mfma_f32_16x16x32_f16:
+//   W * a  ~=  Wh*ah  +  2^-11 * (Wh*al + Wl*ah)          (the dropped Wl*al term is 2^-22 relative)
+// fp16 x fp16 products are exact in the fp32 accumulators, so the result is the fp32 convolution of operands rounded to 22
+// bits: <= 1e-5 on every network output like the fp32-operand mode, at 3/16 of its matrix-pipe time.  The conv input rows
+// hold [hi(C) | lo(C)] halfs (the bytes of one fp32 row, + 16 bytes of padding against bank conflicts); the weights' low
+// halves come from net_pack (`wfrag_lo`, same fragment order and offsets as `wfrag`); two accumulator sets (the main
+// one and the 2^11-scaled cross terms) are merged after every conv.  Heads are the fp32 loops of the fp32 mode.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -23,11 +33,16 @@
 namespace lzf32 {
 
 typedef float f4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+constexpr float kLoUp = 2048.0f, kLoDown = 1.0f / 2048.0f;      // 2^11: scale of the low halves (net_pack.LO_SHIFT)
 
 constexpr int kHead = 64, kMlp = 128, kBins = 101, kPool = 3 * kHead;
 constexpr int kThreads = 256, kWaves = 4, kWave = 64;
 
 struct Params {
+    const _Float16* wh;         // split-operand mode: fp16 conv fragments (LzNetDesc.wfrag) ...
+    const _Float16* wl;         // ... and their low halves (LzNetDesc.wfrag_lo)
     const float* w;             // fp32 conv fragments
     const float* fp;            // per-channel parameters + dense head matrices (the fp16 kernel's fparams)
     int layer_off[LZ_NET_MAX_LAYERS];   // element offsets of stem, (conv1, conv2) x blocks, stacked head convs
@@ -36,7 +51,7 @@ struct Params {
     const long long* n_dev;
 };
 
-template <int C>
+template <int C, bool X3 = false>
 struct Cfg {
     static constexpr int S = C == 128 ? 2 : 4;                  // samples per workgroup
     static constexpr int NPOS = S * 36;
@@ -45,7 +60,10 @@ struct Cfg {
     static constexpr int CTW = CT / kWaves;                     // channel tiles per wave in the trunk (1 or 2)
     static constexpr int ROWS = S * 58 + 1;                     // + one all-zero row for padding cells
     static constexpr int ZROW = S * 58;
-    static constexpr int ACT_FLOATS = ROWS * C;
+    // split mode: a row is [hi(C) | lo(C)] halfs + 8 halfs of padding (an odd number of 16-byte slots per row, so that the
+    // 16 cells of a tile do not meet in one bank group); in floats: C + 4
+    static constexpr int ROW_HALFS = 2 * C + 8;
+    static constexpr int ACT_FLOATS = X3 ? ROWS * (C + 4) : ROWS * C;
     static constexpr int MAP_FLOATS = NPOS * kHead;             // one 64-channel head map [cell][channel]
     static constexpr int POOL_OFF = ACT_FLOATS + 2 * MAP_FLOATS;
     static constexpr int G_OFF = POOL_OFF + S * kPool;
@@ -83,6 +101,45 @@ __device__ __forceinline__ void conv(f4 (&acc)[NT][NW], const float* __restrict_
     }
 }
 
+// split-operand conv: main[i][j] += Wh*ah, cross[i][j] += Wh*al + Wl*ah (both low halves carry a factor 2^11); K blocks of 32
+// channels, weights = A operand of v_mfma_f32_16x16x32_f16 in the fp16 kernel's fragment order, fetched one step ahead
+template <int C, int NT, int NW, int TAPS, int KDIM, int CTN>
+__device__ __forceinline__ void conv_x3(f4 (&main)[NT][NW], f4 (&cross)[NT][NW], const _Float16* __restrict__ wh,
+                                        const _Float16* __restrict__ wl, int layer_off, int ct0, const _Float16* act,
+                                        const int (&row)[NT], int lane) {
+    constexpr int RS = 2 * C + 8, KB = KDIM / 32, STEPS = TAPS * KB;
+    const int k4 = lane >> 4;
+    const _Float16* whl = wh + layer_off + (size_t)ct0 * 512 + lane * 8;
+    const _Float16* wll = wl + layer_off + (size_t)ct0 * 512 + lane * 8;
+    h8 ah[NW], al[NW], nh[NW], nl[NW];
+#pragma unroll
+    for (int j = 0; j < NW; ++j) { ah[j] = *reinterpret_cast<const h8*>(whl + j * 512); al[j] = *reinterpret_cast<const h8*>(wll + j * 512); }
+    for (int s = 0; s < STEPS; ++s) {
+        const int t = s / KB, kb = s - t * KB;
+        const int toff = TAPS == 9 ? ((t / 3) - 1) * 7 + (t % 3) - 1 : 0;
+        const int sn = s + 1 < STEPS ? s + 1 : s;               // the last step re-reads its own fragments (unused)
+#pragma unroll
+        for (int j = 0; j < NW; ++j) {
+            nh[j] = *reinterpret_cast<const h8*>(whl + ((size_t)sn * CTN + j) * 512);
+            nl[j] = *reinterpret_cast<const h8*>(wll + ((size_t)sn * CTN + j) * 512);
+        }
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            const _Float16* r = act + (row[i] + toff) * RS + kb * 32 + k4 * 8;
+            const h8 bh = *reinterpret_cast<const h8*>(r);
+            const h8 bl = *reinterpret_cast<const h8*>(r + C);
+#pragma unroll
+            for (int j = 0; j < NW; ++j) {
+                main[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[j], bh, main[i][j], 0, 0, 0);
+                cross[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[j], bl, cross[i][j], 0, 0, 0);
+                cross[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[j], bh, cross[i][j], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NW; ++j) { ah[j] = nh[j]; al[j] = nl[j]; }
+    }
+}
+
 // global pooling of a [cell][64] map -> pooled[s][192] = mean | max | sqrt(var + 1e-6)  (src/neural_network.py:67-80,
 // var with unbiased=False, two passes)
 template <int S>
@@ -100,17 +157,19 @@ __device__ __forceinline__ void gpool(const float* map, float* pooled, int tid) 
     }
 }
 
-template <int C>
+template <int C, bool X3 = false>
 __global__ __launch_bounds__(kThreads) void net_forward_f32_kernel(Params P, const float* __restrict__ planes,
                                                                    const uint64_t* __restrict__ packed, int64_t N,
                                                                    float* __restrict__ lp1, float* __restrict__ lp2,
                                                                    float* __restrict__ lpm, float* __restrict__ vlogits,
                                                                    float* __restrict__ value) {
-    using K = Cfg<C>;
+    using K = Cfg<C, X3>;
     constexpr int S = K::S, NT = K::NT, NW = K::CTW;
     if (P.n_dev != nullptr) { const long long nd = *P.n_dev; N = nd < N ? nd : N; }
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* act = lds;
+    _Float16* acth = reinterpret_cast<_Float16*>(lds);        // split mode: rows of [hi(C) | lo(C) | pad] halfs
+    constexpr int RS = K::ROW_HALFS;
     float* pmap = lds + K::ACT_FLOATS;
     float* vmap = pmap + K::MAP_FLOATS;
     float* pooled = lds + K::POOL_OFF;
@@ -154,16 +213,36 @@ __global__ __launch_bounds__(kThreads) void net_forward_f32_kernel(Params P, con
                     v = planes[(n0 + s) * 396 + ch * 36 + p];
                 }
             }
-            act[board_row(n) * C + ch] = v;
+            if constexpr (X3) acth[board_row(n) * RS + ch] = (_Float16)v;      // planes are 0 / 1: exact, low half 0
+            else act[board_row(n) * C + ch] = v;
         }
         __syncthreads();
         f4 x[NT][NW], acc[NT][NW];
+        f4 cr[NT][NW];                                        // split mode: the 2^11-scaled cross terms of the running conv
+        auto zero_cr = [&]() {
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+#pragma unroll
+                for (int j = 0; j < NW; ++j) cr[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
+        };
+        auto merge_cr = [&](f4 (&into)[NT][NW]) {
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+#pragma unroll
+                for (int j = 0; j < NW; ++j) into[i][j] = into[i][j] + cr[i][j] * kLoDown;
+        };
 #pragma unroll
         for (int i = 0; i < NT; ++i)
 #pragma unroll
             for (int j = 0; j < NW; ++j) x[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
         // ---- stem: x = relu(conv(planes) + bias) ----
-        conv<C, NT, NW, 9, 32, K::CT>(x, P.w, P.layer_off[0], ct0, act, row, lane);
+        if constexpr (X3) {
+            zero_cr();
+            conv_x3<C, NT, NW, 9, 32, K::CT>(x, cr, P.wh, P.wl, P.layer_off[0], ct0, acth, row, lane);
+            merge_cr(x);
+        } else {
+            conv<C, NT, NW, 9, 32, K::CT>(x, P.w, P.layer_off[0], ct0, act, row, lane);
+        }
 #pragma unroll
         for (int j = 0; j < NW; ++j) {
             const f4 b = *reinterpret_cast<const f4*>(fp + P.stem_bias + (ct0 + j) * 16 + chq);
@@ -186,8 +265,15 @@ __global__ __launch_bounds__(kThreads) void net_forward_f32_kernel(Params P, con
                 for (int i = 0; i < NT; ++i) {
                     if (row[i] == K::ZROW) continue;          // padding cells of the last tile
                     const f4 t = v[i][j] * sc + sh;
-                    *reinterpret_cast<f4*>(act + row[i] * C + ch) =
-                        (f4){fmaxf(t[0], 0.f), fmaxf(t[1], 0.f), fmaxf(t[2], 0.f), fmaxf(t[3], 0.f)};
+                    const f4 r = (f4){fmaxf(t[0], 0.f), fmaxf(t[1], 0.f), fmaxf(t[2], 0.f), fmaxf(t[3], 0.f)};
+                    if constexpr (X3) {
+                        const h4 hi = __builtin_convertvector(r, h4);
+                        const h4 lo = __builtin_convertvector((r - __builtin_convertvector(hi, f4)) * kLoUp, h4);
+                        *reinterpret_cast<h4*>(acth + row[i] * RS + ch) = hi;
+                        *reinterpret_cast<h4*>(acth + row[i] * RS + C + ch) = lo;
+                    } else {
+                        *reinterpret_cast<f4*>(act + row[i] * C + ch) = r;
+                    }
                 }
             }
             __syncthreads();
@@ -200,16 +286,37 @@ __global__ __launch_bounds__(kThreads) void net_forward_f32_kernel(Params P, con
             for (int i = 0; i < NT; ++i)
 #pragma unroll
                 for (int j = 0; j < NW; ++j) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
-            conv<C, NT, NW, 9, C, K::CT>(acc, P.w, P.layer_off[1 + 2 * blk], ct0, act, row, lane);
+            if constexpr (X3) {
+                zero_cr();
+                conv_x3<C, NT, NW, 9, C, K::CT>(acc, cr, P.wh, P.wl, P.layer_off[1 + 2 * blk], ct0, acth, row, lane);
+                merge_cr(acc);
+            } else {
+                conv<C, NT, NW, 9, C, K::CT>(acc, P.w, P.layer_off[1 + 2 * blk], ct0, act, row, lane);
+            }
             store(acc, -1, bp + 2 * C);
-            conv<C, NT, NW, 9, C, K::CT>(x, P.w, P.layer_off[2 + 2 * blk], ct0, act, row, lane);
+            if constexpr (X3) {
+                zero_cr();
+                conv_x3<C, NT, NW, 9, C, K::CT>(x, cr, P.wh, P.wl, P.layer_off[2 + 2 * blk], ct0, acth, row, lane);
+                merge_cr(x);
+            } else {
+                conv<C, NT, NW, 9, C, K::CT>(x, P.w, P.layer_off[2 + 2 * blk], ct0, act, row, lane);
+            }
         }
         // ---- trunk output relu(bn(x)); head 1x1 convs: 8 output tiles (policy 0..3 | value 4..7), 2 per wave ----
         store(x, P.trunk_a, P.trunk_b);
         f4 h[NT][2];
 #pragma unroll
         for (int i = 0; i < NT; ++i) { h[i][0] = (f4){0.f, 0.f, 0.f, 0.f}; h[i][1] = (f4){0.f, 0.f, 0.f, 0.f}; }
-        conv<C, NT, 2, 1, C, 8>(h, P.w, P.layer_off[1 + 2 * P.blocks], wave * 2, act, row, lane);
+        if constexpr (X3) {
+            f4 hc[NT][2];
+#pragma unroll
+            for (int i = 0; i < NT; ++i) { hc[i][0] = (f4){0.f, 0.f, 0.f, 0.f}; hc[i][1] = (f4){0.f, 0.f, 0.f, 0.f}; }
+            conv_x3<C, NT, 2, 1, C, 8>(h, hc, P.wh, P.wl, P.layer_off[1 + 2 * P.blocks], wave * 2, acth, row, lane);
+#pragma unroll
+            for (int i = 0; i < NT; ++i) { h[i][0] = h[i][0] + hc[i][0] * kLoDown; h[i][1] = h[i][1] + hc[i][1] * kLoDown; }
+        } else {
+            conv<C, NT, 2, 1, C, 8>(h, P.w, P.layer_off[1 + 2 * P.blocks], wave * 2, act, row, lane);
+        }
         {
             float* map = wave < 2 ? pmap : vmap;              // waves 0,1 -> policy map, 2,3 -> value map
 #pragma unroll
@@ -291,13 +398,13 @@ __global__ __launch_bounds__(kThreads) void net_forward_f32_kernel(Params P, con
     }
 }
 
-template <int C>
+template <int C, bool X3 = false>
 int launch(const Params& P, const float* planes, const uint64_t* packed, int64_t N, float* lp1, float* lp2, float* lpm,
            float* vlogits, float* value, int max_blocks, hipStream_t st) {
-    using K = Cfg<C>;
+    using K = Cfg<C, X3>;
     static bool configured = false;
     if (!configured) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(net_forward_f32_kernel<C>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(net_forward_f32_kernel<C, X3>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS_BYTES) != hipSuccess)
             return LZ_ERR_LAUNCH;
         configured = true;
@@ -305,7 +412,7 @@ int launch(const Params& P, const float* planes, const uint64_t* packed, int64_t
     const int64_t n_pass = (N + K::S - 1) / K::S;
     int grid = (int)(n_pass < max_blocks ? n_pass : max_blocks);
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(net_forward_f32_kernel<C>, dim3(grid), dim3(kThreads), K::LDS_BYTES, st, P, planes, packed, N, lp1,
+    hipLaunchKernelGGL((net_forward_f32_kernel<C, X3>), dim3(grid), dim3(kThreads), K::LDS_BYTES, st, P, planes, packed, N, lp1,
                        lp2, lpm, vlogits, value);
     return hipGetLastError() == hipSuccess ? LZ_OK : LZ_ERR_LAUNCH;
 }
@@ -316,9 +423,18 @@ int launch(const Params& P, const float* planes, const uint64_t* packed, int64_t
 extern "C" int lz_net_forward_f32_dispatch(const LzNetDesc* d, const float* planes, const uint64_t* packed, int64_t N, float* lp1,
                                 float* lp2, float* lpmc, float* value_logits, float* value, const int64_t* n_dev,
                                 void* stream) {
-    if (!d->wfrag_f32 || (reinterpret_cast<uintptr_t>(d->wfrag_f32) & 15)) return LZ_ERR_ARG;
+    const bool x3 = (d->flags & 8) != 0;                       // split-operand mode: fp16 fragments + their low halves
+    if (x3) {
+        if (!d->wfrag_lo || (reinterpret_cast<uintptr_t>(d->wfrag_lo) & 15) || (reinterpret_cast<uintptr_t>(d->wfrag) & 15) ||
+            d->wfrag_lo_bytes < (int64_t)d->layer_offsets[d->num_layers - 1] * 2)
+            return LZ_ERR_ARG;
+    } else if (!d->wfrag_f32 || (reinterpret_cast<uintptr_t>(d->wfrag_f32) & 15)) {
+        return LZ_ERR_ARG;
+    }
     lzf32::Params P;
     P.w = d->wfrag_f32;
+    P.wh = reinterpret_cast<const _Float16*>(d->wfrag);
+    P.wl = reinterpret_cast<const _Float16*>(d->wfrag_lo);
     P.fp = d->fparams;
     for (int i = 0; i < d->num_layers; ++i) P.layer_off[i] = d->layer_offsets[i];
     P.blocks = d->blocks;
@@ -328,6 +444,11 @@ extern "C" int lz_net_forward_f32_dispatch(const LzNetDesc* d, const float* plan
     P.p_out = d->off_p_out; P.v_w1T = d->off_v_w1T; P.v_b1 = d->off_v_b1; P.v_w2T = d->off_v_w2T; P.v_b2 = d->off_v_b2;
     const int max_blocks = d->max_blocks > 0 ? d->max_blocks : 1024;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (x3) {
+        if (d->channels == 64) return lzf32::launch<64, true>(P, planes, packed, N, lp1, lp2, lpmc, value_logits, value, max_blocks, st);
+        if (d->channels == 128) return lzf32::launch<128, true>(P, planes, packed, N, lp1, lp2, lpmc, value_logits, value, max_blocks, st);
+        return LZ_ERR_UNSUPPORTED;
+    }
     if (d->channels == 64) return lzf32::launch<64>(P, planes, packed, N, lp1, lp2, lpmc, value_logits, value, max_blocks, st);
     if (d->channels == 128) return lzf32::launch<128>(P, planes, packed, N, lp1, lp2, lpmc, value_logits, value, max_blocks, st);
     return LZ_ERR_UNSUPPORTED;

@@ -169,7 +169,7 @@ int lz_tree_search_persistent(const LzTreeDesc* d, const LzNetDesc* net, int64_t
     if ((reinterpret_cast<uintptr_t>(net->wfrag) & 15) || (reinterpret_cast<uintptr_t>(net->fparams) & 15)) return LZ_ERR_ALIGN;
     // built for the 64-channel network (two 4-wave workgroups per CU); the fp32 parity mode and the 128-channel
     // network (one workgroup fills a CU's LDS: nothing would overlap the tree step) stay on lz_tree_search
-    if (net->channels != 64 || (net->flags & 4)) return LZ_ERR_UNSUPPORTED;
+    if (net->channels != 64 || (net->flags & (4 | 8))) return LZ_ERR_UNSUPPORTED;
     const int64_t B = d->num_games;
     if (B == 0) return LZ_OK;
     int device = 0;

@@ -30,7 +30,7 @@ class LzNetDesc(C.Structure):
                [(n, C.c_int32) for n in ("off_stem_bias", "off_block0", "off_trunk_a", "off_trunk_b", "off_head_bias",
                                          "off_p_gwT", "off_p_a2", "off_p_b2", "off_p_out", "off_v_w1T", "off_v_b1",
                                          "off_v_w2T", "off_v_b2", "flags")] + \
-               [("wfrag_f32", C.c_void_p), ("wfrag_f32_bytes", C.c_int64)]
+               [("wfrag_f32", C.c_void_p), ("wfrag_f32_bytes", C.c_int64), ("wfrag_lo", C.c_void_p), ("wfrag_lo_bytes", C.c_int64)]
 
 
 _configured = False
@@ -75,19 +75,21 @@ class FusedNet:
         operand reads of the 8-wave shape (flags bit 1); None: env LZ_NET_WIDE (default off).
         `precision`: "fp16" = fp16 MFMA operands with fp32 accumulation (the reference's autocast inference mode);
         "fp32" = fp32 operands (csrc/lz_net_f32.hip, flags bit 2): the reference's fp32 forward within 1e-5 -- the parity
-        mode, many times slower, honoured by every entry point including the captured search loops."""
+        mode, many times slower, honoured by every entry point including the captured search loops;
+        "fp16x3" = split fp16 operands (round 6, flags bit 3): every operand as two fp16 numbers (22 bits), every product
+        as three fp16 MFMAs -- within 1e-5 of the fp32 forward on every output like "fp32", several times faster."""
         global _configured
         dev = torch.device(device) if device is not None else next(model.parameters()).device
         if dev.type != "cuda":
             raise RuntimeError("FusedNet needs a HIP device (no CPU path)")
         self.device = dev
-        if precision not in ("fp16", "fp32"):
-            raise ValueError(f"precision must be fp16 or fp32, got {precision!r}")
+        if precision not in ("fp16", "fp32", "fp16x3"):
+            raise ValueError(f"precision must be fp16, fp32 or fp16x3, got {precision!r}")
         self.precision = precision
         why = fused_unsupported_reason(model)
         if why is not None:
             raise RuntimeError(f"fused network kernel does not cover this model: {why}")
-        self.pack: NetPack = pack_model(model, fp32_fragments=precision == "fp32").to(dev)
+        self.pack: NetPack = pack_model(model, fp32_fragments=precision == "fp32", lo_fragments=precision == "fp16x3").to(dev)
         d = LzNetDesc()
         d.channels, d.blocks = self.pack.channels, self.pack.blocks
         d.num_layers = len(self.pack.layer_offsets)
@@ -100,6 +102,10 @@ class FusedNet:
             d.flags |= 4
             d.wfrag_f32 = self.pack.wfrag_f32.data_ptr()
             d.wfrag_f32_bytes = int(self.pack.wfrag_f32.numel()) * 4
+        elif precision == "fp16x3":
+            d.flags |= 8
+            d.wfrag_lo = self.pack.wfrag_lo.data_ptr()
+            d.wfrag_lo_bytes = int(self.pack.wfrag_lo.numel()) * 2
         d.wfrag, d.fparams = self.pack.wfrag.data_ptr(), self.pack.fparams.data_ptr()
         d.wfrag_bytes = int(self.pack.wfrag.numel()) * 2
         d.fparams_bytes = int(self.pack.fparams.numel()) * 4
@@ -130,13 +136,15 @@ class FusedNet:
         """Re-pack `model`'s current weights INTO the existing device buffers (same architecture): descriptors, kernel
         arguments frozen in captured graphs and every `variant()` keep pointing at valid, now updated, memory.  The
         checkpoint hand-off of a training iteration (v1/train.py:978 writes `model_state_cpu.pt` for the workers)."""
-        p = pack_model(model, fp32_fragments=self.precision == "fp32")
+        p = pack_model(model, fp32_fragments=self.precision == "fp32", lo_fragments=self.precision == "fp16x3")
         if (p.channels, p.blocks) != (self.pack.channels, self.pack.blocks) or p.wfrag.numel() != self.pack.wfrag.numel():
             raise ValueError("refresh() needs the architecture this FusedNet was built for")
         self.pack.wfrag.copy_(p.wfrag.to(self.device))
         self.pack.fparams.copy_(p.fparams.to(self.device))
         if p.wfrag_f32 is not None:
             self.pack.wfrag_f32.copy_(p.wfrag_f32.to(self.device))
+        if p.wfrag_lo is not None:
+            self.pack.wfrag_lo.copy_(p.wfrag_lo.to(self.device))
         return self
 
     def variant(self, half_workgroups: bool = False, wide_tiles: Optional[bool] = None) -> "FusedNet":
@@ -147,7 +155,7 @@ class FusedNet:
         C.memmove(C.byref(d), C.byref(self.desc), C.sizeof(LzNetDesc))
         wide = bool(self.desc.flags & 2) if wide_tiles is None else bool(wide_tiles)
         d.flags = (1 if (half_workgroups and self.pack.channels == 64) else 0) | \
-                  (2 if (wide and self.pack.channels == 128) else 0) | (self.desc.flags & 4)
+                  (2 if (wide and self.pack.channels == 128) else 0) | (self.desc.flags & (4 | 8))
         other.desc = d
         other.last_value = None
         return other

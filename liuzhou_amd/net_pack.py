@@ -32,8 +32,12 @@ def _bn_affine(bn) -> Tuple[torch.Tensor, torch.Tensor]:
     return a, b
 
 
-def _frag_conv(w: torch.Tensor, k_pad: int) -> torch.Tensor:
-    """w [Co, Ci, kh, kw] (double) -> fp16 fragments [taps][kb][ct][64][8]"""
+LO_SHIFT = 11        # the fp16 "low half" of a split operand is stored scaled by 2^LO_SHIFT (csrc/lz_net_x3.hip)
+
+
+def _frag_conv(w: torch.Tensor, k_pad: int, lo: bool = False) -> torch.Tensor:
+    """w [Co, Ci, kh, kw] (double) -> fp16 fragments [taps][kb][ct][64][8].
+    `lo`: the fragments of the split-operand mode's LOW halves instead: fp16((w - fp16(w)) * 2^LO_SHIFT), same order."""
     co, ci, kh, kw = w.shape
     taps = kh * kw
     wp = torch.zeros((co, k_pad, kh, kw), dtype=torch.float64)
@@ -51,6 +55,8 @@ def _frag_conv(w: torch.Tensor, k_pad: int) -> torch.Tensor:
                 cos = (16 * ct + row).view(64, 1).expand(64, 8)
                 cis = (32 * kb + kbase.view(64, 1) + j.view(1, 8))
                 out[t, kb, ct] = wp[cos, cis, ky, kx]
+    if lo:
+        return ((out - out.to(torch.float16).to(torch.float64)) * float(1 << LO_SHIFT)).to(torch.float16)
     return out.to(torch.float16)
 
 
@@ -81,14 +87,16 @@ class NetPack:
     foff: Dict[str, int]           # offsets (in floats) into fparams
     head_offsets: List[int] = None  # offsets (in halfs) of gpool_linear / fc1 / fc2 / out-conv fragments
     wfrag_f32: torch.Tensor = None  # optional fp32 conv fragments (parity mode), same element offsets as wfrag
+    wfrag_lo: torch.Tensor = None   # optional fp16 LOW halves of the conv weights (split-operand mode), same offsets as wfrag
 
     def to(self, device) -> "NetPack":
         return NetPack(self.channels, self.blocks, self.wfrag.to(device), self.fparams.to(device),
                        list(self.layer_offsets), dict(self.foff), list(self.head_offsets),
-                       None if self.wfrag_f32 is None else self.wfrag_f32.to(device))
+                       None if self.wfrag_f32 is None else self.wfrag_f32.to(device),
+                       None if self.wfrag_lo is None else self.wfrag_lo.to(device))
 
 
-def pack_model(model, fp32_fragments: bool = False) -> NetPack:
+def pack_model(model, fp32_fragments: bool = False, lo_fragments: bool = False) -> NetPack:
     """Single-threaded wrapper of `_pack_model`: the packing is a few hundred small fp64 host operators, and torch's
     intra-op pool (one thread per core: 128 on the GPU box) costs more to wake per operator than the operator takes --
     measured 0.7 - 2.5 s with the pool, 0.09 s on one thread (`scripts/micro/worker_setup.py`); it was most of the
@@ -96,13 +104,15 @@ def pack_model(model, fp32_fragments: bool = False) -> NetPack:
     prev = torch.get_num_threads()
     torch.set_num_threads(1)
     try:
-        return _pack_model(model, fp32_fragments)
+        return _pack_model(model, fp32_fragments, lo_fragments)
     finally:
         torch.set_num_threads(prev)
 
 
-def _pack_model(model, fp32_fragments: bool = False) -> NetPack:
+def _pack_model(model, fp32_fragments: bool = False, lo_fragments: bool = False) -> NetPack:
     """`fp32_fragments`: also lay the (BN-folded) conv weights out as fp32 MFMA fragments for the parity-mode kernel.
+    `lo_fragments`: also the fp16 low halves of the conv weights, w = fp16(w) + lo * 2^-LO_SHIFT to ~22 bits, for the
+    split-operand mode (csrc/lz_net_x3.hip: three fp16 MFMAs per product instead of one fp32 MFMA at 1/16 of the rate).
     BN folding + MFMA fragment order, on a detached host copy: the caller's module keeps its device, its train /
     eval mode and its parameter storages (optimizer state, DDP buckets and captured graphs keep pointing at them)."""
     import copy
@@ -119,12 +129,15 @@ def _pack_model(model, fp32_fragments: bool = False) -> NetPack:
 
     frags: List[torch.Tensor] = []
     frags32: List[torch.Tensor] = []
+    frags_lo: List[torch.Tensor] = []
     fl: List[torch.Tensor] = []
 
     def conv_layer(w: torch.Tensor, k_pad: int) -> None:
         frags.append(_frag_conv(w, k_pad))
         if fp32_fragments:
             frags32.append(_frag_conv_f32(w, k_pad))
+        if lo_fragments:
+            frags_lo.append(_frag_conv(w, k_pad, lo=True))
     foff: Dict[str, int] = {}
 
     def put(name: str, t: torch.Tensor) -> None:
@@ -184,7 +197,8 @@ def _pack_model(model, fp32_fragments: bool = False) -> NetPack:
     wfrag = torch.cat([f.reshape(-1) for f in frags]).contiguous()
     fparams = torch.cat(fl).to(torch.float32).contiguous()
     wf32 = torch.cat([f.reshape(-1) for f in frags32]).contiguous() if fp32_fragments else None
-    return NetPack(C, NB, wfrag, fparams, offsets, foff, head_offsets, wf32)
+    wlo = torch.cat([f.reshape(-1) for f in frags_lo]).contiguous() if lo_fragments else None     # conv layers only
+    return NetPack(C, NB, wfrag, fparams, offsets, foff, head_offsets, wf32, wlo)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -442,7 +442,7 @@ class TreeEngine:
     def persistent_ok(self, net: FusedNet) -> bool:
         """Whether search() runs the one-launch-per-move kernel: 64-channel net in fp16 mode, not switched off
         (`persistent` attribute; env LZ_TREE_PERSISTENT=0)."""
-        return (bool(self.persistent) and self.batch_k <= 1 and int(net.desc.channels) == 64 and not (int(net.desc.flags) & 4)
+        return (bool(self.persistent) and self.batch_k <= 1 and int(net.desc.channels) == 64 and not (int(net.desc.flags) & (4 | 8))
                 and not self.compact_evals)
 
     def enable_phase_ticks(self) -> torch.Tensor:

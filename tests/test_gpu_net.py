@@ -130,9 +130,12 @@ def _g9_model(name, seed):
     return m.eval()
 
 
+@pytest.mark.parametrize("precision", ["fp32", "fp16x3"])
 @pytest.mark.parametrize("name", ["b6c64", "b10c128"])
-def test_fp32_operand_kernel_meets_the_reference_tolerance(name):
-    """The hand-written kernel in its fp32-operand mode (csrc/lz_net_f32.hip, v_mfma_f32_16x16x4_f32) against the
+def test_fp32_operand_kernel_meets_the_reference_tolerance(name, precision):
+    """(`fp16x3`, round 6: the same kernel with every conv operand split into two fp16 numbers -- 22 bits -- and every
+    product as three fp16 MFMAs: the same bar, several times faster; bench.py `also.C2_fp16x3`.)
+    The hand-written kernel in its fp32-operand mode (csrc/lz_net_f32.hip, v_mfma_f32_16x16x4_f32) against the
     REFERENCE's own outputs (tests/golden/g9_net.npz: src/neural_network.py ChessNet in fp32, weights regenerated from
     the seed) and against the fp32 module on several hundred real positions: <= 1e-5 on the three log-prob heads, the
     101 value logits and the scalar value -- north_star's tolerance for policy / value tensors."""
@@ -142,7 +145,7 @@ def test_fp32_operand_kernel_meets_the_reference_tolerance(name):
     from liuzhou_amd.net_hip import FusedNet
     z = load("g9_net.npz")
     m = _g9_model(name, 20260314).to(DEV)
-    f32 = FusedNet(m, precision="fp32")
+    f32 = FusedNet(m, precision=precision)
     x = torch.from_numpy(z["inputs"].astype(np.float32)).to(DEV)
     got = f32(x)
     for g, k in zip(got, ("lp1", "lp2", "lpmc", "value_logits")):
@@ -153,8 +156,10 @@ def test_fp32_operand_kernel_meets_the_reference_tolerance(name):
         val = f32.last_value
         with torch.inference_mode():
             r1, r2, rm, rv = m(xs)
-        for a, b in ((lp1, r1), (lp2, r2), (lpm, rm), (vl, rv), (val, bucket_logits_to_scalar(rv))):
-            assert (a - b).abs().max().item() <= 1e-5, (name, n, (a - b).abs().max().item())
+        worst = max((a - b).abs().max().item() for a, b in ((lp1, r1), (lp2, r2), (lpm, rm), (vl, rv),
+                                                            (val, bucket_logits_to_scalar(rv))))
+        print(f"{precision} {name} n={n}: max |d| over log-probs / value logits / value {worst:.2e}")
+        assert worst <= 1e-5, (name, precision, n, worst)
     # packed-state entry point (the search loop's) == planes entry point, and the mode survives variant()
     from liuzhou_amd.tree_engine import TreeEngine
     from tests.tree_parity import to_gpu_batch
@@ -168,6 +173,44 @@ def test_fp32_operand_kernel_meets_the_reference_tolerance(name):
     b = f32.forward_packed(eng.buf["root_state"])
     for u, v in zip(a[:3], b[:3]):
         assert torch.equal(u, v)
+
+
+def test_split_operand_mode_on_trained_scale_activations_and_inside_the_search():
+    """fp16x3 where fp16's range could bite: BatchNorm statistics that make the activations 64x larger (low halves far
+    above fp16's subnormals, high halves still finite) and 1/64 as large (low halves would be subnormal without their
+    2^11 scale) -- still within 1e-5 relative to the logits' scale; refresh() re-packs the low halves too; and the mode runs
+    inside the captured tree search (every entry point honours LzNetDesc.flags bit 3)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from liuzhou_amd.net_hip import FusedNet
+    from liuzhou_amd.tree_engine import PortableTreeMCTS
+    from liuzhou_amd.mcts_gpu import GpuStateBatch
+    for scale in (64.0, 1.0 / 64.0):
+        m = _g9_model("b6c64", 7).to(DEV)
+        with torch.no_grad():
+            m.stem_bn.weight.mul_(scale); m.stem_bn.bias.mul_(scale)          # the whole residual stream scales with it
+            m.trunk_bn.weight.div_(scale)                                      # ... and the heads see the usual scale
+        x = _planes(200, seed=3)
+        f = FusedNet(m, precision="fp16x3")
+        with torch.inference_mode():
+            ref = m(x)
+        for got, want in zip(f(x), ref):
+            assert (got - want).abs().max().item() <= 1e-5 * max(1.0, want.abs().max().item()), scale
+    m = _g9_model("b6c64", 8).to(DEV)
+    f = FusedNet(m, precision="fp16x3")
+    with torch.no_grad():
+        for p in m.parameters():
+            p.add_(torch.randn_like(p) * 0.02)
+    f.refresh(m)
+    x = _planes(64, seed=4)
+    for a, b in zip(f(x), FusedNet(m, precision="fp16x3")(x)):
+        assert torch.equal(a, b)
+    a = PortableTreeMCTS(f, 64, 24, DEV, add_dirichlet_noise=False, sample_moves=False)
+    b = PortableTreeMCTS(FusedNet(m, precision="fp32"), 64, 24, DEV, add_dirichlet_noise=False, sample_moves=False)
+    st = GpuStateBatch.initial(DEV, 64)
+    temps = torch.ones(64, device=DEV)
+    oa, ob = a.search_batch(st, temperatures=temps), b.search_batch(st, temperatures=temps)
+    assert torch.allclose(oa.policy_dense, ob.policy_dense, atol=1e-3) and torch.allclose(oa.root_value, ob.root_value, atol=1e-4)
 
 
 def test_refresh_repacks_into_the_same_buffers_and_leaves_the_module_alone():
