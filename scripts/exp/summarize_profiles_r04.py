@@ -99,7 +99,7 @@ def traffic():
         return
     with open(os.path.join(out, f"{tag}_pmc_net_forward.md"), "w") as f:
         f.write(f"# {tag} PMC passes of `net_forward_kernel` at the three launch shapes of bench.py\n\n"
-                f"One counter per pass with `--kernel-trace` only (HBM section of MI355X_MICROARCH.md), `scripts/prof_{tag}.sh`:\n\n"
+                f"One counter per pass with `--kernel-trace` only (HBM section of MI355X_MICROARCH.md), `scripts/exp/prof_{tag}.sh`:\n\n"
                 "    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -- python3 scripts/prof_net_once.py <model> <batch> <full|half>\n"
                 "    rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -- python3 scripts/prof_net_once.py <model> <batch> <full|half>\n\n"
                 "Launch = one network evaluation of the whole batch from 32-byte packed states (the search loop's shape), mean "
@@ -128,7 +128,7 @@ def sq():
     keys = sorted(set(k for c, _, _ in cols.values() for k in c))
     with open(os.path.join(out, f"{tag}_pmc_sq_net_forward.md"), "w") as g:
         g.write(f"# {tag}: SQ counters of the network kernel at the two production launch shapes\n\n"
-                f"`scripts/prof_{tag}.sh`: two `rocprofv3 --pmc ... --kernel-trace` passes (no other trace domain) per shape of "
+                f"`scripts/exp/prof_{tag}.sh`: two `rocprofv3 --pmc ... --kernel-trace` passes (no other trace domain) per shape of "
                 "`scripts/prof_net_once.py` (20 launches alone on the device; means per launch).\n\n"
                 "| counter | " + " | ".join(cols) + " |\n|---|" + "---:|" * len(cols) + "\n")
         for k in keys:
