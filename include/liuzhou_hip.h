@@ -439,7 +439,7 @@ typedef struct LzTreeDesc {
  * whose rows the network evaluates (device-counted batch) and lz_tree_wave_expand reads back through `eval_row`. */
 typedef struct LzTreeWaveDesc {
     int32_t  batch_k;              /* leaves per game and wave, 1..32 */
-    int32_t  path_cap;             /* entries per leaf path, > 48 (deeper descents are not followed) */
+    int32_t  path_cap;             /* entries per leaf path, > 160 (the level stack of a walk; a game lasts <= 144 plies) */
     int32_t* path;                 /* [batch_k][B][path_cap] */
     int32_t* path_len;             /* [batch_k][B] */
     int32_t* leaf_kind;            /* [batch_k][B] 0 inactive, 1 needs evaluation, 2 terminal */

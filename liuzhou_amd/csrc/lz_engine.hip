@@ -203,9 +203,10 @@ __global__ __launch_bounds__(kBlock) void tree_expand_select_kernel(Tree t, cons
 // restarting it: per level it remembers the (score, index) of the last child it consumed and picks the next one
 // in that order; a reserved / terminal / unexpanded child is a leaf, an expanded child is entered, a node without
 // candidates is left.  Leaves go to slot j of the [batch_k][B] slot-major arrays; the slots' leaf states are the next
-// network batch.  (The reference's safety limits -- 128 back-steps per walk, 8K walks per wave -- are not modelled;
-// descents deeper than kWaveDepth levels are not followed.)
-constexpr int kWaveDepth = 48;
+// network batch.  (Of the reference's safety limits the 128 back-steps per walk are modelled, see `ups` below; the 8K walks
+// per wave only end futile repetition.  kWaveDepth levels cover every descent: a game lasts at most 144 plies,
+// game_state.py:87-89 -- round 6; 48 before.)
+constexpr int kWaveDepth = 160;
 struct WaveArrays {
     int K, cap;
     int* path; int* path_len; int* leaf_kind; Packed* leaf_state; float* leaf_value; int* leaf_edge; int* leaf_parent;
@@ -320,7 +321,7 @@ __device__ __forceinline__ void tree_select_wave(const Tree& t, const WaveArrays
             if (terminal || c_child < 0) {                             // a leaf: slot `found`
                 const size_t slot = (size_t)found * t.B + g;
                 int* path = w.path + slot * w.cap;
-                if (lane < d) path[lane] = stack[lane + 1].in_edge;
+                for (int l = lane; l < d; l += kWave) path[l] = stack[l + 1].in_edge;
                 if (lane == 0) {
                     path[d] = entry;
                     w.path_len[slot] = d + 1;
@@ -336,7 +337,7 @@ __device__ __forceinline__ void tree_select_wave(const Tree& t, const WaveArrays
                 continue;
             }
             last_leaf = false;
-            if (d + 1 >= kWaveDepth) continue;                          // too deep: not followed
+            if (d + 1 >= kWaveDepth) continue;                          // deeper than a game can last: cannot happen
             if (lane == 0) {
                 Level here;
                 here.e0 = e0; here.ne_pl = ne | (node_player < 0 ? 0x100 : 0); here.parent_n = parent_n; here.node = node;

@@ -102,7 +102,10 @@ __device__ __forceinline__ void conv(f4 (&acc)[NT][NW], const float* __restrict_
 }
 
 // split-operand conv: main[i][j] += Wh*ah, cross[i][j] += Wh*al + Wl*ah (both low halves carry a factor 2^11); K blocks of 32
-// channels, weights = A operand of v_mfma_f32_16x16x32_f16 in the fp16 kernel's fragment order, fetched one step ahead
+// channels, weights = A operand of v_mfma_f32_16x16x32_f16 in the fp16 kernel's fragment order.  The weight fragments are
+// fetched TWO K steps ahead into three register sets used in rotation (the step loop is unrolled by three, so the rotation
+// is a renaming, not a copy that would wait for the load): with one wave per SIMD a K step is ~450 matrix cycles, an L2
+// round trip more than that -- one step ahead left half of every load's latency on the critical path.
 template <int C, int NT, int NW, int TAPS, int KDIM, int CTN>
 __device__ __forceinline__ void conv_x3(f4 (&main)[NT][NW], f4 (&cross)[NT][NW], const _Float16* __restrict__ wh,
                                         const _Float16* __restrict__ wl, int layer_off, int ct0, const _Float16* act,
@@ -111,18 +114,18 @@ __device__ __forceinline__ void conv_x3(f4 (&main)[NT][NW], f4 (&cross)[NT][NW],
     const int k4 = lane >> 4;
     const _Float16* whl = wh + layer_off + (size_t)ct0 * 512 + lane * 8;
     const _Float16* wll = wl + layer_off + (size_t)ct0 * 512 + lane * 8;
-    h8 ah[NW], al[NW], nh[NW], nl[NW];
-#pragma unroll
-    for (int j = 0; j < NW; ++j) { ah[j] = *reinterpret_cast<const h8*>(whl + j * 512); al[j] = *reinterpret_cast<const h8*>(wll + j * 512); }
-    for (int s = 0; s < STEPS; ++s) {
-        const int t = s / KB, kb = s - t * KB;
-        const int toff = TAPS == 9 ? ((t / 3) - 1) * 7 + (t % 3) - 1 : 0;
-        const int sn = s + 1 < STEPS ? s + 1 : s;               // the last step re-reads its own fragments (unused)
+    struct Frag { h8 h[NW], l[NW]; };
+    auto fetch = [&](Frag& f, int s) {
+        const int sn = s < STEPS ? s : STEPS - 1;               // past the end: re-read the last step's (unused)
 #pragma unroll
         for (int j = 0; j < NW; ++j) {
-            nh[j] = *reinterpret_cast<const h8*>(whl + ((size_t)sn * CTN + j) * 512);
-            nl[j] = *reinterpret_cast<const h8*>(wll + ((size_t)sn * CTN + j) * 512);
+            f.h[j] = *reinterpret_cast<const h8*>(whl + ((size_t)sn * CTN + j) * 512);
+            f.l[j] = *reinterpret_cast<const h8*>(wll + ((size_t)sn * CTN + j) * 512);
         }
+    };
+    auto step = [&](const Frag& a, int s) {
+        const int t = s / KB, kb = s - t * KB;
+        const int toff = TAPS == 9 ? ((t / 3) - 1) * 7 + (t % 3) - 1 : 0;
 #pragma unroll
         for (int i = 0; i < NT; ++i) {
             const _Float16* r = act + (row[i] + toff) * RS + kb * 32 + k4 * 8;
@@ -130,14 +133,23 @@ __device__ __forceinline__ void conv_x3(f4 (&main)[NT][NW], f4 (&cross)[NT][NW],
             const h8 bl = *reinterpret_cast<const h8*>(r + C);
 #pragma unroll
             for (int j = 0; j < NW; ++j) {
-                main[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[j], bh, main[i][j], 0, 0, 0);
-                cross[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[j], bl, cross[i][j], 0, 0, 0);
-                cross[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[j], bh, cross[i][j], 0, 0, 0);
+                main[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.h[j], bh, main[i][j], 0, 0, 0);
+                cross[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.h[j], bl, cross[i][j], 0, 0, 0);
+                cross[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.l[j], bh, cross[i][j], 0, 0, 0);
             }
         }
-#pragma unroll
-        for (int j = 0; j < NW; ++j) { ah[j] = nh[j]; al[j] = nl[j]; }
+    };
+    Frag a0, a1, a2;
+    fetch(a0, 0);
+    fetch(a1, 1);
+    int s = 0;
+    for (; s + 3 <= STEPS; s += 3) {
+        fetch(a2, s + 2); step(a0, s);
+        fetch(a0, s + 3); step(a1, s + 1);
+        fetch(a1, s + 4); step(a2, s + 2);
     }
+    if constexpr (STEPS % 3 >= 1) step(a0, s);
+    if constexpr (STEPS % 3 == 2) step(a1, s + 1);
 }
 
 // global pooling of a [cell][64] map -> pooled[s][192] = mean | max | sqrt(var + 1e-6)  (src/neural_network.py:67-80,

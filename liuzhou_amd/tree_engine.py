@@ -56,7 +56,7 @@ class LzTreeWaveDesc(C.Structure):
                [("max_backtrack_steps", C.c_int32), ("reserved_", C.c_int32)]
 
 
-WAVE_PATH_CAP = 64             # entries per leaf path of a wave (the kernel follows descents up to 48 levels)
+WAVE_PATH_CAP = 176            # entries per leaf path of a wave (the kernel's level stack holds 160: a game lasts <= 144 plies)
 EDGE_CHUNK = 1024              # edges per chunk of the engine's edge pool (32 KB); a run of <= 72 edges never straddles chunks
 # pool sizing: 3 x sims nodes of 32 edges per game.  Measured peak use (bench.py `reuse.edge_pool.peak_use_frac`, round 4):
 # 15 edges per simulation of the budget at C3 (16 384 x 800) and 17 at C2 -- a steady-state population is mostly in the

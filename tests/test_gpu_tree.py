@@ -599,6 +599,28 @@ def test_gpu_wave_batched_search_matches_oracle(batch_k, sims):
     assert waves >= 3 * -(-sims // batch_k)
 
 
+def test_gpu_wave_search_follows_descents_deeper_than_48_levels():
+    """A pseudo-network that puts nearly all prior mass on the first legal action and values every position 0 makes the
+    tree one long line: with 130 simulations from the empty board the walks go more than 100 levels deep (until round 5 the
+    wave kernel stopped following a descent at level 48; its level stack now covers the 144 plies a game can last).  Same
+    leaves in the same order as the oracle in every wave, bit-exact visit counts."""
+    _need_gpu()
+    from tests.tree_parity import run_injected_wave_parity, hash_evaluator
+
+    def line_evaluator(st):
+        pri, _ = hash_evaluator(st)
+        mask, _ = O.encode_actions(st)
+        first = np.argmax(mask, axis=1)
+        pri = (pri * np.float32(1e-3)).astype(np.float32)
+        pri[np.arange(pri.shape[0]), first] = np.float32(1.0)
+        return pri, np.zeros(pri.shape[0], np.float32)
+
+    eng, waves, short = run_injected_wave_parity("cuda:0", sims=130, batch_k=4, moves=1, seed=2, with_noise=False,
+                                                 states=O.initial_states(6), evaluator=line_evaluator)
+    depth = int(eng.wbuf["path_len"].max().item())
+    assert depth > 48, depth                                   # the last wave's deepest leaf path
+
+
 @pytest.mark.parametrize("limit", [3, 9])
 def test_gpu_wave_walks_give_up_after_the_references_backtrack_limit(limit):
     """src/mcts.py:337,371-414: a walk gives up after MAX_BACKTRACK_STEPS (128) upward moves, and since every walk of a wave

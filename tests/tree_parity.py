@@ -230,7 +230,7 @@ def run_injected_reuse_parity(device, num_games=48, sims=48, moves=4, seed=3, c=
 
 
 def run_injected_wave_parity(device, num_games=48, sims=50, batch_k=16, moves=3, seed=5, c=1.0, with_noise=True, eps=0.25,
-                             reuse_factor=4.0, states=None, max_backtrack=None):
+                             reuse_factor=4.0, states=None, max_backtrack=None, evaluator=None):
     """The legacy search's waves (src/mcts.py batch_K, oracle: lzo_tree_select_wave / complete_wave, pinned by g13) on
     the GPU engine: `moves` consecutive searches with subtree reuse, both sides driven by `hash_evaluator`.  Every wave
     must collect the same leaves in the same order (the leaf states are compared), and after every search the root
@@ -239,6 +239,7 @@ def run_injected_wave_parity(device, num_games=48, sims=50, batch_k=16, moves=3,
     from oracle.selfplay_oracle import deterministic_pick
     from tests.golden_utils import load, states as gstates
     rng = np.random.default_rng(seed)
+    evaluate = evaluator or hash_evaluator
     if states is None:
         z = load("g1_rules.npz")
         st_all = gstates(z, "s")
@@ -262,7 +263,7 @@ def run_injected_wave_parity(device, num_games=48, sims=50, batch_k=16, moves=3,
         leaf = unpack_packed(eng.buf["leaf_state"].cpu().numpy())
         pend = [t.prepare_root() for t in trees]
         assert np.array_equal(kind == 1, np.array(pend)), f"move {mv}: fresh / kept roots differ"
-        pri, val = hash_evaluator(leaf)
+        pri, val = evaluate(leaf)
         for i, t in enumerate(trees):
             if pend[i]:
                 t.complete(pri[i], float(val[i]), None if noise is None else noise[i], eps)
@@ -277,7 +278,7 @@ def run_injected_wave_parity(device, num_games=48, sims=50, batch_k=16, moves=3,
             first = False
             kinds = eng.wbuf["leaf_kind"].cpu().numpy().reshape(K, B)
             slots = unpack_packed(eng.wbuf["leaf_state"].cpu().numpy())            # [K*B] slot-major
-            pri, val = hash_evaluator(slots)
+            pri, val = evaluate(slots)
             progressed = False
             for i, t in enumerate(trees):
                 if done[i] >= sims or t.root_terminal():
