@@ -186,14 +186,60 @@ __global__ __launch_bounds__(kBlock) void tree_expand_select_kernel(Tree t, cons
     const unsigned long long lz_t0 = __builtin_readcyclecounter();
 #endif
     tree_expand<IS_ROOT>(t, g, lane, lp1 + o * 36, lp2 + o * 36, lpm + o * 36, nullptr, values + o, noise, noise_stride,
-                         epsilon, sc, &root, step LZ_TSTAMP_PASS);
+                         epsilon, sc, &root, step, nullptr, nullptr LZ_TSTAMP_PASS);
     __threadfence_block();
     if (IS_ROOT) root = load_root_info(t, g);                  // the root record itself was just written
     LZ_TSTAMP(g, 7)                                            // fence (+ root reload)
-    tree_select(t, g, lane, root LZ_TSTAMP_PASS);
+    tree_select(t, g, lane, root, -1, -1, nullptr LZ_TSTAMP_PASS);
 #ifdef LZ_EXP_TREE_STAMPS
     LZ_TADD(g, 19, 1)
 #endif
+}
+
+// The same step on TWO waves per game (round 6).  One wave's step is a chain of ~32 k cycles at the C2 launch shape (2 048
+// games: two waves per SIMD, the kernel's duration IS that chain -- profiles/r05_pmc_sq_tree.md): 14 k of expansion, 2 k
+// of backup, 16 k of descent.  The descent of simulation s + 1 does not depend on the expansion of simulation s except
+// for ONE edge (the one the new node hangs on), so the game's first wave expands while its second backs up and descends;
+// the critical path is the longer of the two (~20 k).  Hand-offs through an LDS word per game (tree_select, split_wait):
+//   first wave : inputs in registers -> flag = 1;  node + edges written, release -> flag = 2
+//   second wave: backup, fence, wait for 1 (it will overwrite the leaf record), descent (waits for 2 only if it reaches
+//                the edge being expanded)
+// Same stores in the same per-address order as the one-wave step: bit-identical trees (every tree parity test runs through
+// this kernel; LZ_TREE_SPLIT=0 takes the one-wave kernel, tests/test_gpu_tree.py compares the two).  Used for launches of
+// at most kSplitMaxGames games: at 16 384 games the SIMDs are issue-bound and twice the waves buy nothing.
+constexpr int kSplitMaxGames = 8192;
+template <bool COMPACT>
+__global__ __launch_bounds__(kBlock) void tree_expand_select_split_kernel(Tree t, const float* __restrict__ lp1,
+                                                                          const float* __restrict__ lp2,
+                                                                          const float* __restrict__ lpm,
+                                                                          const float* __restrict__ values, int step) {
+    __builtin_amdgcn_s_setprio(3);
+    LZ_EXPAND_SCRATCH(sc);
+    __shared__ int s_flag[kWavesPerBlock / 2];
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int pair = wv >> 1, role = wv & 1;                      // role 0: expansion, role 1: backup + descent
+    const int g = blockIdx.x * (kWavesPerBlock / 2) + pair;
+    const int lane = lane_id();
+    if (role == 0 && lane == 0) s_flag[pair] = 0;
+    __syncthreads();                                               // the only workgroup barrier: before any early exit
+    if (g >= t.B) return;
+    volatile int* flag = &s_flag[pair];
+    ptrdiff_t o = 0;
+    if (COMPACT) o = (ptrdiff_t)(t.leaf_kind[g] == kLeafExpand ? t.live_row[g] : 0) - g;
+    if (role == 0) {
+        tree_expand<false, 1>(t, g, lane, lp1 + o * 36, lp2 + o * 36, lpm + o * 36, nullptr, values + o, nullptr, 0, 0.f, sc,
+                              nullptr, step, flag);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     // node, edges, the parent edge's child fields
+        if (lane == 0) *flag = kSplitExpanded;
+    } else {
+        RootInfo root;
+        SplitInfo split;
+        tree_expand<false, 2>(t, g, lane, lp1 + o * 36, lp2 + o * 36, lpm + o * 36, nullptr, values + o, nullptr, 0, 0.f, sc,
+                              &root, step, flag, &split);
+        __threadfence_block();
+        split_wait(flag, kSplitInputsRead);                        // the descent's end overwrites the leaf record
+        tree_select(t, g, lane, root, split.wait_edge, split.nolegal_edge, flag);
+    }
 }
 
 // ---- wave-batched leaves: the legacy search of src/mcts.py (batch_K leaves per tree and wave, no virtual loss) ------
@@ -1136,6 +1182,12 @@ bool wave_ok(const LzTreeWaveDesc* w) {
            w->unfinished && w->eval_row && w->eval_state && w->eval_count && w->eval_total;
 }
 inline unsigned gw(int64_t n) { return (unsigned)((n + kWavesPerBlock - 1) / kWavesPerBlock); }
+inline unsigned gw2(int64_t n) { return (unsigned)((n + kWavesPerBlock / 2 - 1) / (kWavesPerBlock / 2)); }   // two waves per game
+// the split step (two waves per game) for launches that leave the SIMDs room for twice the waves; LZ_TREE_SPLIT=0: never
+inline bool split_step(int64_t games) {
+    const char* e = getenv("LZ_TREE_SPLIT");                   // read per call: the choice is frozen into a captured graph
+    return !(e && e[0] == '0') && games <= kSplitMaxGames;
+}
 inline unsigned gt(int64_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
 
 }  // namespace
@@ -1270,8 +1322,12 @@ static int tree_search_impl(const LzTreeDesc* d, const LzNetDesc* net, int64_t s
                                    t, lp1, lp2, lpmc, values, noise, (int)noise_stride, epsilon, (int)s);
             } else {
                 (void)lz_prof_aux_begin(0, stream);
-                hipLaunchKernelGGL((tree_expand_select_kernel<false, true>), dim3(gw(t.B)), dim3(kBlock), 0, as_stream(stream),
-                                   t, lp1, lp2, lpmc, values, nullptr, 0, 0.f, (int)s);
+                if (split_step(t.B))
+                    hipLaunchKernelGGL((tree_expand_select_split_kernel<true>), dim3(gw2(t.B)), dim3(kBlock), 0,
+                                       as_stream(stream), t, lp1, lp2, lpmc, values, (int)s);
+                else
+                    hipLaunchKernelGGL((tree_expand_select_kernel<false, true>), dim3(gw(t.B)), dim3(kBlock), 0, as_stream(stream),
+                                       t, lp1, lp2, lpmc, values, nullptr, 0, 0.f, (int)s);
                 (void)lz_prof_aux_end(0, stream, B);
             }
             if (s < sims)                                           // the leaves of simulation s + 1
@@ -1295,8 +1351,12 @@ static int tree_search_impl(const LzTreeDesc* d, const LzNetDesc* net, int64_t s
                                lp2, lpmc, values, noise, (int)noise_stride, epsilon, (int)s);
         } else {
             (void)lz_prof_aux_begin(0, stream);                      // no-ops unless lz_prof_enable(1) (never in a capture)
-            hipLaunchKernelGGL(tree_expand_select_kernel<false>, dim3(gw(t.B)), dim3(kBlock), 0, as_stream(stream), t, lp1,
-                               lp2, lpmc, values, nullptr, 0, 0.f, (int)s);
+            if (split_step(t.B))
+                hipLaunchKernelGGL((tree_expand_select_split_kernel<false>), dim3(gw2(t.B)), dim3(kBlock), 0, as_stream(stream),
+                                   t, lp1, lp2, lpmc, values, (int)s);
+            else
+                hipLaunchKernelGGL(tree_expand_select_kernel<false>, dim3(gw(t.B)), dim3(kBlock), 0, as_stream(stream), t, lp1,
+                                   lp2, lpmc, values, nullptr, 0, 0.f, (int)s);
             (void)lz_prof_aux_end(0, stream, B);
         }
     }

@@ -221,7 +221,19 @@ __device__ __forceinline__ RootInfo load_root_info(const Tree& t, int g) {
     return r;
 }
 
-__device__ __forceinline__ void tree_select(const Tree& t, int g, int lane, const RootInfo& root LZ_TSTAMP_ARG) {
+// Split step (tree_expand_select_split_kernel): the descent runs on the game's SECOND wave while the first one still
+// expands the previous simulation's leaf.  Nothing the descent reads depends on that expansion except the child fields of
+// ONE edge (`wait_edge`: the edge the new node hangs on) -- reaching it, the descent waits for the partner's flag (LDS,
+// workgroup-scope release / acquire: both waves share the CU's L1) and re-reads the record; `nolegal_edge`: the previous
+// leaf turned out to have no legal move, which the partner records as a terminal flag on that edge (value -1).
+constexpr int kSplitInputsRead = 1, kSplitExpanded = 2;
+__device__ __forceinline__ void split_wait(volatile int* flag, int phase) {
+    while (*flag < phase) __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+__device__ __forceinline__ void tree_select(const Tree& t, int g, int lane, const RootInfo& root, int wait_edge = -1,
+                                            int nolegal_edge = -1, volatile int* flag = nullptr LZ_TSTAMP_ARG) {
     if (t.root_terminal[g]) { if (lane == 0) t.leaf_kind[g] = kLeafInactive; return; }
     const Node* nodes = t.nodes + (size_t)g * t.node_cap;
     const Edge* edges = t.edges;                               // pool indices
@@ -279,10 +291,17 @@ __device__ __forceinline__ void tree_select(const Tree& t, int g, int lane, cons
         const int src = chosen & 63;
         const bool up = chosen >= kWave;
         const uint32_t c_ni = (uint32_t)lzw::lane_bcast((int)(up ? mine[1].n_info : mine[0].n_info), src);
-        const int c_child = lzw::lane_bcast(up ? mine[1].child : mine[0].child, src);
-        const int c_begin = lzw::lane_bcast(up ? mine[1].cbegin : mine[0].cbegin, src);
-        const int c_meta = lzw::lane_bcast((int)(up ? mine[1].act : mine[0].act) | ((int)(up ? mine[1].cn : mine[0].cn) << 8), src);
-        const uint8_t info = edge_info(c_ni);
+        int c_child = lzw::lane_bcast(up ? mine[1].child : mine[0].child, src);
+        int c_begin = lzw::lane_bcast(up ? mine[1].cbegin : mine[0].cbegin, src);
+        int c_meta = lzw::lane_bcast((int)(up ? mine[1].act : mine[0].act) | ((int)(up ? mine[1].cn : mine[0].cn) << 8), src);
+        uint8_t info = edge_info(c_ni);
+        if (e0 + chosen == wait_edge) {                        // the partner wave is hanging a node on this edge right now
+            split_wait(flag, kSplitExpanded);
+            const Edge fresh = load_edge(&run[chosen]);
+            c_child = fresh.child; c_begin = fresh.cbegin;
+            c_meta = (int)fresh.act | ((int)fresh.cn << 8);
+        }
+        if (e0 + chosen == nolegal_edge) info |= kInfoTerminal;   // value bits 0 = -1 (tree_expand, n == 0)
         const int child_player = (info & kInfoWhite) ? -1 : 1;
 #ifdef LZ_EXP_TREE_STAMPS
         { LZ_TCLOCK(g, lv_t2) LZ_TADD(g, 17, lv_t2 - lv_t0) LZ_TADD(g, 18, 1) }                                        // scores, maximum, broadcast
@@ -338,12 +357,18 @@ constexpr int kExpandScratchBytes = 80 * 8;
 // counters, the path, the root's statistics); the backup is fire-and-forget device atomics (N += 1 on the count
 // field, W += v in double -- one addition per edge and simulation, so bit-identical to a read-modify-write), the
 // signs come from the flip bits select left in the path entries.  Dependent round trips: 1 (was 5).
-template <bool IS_ROOT>
+// ROLE 0: the whole step on one wave.  Split step (two waves per game): ROLE 1 = the expansion only (signals `flag`: its inputs
+// are in registers / its node and edges are written), ROLE 2 = the backup only (+ what the descent must know about the
+// leaf, `split`: the edge a node is being hung on, or the edge of a leaf without a legal move).
+struct SplitInfo { int wait_edge, nolegal_edge; };
+template <bool IS_ROOT, int ROLE = 0>
 __device__ __forceinline__ void tree_expand(const Tree& t, int g, int lane, const float* __restrict__ lp1,
                                             const float* __restrict__ lp2, const float* __restrict__ lpm,
                                             const float* __restrict__ priors220, const float* __restrict__ values,
                                             const float* __restrict__ noise, int noise_stride, float epsilon,
-                                            ExpandScratch sc, RootInfo* root_after = nullptr, int step = -1 LZ_TSTAMP_ARG) {
+                                            ExpandScratch sc, RootInfo* root_after = nullptr, int step = -1,
+                                            volatile int* flag = nullptr, SplitInfo* split = nullptr LZ_TSTAMP_ARG) {
+    static_assert(ROLE == 0 || !IS_ROOT, "the root step is never split");
     LZ_TSTAMP(g, 0)
     const int kind = t.leaf_kind[g];
     Node* nodes = t.nodes + (size_t)g * t.node_cap;
@@ -368,9 +393,14 @@ __device__ __forceinline__ void tree_expand(const Tree& t, int g, int lane, cons
     ne_ld = t.n_edges[g];
     value_ld = values[g];
     if (root_after != nullptr) *root_after = root;
+    if (ROLE == 1) {                                           // the partner may now overwrite the leaf record (next leaf)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) *flag = kSplitInputsRead;
+    }
+    if (ROLE == 2) { split->wait_edge = -1; split->nolegal_edge = -1; }
     LZ_TSTAMP(g, 1)                                            // the independent loads have arrived
     // trace slot of this step (parity tests only; wave-uniform)
-    const bool tracing = t.trace_kind != nullptr && step >= 0 && step < t.trace_cap;
+    const bool tracing = ROLE != 2 && t.trace_kind != nullptr && step >= 0 && step < t.trace_cap;
     const size_t tslot = tracing ? (size_t)step * (size_t)t.B + (size_t)g : 0;
     if (tracing) {
         if (lane == 0) { t.trace_kind[tslot] = kind; t.trace_leaf[tslot] = leaf_packed; t.trace_value[tslot] = value_ld; }
@@ -415,11 +445,14 @@ __device__ __forceinline__ void tree_expand(const Tree& t, int g, int lane, cons
     if (kind == kLeafTerminal) {
         backup_value = (double)leaf_value_ld;
     } else {
-        if (t.eval_count != nullptr && lane == 0) t.eval_count[g] += 1;     // this game's wave is the only writer
+        if (ROLE != 2 && t.eval_count != nullptr && lane == 0) t.eval_count[g] += 1;     // this game's wave is the only writer
         const State s = unpack(leaf_packed);
         const Legal L = legal_actions(s, /*fallback_forced=*/0);     // python semantics (move_generator.py:24-70)
         const int n = legal_count(L);
-        if (n == 0) {
+        if (ROLE == 2) {                                       // the partner wave expands; this one only needs the value
+            backup_value = n == 0 ? -1.0 : (double)value_ld;
+            if (n == 0) split->nolegal_edge = leaf_edge; else split->wait_edge = leaf_edge;
+        } else if (n == 0) {
             // portable_mcts.py:433-441: no legal move on a non-finished state => terminal, value -1
             backup_value = -1.0;
             if (lane == 0) {
@@ -572,7 +605,7 @@ __device__ __forceinline__ void tree_expand(const Tree& t, int g, int lane, cons
             LZ_TSTAMP(g, 5)                                    // child states, terminal tests, edge records
         }
     }
-    if (IS_ROOT) return;
+    if (IS_ROOT || ROLE == 1) return;
     // ---- backup along the path (portable_mcts.py:123-138), one lane per path entry ----
     // value added at offset j = v0 * (-1)^(#mover changes at offsets > j); the root gets the fully flipped value.
     if (plen > 0) {

@@ -601,8 +601,9 @@ def test_gpu_wave_batched_search_matches_oracle(batch_k, sims):
 
 def test_gpu_wave_search_follows_descents_deeper_than_48_levels():
     """A pseudo-network that puts nearly all prior mass on the first legal action and values every position 0 makes the
-    tree one long line: with 130 simulations from the empty board the walks go more than 100 levels deep (until round 5 the
-    wave kernel stopped following a descent at level 48; its level stack now covers the 144 plies a game can last).  Same
+    tree one long line that grows by one level per wave: with 320 simulations in waves of 4 from the empty board the walks go
+    about 80 levels deep (until round 5 the wave kernel stopped following a descent at level 48; its level stack now covers
+    the 144 plies a game can last).  Same
     leaves in the same order as the oracle in every wave, bit-exact visit counts."""
     _need_gpu()
     from tests.tree_parity import run_injected_wave_parity, hash_evaluator
@@ -615,8 +616,8 @@ def test_gpu_wave_search_follows_descents_deeper_than_48_levels():
         pri[np.arange(pri.shape[0]), first] = np.float32(1.0)
         return pri, np.zeros(pri.shape[0], np.float32)
 
-    eng, waves, short = run_injected_wave_parity("cuda:0", sims=130, batch_k=4, moves=1, seed=2, with_noise=False,
-                                                 states=O.initial_states(6), evaluator=line_evaluator)
+    eng, waves, short = run_injected_wave_parity("cuda:0", sims=320, batch_k=4, moves=1, seed=2, with_noise=False,
+                                                 states=O.initial_states(4), evaluator=line_evaluator)
     depth = int(eng.wbuf["path_len"].max().item())
     assert depth > 48, depth                                   # the last wave's deepest leaf path
 
@@ -826,6 +827,24 @@ def test_production_search_direct_launches_equal_graph_replay():
     b, _ = run_production_parity(DEV, "b6c64", num_games=48, sims=64, moves=2, seed=23, use_graph=False)
     for x, y in zip(root_edges(a.engine), root_edges(b.engine)):
         assert all(x[f].tobytes() == y[f].tobytes() for f in EDGE_LOGICAL) and ((x["child"] >= 0) == (y["child"] >= 0)).all()
+
+
+@pytest.mark.parametrize("model,compact", [("b6c64", False), ("b10c128", True)])
+def test_split_step_on_two_waves_builds_the_same_trees_as_the_one_wave_step(monkeypatch, model, compact):
+    """Round 6: launches of at most 8 192 games run the simulation step on TWO waves per game (the first expands the previous
+    leaf while the second backs up and descends; csrc/lz_engine.hip::tree_expand_select_split_kernel).  Both forms replay
+    against the oracle (run_production_parity compares every simulation's leaf) and end with byte-identical root records;
+    also with the compact evaluation lists, over consecutive moves with kept subtrees."""
+    _need_gpu()
+    from tests.tree_parity import run_production_parity, root_edges, EDGE_LOGICAL
+    kw = dict(num_games=96, sims=72, moves=3, seed=31, compact_evals=compact)
+    monkeypatch.setenv("LZ_TREE_SPLIT", "1")
+    a, _ = run_production_parity(DEV, model, **kw)
+    monkeypatch.setenv("LZ_TREE_SPLIT", "0")
+    b, _ = run_production_parity(DEV, model, **kw)
+    for x, y in zip(root_edges(a.engine), root_edges(b.engine)):
+        assert all(x[f].tobytes() == y[f].tobytes() for f in EDGE_LOGICAL) and ((x["child"] >= 0) == (y["child"] >= 0)).all()
+    assert torch.equal(a.engine.buf["n_nodes"], b.engine.buf["n_nodes"]) and torch.equal(a.engine.buf["root_w"], b.engine.buf["root_w"])
 
 
 def test_graph_capture_failure_falls_back_to_direct_launches(monkeypatch):
