@@ -105,7 +105,9 @@ __device__ __forceinline__ void conv(f4 (&acc)[NT][NW], const float* __restrict_
 // channels, weights = A operand of v_mfma_f32_16x16x32_f16 in the fp16 kernel's fragment order.  The weight fragments are
 // fetched TWO K steps ahead into three register sets used in rotation (the step loop is unrolled by three, so the rotation
 // is a renaming, not a copy that would wait for the load): with one wave per SIMD a K step is ~450 matrix cycles, an L2
-// round trip more than that -- one step ahead left half of every load's latency on the critical path.
+// round trip more than that -- one step ahead left half of every load's latency on the critical path.  Measured
+// (profiles/r06_experiments.md section 5): 10x128 0.80 -> 1.26 M evaluations/s; 6x64 6.20 -> 5.96 M, so the 64-channel
+// kernel (9 cell tiles per fragment: a K step is already longer than the load) keeps ONE step ahead (`AHEAD`).
 template <int C, int NT, int NW, int TAPS, int KDIM, int CTN>
 __device__ __forceinline__ void conv_x3(f4 (&main)[NT][NW], f4 (&cross)[NT][NW], const _Float16* __restrict__ wh,
                                         const _Float16* __restrict__ wl, int layer_off, int ct0, const _Float16* act,
@@ -139,17 +141,29 @@ __device__ __forceinline__ void conv_x3(f4 (&main)[NT][NW], f4 (&cross)[NT][NW],
             }
         }
     };
-    Frag a0, a1, a2;
-    fetch(a0, 0);
-    fetch(a1, 1);
-    int s = 0;
-    for (; s + 3 <= STEPS; s += 3) {
-        fetch(a2, s + 2); step(a0, s);
-        fetch(a0, s + 3); step(a1, s + 1);
-        fetch(a1, s + 4); step(a2, s + 2);
+    constexpr int AHEAD = C == 128 ? 2 : 1;
+    if constexpr (AHEAD == 2) {
+        Frag a0, a1, a2;
+        fetch(a0, 0);
+        fetch(a1, 1);
+        int s = 0;
+        for (; s + 3 <= STEPS; s += 3) {
+            fetch(a2, s + 2); step(a0, s);
+            fetch(a0, s + 3); step(a1, s + 1);
+            fetch(a1, s + 4); step(a2, s + 2);
+        }
+        if constexpr (STEPS % 3 >= 1) step(a0, s);
+        if constexpr (STEPS % 3 == 2) step(a1, s + 1);
+    } else {
+        Frag a0, a1;
+        fetch(a0, 0);
+        int s = 0;
+        for (; s + 2 <= STEPS; s += 2) {
+            fetch(a1, s + 1); step(a0, s);
+            fetch(a0, s + 2); step(a1, s + 1);
+        }
+        if constexpr (STEPS % 2 == 1) step(a0, s);
     }
-    if constexpr (STEPS % 3 >= 1) step(a0, s);
-    if constexpr (STEPS % 3 == 2) step(a1, s + 1);
 }
 
 // global pooling of a [cell][64] map -> pooled[s][192] = mean | max | sqrt(var + 1e-6)  (src/neural_network.py:67-80,
