@@ -58,25 +58,28 @@ def _overlap(dev: torch.device, s1: torch.cuda.Stream, s2: torch.cuda.Stream) ->
 
 
 def stream_pair_mode() -> str:
-    """LZ_STREAM_PAIR: "priority" (default since round 6) = the k streams get DISTINCT priorities (-1, 0[, 1]), which the
-    runtime serves from distinct hardware-queue pools -- the mapping is then a property of how the streams were created,
-    not of what else the process has alive: controlled instead of probed-and-watched.  Same-box A/B inside bench.py at C2
-    (profiles/r06_experiments.md): 196.4 / 196.6 k positions/s against 196.8 / 196.3 k for a probed equal-priority pair,
-    0 re-draws either way -- the asymmetry costs nothing (each half is one serial chain of kernels; the priority only
-    decides who goes first when both have a kernel ready).  "probe" = equal priorities, probed (rounds 5's default).
-    The pair is still probed once when it is created and watched by DualStreamTreeMCTS, as a safety net."""
-    return os.environ.get("LZ_STREAM_PAIR", "priority").strip().lower()
+    """LZ_STREAM_PAIR: "probe" (default) = an equal-priority pair, probed when drawn; "priority" (round 6) = the k streams
+    get DISTINCT priorities (-1, 0[, 1]), which the runtime serves from distinct hardware-queue pools -- the mapping is then
+    a property of how the streams were created, not of what else the process has alive.  Same-box A/B inside bench.py at C2
+    (profiles/r06_experiments.md section 2): 196.4 / 196.6 k positions/s against 196.8 / 196.3 k for the probed pair, 0
+    re-draws either way; 8 isolated runner runs of either kind at 20.4 - 20.5 ms per ply.  But ONE default bench invocation
+    with the priority pair ran its whole C2 runner leg at 31.9 ms per ply (the serialised figure) without the overlap watch
+    noticing: distinct queues do not stop one chain from starving the other, and a starved half NESTS in the other's
+    interval instead of following it.  So the symmetric pair stays the default, the watch (DualStreamTreeMCTS) now flags
+    nested halves too, and a pair that fails is replaced by a pair of the other kind."""
+    return os.environ.get("LZ_STREAM_PAIR", "probe").strip().lower()
 
 
-def overlapping_streams(device, k: int = 2, max_tries: int = 12) -> Tuple[torch.cuda.Stream, ...]:
+def overlapping_streams(device, k: int = 2, max_tries: int = 12, mode: str = None) -> Tuple[torch.cuda.Stream, ...]:
     """`k` streams on `device` whose kernels overlap pairwise (see the module docstring).  Falls back to the last
-    candidates after `max_tries` collisions (results never depend on the overlap, only the speed does)."""
+    candidates after `max_tries` collisions (results never depend on the overlap, only the speed does).
+    `mode`: "priority" / "probe" (default: `stream_pair_mode()`)."""
     dev = torch.device(device)
     chosen: List[torch.cuda.Stream] = []
     rejected: List[torch.cuda.Stream] = []
     with torch.cuda.device(dev):
         _spin_cycles(dev)
-        if stream_pair_mode() == "priority" and int(k) <= 3:
+        if (mode or stream_pair_mode()) == "priority" and int(k) <= 3:
             # priorities on this runtime: -1 (high), 0 (normal), 1 (low) where the range allows; k = 2 -> (high, normal)
             prios = [-1, 0, 1][: int(k)]
             cand = [torch.cuda.Stream(dev, priority=p) for p in prios]

@@ -862,6 +862,7 @@ class DualStreamTreeMCTS:
         self.device = dev
         from .streams import overlapping_streams
         self.streams = overlapping_streams(dev, k)              # probed: two new streams CAN share a hardware queue
+        self._pair_mode = overlapping_streams.last_mode
         self.parts = []
         base = model if isinstance(model, FusedNet) else FusedNet(model, dev)
         kw.pop("game_offset", None); kw.pop("game_stride", None)
@@ -930,13 +931,21 @@ class DualStreamTreeMCTS:
             d0, d1 = s0.elapsed_time(e0), s1.elapsed_time(e1)
             lead = s0.elapsed_time(s1)                           # start of part 1 relative to part 0 (ms, may be < 0)
             union = max(d0, lead + d1) - min(0.0, lead)
-            if d0 > 1.0 and d1 > 1.0 and union > 0.9 * (d0 + d1):
+            # Two signatures of halves that do not share the chip: (a) one after the other on one hardware queue -- disjoint
+            # intervals, union ~ sum; (b) one half STARVED by the other -- nested intervals: both start together, one
+            # finishes in about half the time of the other (seen once in round 6 with a (-1, 0) priority pair: the whole
+            # runner leg at 31.9 ms per ply, which test (a) alone did not flag).  Halves that overlap properly take about the
+            # same time: they are equal work on equal shares of the chip.
+            serial = union > 0.9 * (d0 + d1) or min(d0, d1) < 0.7 * max(d0, d1)
+            if d0 > 1.0 and d1 > 1.0 and serial:
                 self._serial_seen += 1
                 self._watch_left = max(self._watch_left, 2)
                 if self._serial_seen >= 2 and self.stream_redraws < 6:
                     from .streams import overlapping_streams
                     self._old_streams = getattr(self, "_old_streams", []) + list(self.streams)   # keep them: work may be queued
-                    self.streams = overlapping_streams(self.device, len(self.parts))
+                    # a pair that failed is replaced by a pair of the OTHER kind (distinct priorities <-> equal, probed)
+                    self._pair_mode = "probe" if getattr(self, "_pair_mode", overlapping_streams.last_mode) == "priority" else "priority"
+                    self.streams = overlapping_streams(self.device, len(self.parts), mode=self._pair_mode)
                     self.stream_redraws += 1
                     self._serial_seen = 0
                     self._watch_left = 4

@@ -225,3 +225,48 @@ def test_every_script_compiles():
     assert len(files) > 40
     for f in files:
         compile(open(f).read(), f, "exec")                       # syntax only: nothing is written, nothing is run
+
+
+def test_overlap_watch_flags_disjoint_and_nested_halves(monkeypatch):
+    """DualStreamTreeMCTS._check_overlap on recorded (start, end) brackets of the two halves: halves that share the chip
+    take about the same time; one after the other (one hardware queue) and one nested in the other (one chain starved by the
+    other -- seen once in round 6, unnoticed by the union test alone) both count as serial, two in a row replace the pair by
+    a pair of the other kind."""
+    from liuzhou_amd import streams as S
+    from liuzhou_amd.tree_engine import DualStreamTreeMCTS
+
+    class Ev:
+        def __init__(self, t): self.t = t
+        def query(self): return True
+        def elapsed_time(self, other): return other.t - self.t
+
+    drawn = []
+    def fake_streams(device, k=2, max_tries=12, mode=None):
+        drawn.append(mode)
+        return (object(), object())
+    fake_streams.last_mode = "probe"
+    monkeypatch.setattr(S, "overlapping_streams", fake_streams)
+
+    def engine():
+        d = DualStreamTreeMCTS.__new__(DualStreamTreeMCTS)
+        d._watch, d._watch_left, d._searches, d._serial_seen, d.stream_redraws = [], 6, 0, 0, 0
+        d.parts, d.device, d.streams, d._pair_mode = [None, None], "cuda:0", ("a", "b"), "probe"
+        return d
+
+    def feed(d, s0, e0, s1, e1):
+        d._watch.append([Ev(s0), Ev(e0), Ev(s1), Ev(e1)])
+        d._check_overlap()
+
+    d = engine()
+    for _ in range(4):
+        feed(d, 0.0, 20.0, 0.2, 20.5)                     # healthy: both halves ~20 ms, side by side
+    assert d.stream_redraws == 0 and d._serial_seen == 0
+    feed(d, 0.0, 15.4, 15.5, 31.0); feed(d, 0.0, 15.4, 15.5, 31.0)      # one after the other
+    assert d.stream_redraws == 1 and drawn == ["priority"] and d._pair_mode == "priority"
+    d = engine()
+    feed(d, 0.0, 15.4, 0.1, 31.0)                          # nested: the second half starved until the first is done
+    assert d._serial_seen == 1 and d.stream_redraws == 0
+    feed(d, 0.0, 20.0, 0.1, 20.3)                          # a healthy search in between resets the count
+    assert d._serial_seen == 0
+    feed(d, 0.0, 15.4, 0.1, 31.0); feed(d, 0.0, 15.0, 0.1, 30.0)
+    assert d.stream_redraws == 1 and d._pair_mode == "priority"
