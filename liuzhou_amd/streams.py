@@ -66,7 +66,7 @@ def stream_pair_mode() -> str:
     with the priority pair ran its whole C2 runner leg at 31.9 ms per ply (the serialised figure) without the overlap watch
     noticing: distinct queues do not stop one chain from starving the other, and a starved half NESTS in the other's
     interval instead of following it.  So the symmetric pair stays the default, the watch (DualStreamTreeMCTS) now flags
-    nested halves too, and a pair that fails is replaced by a pair of the other kind."""
+    nested halves too, and a pair that fails is replaced by a freshly probed equal-priority pair."""
     return os.environ.get("LZ_STREAM_PAIR", "probe").strip().lower()
 
 

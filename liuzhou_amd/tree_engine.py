@@ -936,15 +936,16 @@ class DualStreamTreeMCTS:
             # finishes in about half the time of the other (seen once in round 6 with a (-1, 0) priority pair: the whole
             # runner leg at 31.9 ms per ply, which test (a) alone did not flag).  Halves that overlap properly take about the
             # same time: they are equal work on equal shares of the chip.
-            serial = union > 0.9 * (d0 + d1) or min(d0, d1) < 0.7 * max(d0, d1)
+            serial = union > 0.9 * (d0 + d1) or min(d0, d1) < 0.62 * max(d0, d1)
             if d0 > 1.0 and d1 > 1.0 and serial:
                 self._serial_seen += 1
                 self._watch_left = max(self._watch_left, 2)
                 if self._serial_seen >= 2 and self.stream_redraws < 6:
                     from .streams import overlapping_streams
                     self._old_streams = getattr(self, "_old_streams", []) + list(self.streams)   # keep them: work may be queued
-                    # a pair that failed is replaced by a pair of the OTHER kind (distinct priorities <-> equal, probed)
-                    self._pair_mode = "probe" if getattr(self, "_pair_mode", overlapping_streams.last_mode) == "priority" else "priority"
+                    # a priority pair that failed is replaced by an equal-priority, probed pair (the kind that has never been
+                    # seen to starve a half); an equal-priority pair by another one
+                    self._pair_mode = "probe"
                     self.streams = overlapping_streams(self.device, len(self.parts), mode=self._pair_mode)
                     self.stream_redraws += 1
                     self._serial_seen = 0

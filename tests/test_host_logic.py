@@ -231,7 +231,7 @@ def test_overlap_watch_flags_disjoint_and_nested_halves(monkeypatch):
     """DualStreamTreeMCTS._check_overlap on recorded (start, end) brackets of the two halves: halves that share the chip
     take about the same time; one after the other (one hardware queue) and one nested in the other (one chain starved by the
     other -- seen once in round 6, unnoticed by the union test alone) both count as serial, two in a row replace the pair by
-    a pair of the other kind."""
+    an equal-priority, probed pair."""
     from liuzhou_amd import streams as S
     from liuzhou_amd.tree_engine import DualStreamTreeMCTS
 
@@ -262,11 +262,15 @@ def test_overlap_watch_flags_disjoint_and_nested_halves(monkeypatch):
         feed(d, 0.0, 20.0, 0.2, 20.5)                     # healthy: both halves ~20 ms, side by side
     assert d.stream_redraws == 0 and d._serial_seen == 0
     feed(d, 0.0, 15.4, 15.5, 31.0); feed(d, 0.0, 15.4, 15.5, 31.0)      # one after the other
-    assert d.stream_redraws == 1 and drawn == ["priority"] and d._pair_mode == "priority"
+    assert d.stream_redraws == 1 and drawn == ["probe"] and d._pair_mode == "probe"
     d = engine()
     feed(d, 0.0, 15.4, 0.1, 31.0)                          # nested: the second half starved until the first is done
     assert d._serial_seen == 1 and d.stream_redraws == 0
     feed(d, 0.0, 20.0, 0.1, 20.3)                          # a healthy search in between resets the count
     assert d._serial_seen == 0
     feed(d, 0.0, 15.4, 0.1, 31.0); feed(d, 0.0, 15.0, 0.1, 30.0)
-    assert d.stream_redraws == 1 and d._pair_mode == "priority"
+    assert d.stream_redraws == 1 and d._pair_mode == "probe"
+    d = engine()
+    for _ in range(6):
+        feed(d, 0.0, 16.0, 0.3, 21.0)                      # uneven but sharing the chip (ratio 0.76): not a failure
+    assert d.stream_redraws == 0 and d._serial_seen == 0
