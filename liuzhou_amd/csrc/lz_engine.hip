@@ -1186,7 +1186,9 @@ inline unsigned gw2(int64_t n) { return (unsigned)((n + kWavesPerBlock / 2 - 1) 
 // the split step (two waves per game) for launches that leave the SIMDs room for twice the waves; LZ_TREE_SPLIT=0: never
 inline bool split_step(int64_t games) {
     const char* e = getenv("LZ_TREE_SPLIT");                   // read per call: the choice is frozen into a captured graph
-    return !(e && e[0] == '0') && games <= kSplitMaxGames;
+    const char* m = getenv("LZ_TREE_SPLIT_MAX");               // experiment: another upper limit than kSplitMaxGames
+    const int64_t limit = (m && m[0]) ? atoll(m) : kSplitMaxGames;
+    return !(e && e[0] == '0') && games <= limit;
 }
 inline unsigned gt(int64_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
 
