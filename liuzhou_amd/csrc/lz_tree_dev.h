@@ -70,6 +70,7 @@ struct Tree {
     uint8_t* root_terminal; const uint8_t* active;
     int* leaf_edge; int* leaf_parent;      // edge / node the pending leaf hangs from (written by select)
     double c_puct;
+    int fast_select;                 // tree_select: single-precision argmax where it provably equals the double one (LZ_TREE_F32SEL)
     // optional trace of what every expand step consumed (LzTreeDesc.trace_*; nullptr in production)
     int* trace_kind; Packed* trace_leaf; float* trace_heads; float* trace_priors; float* trace_value;
     int trace_cap;
@@ -250,9 +251,6 @@ __device__ __forceinline__ void tree_select(const Tree& t, int g, int lane, cons
         LZ_TCLOCK(g, lv_t0)
         // the node's run: a wave-uniform base (scalar 64-bit arithmetic) + a 32-bit lane offset per load
         const Edge* run = edges + (size_t)__builtin_amdgcn_readfirstlane(e0);
-        const double sq = sqrt((double)(parent_n > 1 ? parent_n : 1));
-        double best = -INFINITY;
-        int best_k = -1;
         Edge mine[2];
         mine[1] = Edge{};
         // up to 2 children per lane, ascending edge index; the second slot only exists for nodes with more than 64
@@ -261,31 +259,79 @@ __device__ __forceinline__ void tree_select(const Tree& t, int g, int lane, cons
         for (int r = 0; r < 2; ++r) {
             if (r == 1 && ne <= kWave) break;
             const int k = r * kWave + lane;
-            if (k < ne) {
-                mine[r] = load_edge(&run[k]);
+            if (k < ne) mine[r] = load_edge(&run[k]);
+        }
 #ifdef LZ_EXP_TREE_STAMPS
-                if (r == 0 && LZ_TSTAMP_ON(g)) { LZ_TCLOCK(g, lv_t1) LZ_TADD(g, 16, lv_t1 - lv_t0) lv_t0 = lv_t1; }   // wait for the run
+        if (LZ_TSTAMP_ON(g)) { LZ_TCLOCK(g, lv_t1) LZ_TADD(g, 16, lv_t1 - lv_t0) lv_t0 = lv_t1; }   // wait for the run
 #endif
-                const int n = edge_n(mine[r].n_info);
-                double q = 0.0;
-                if (n > 0) {
-                    const double mv = mine[r].W / (double)n;
-                    const int child_player = (edge_info(mine[r].n_info) & kInfoWhite) ? -1 : 1;
-                    q = child_player == node_player ? mv : -mv;
-                }
-                const double u = t.c_puct * (double)mine[r].P * sq / (1.0 + (double)n);
-                const double sc = q + u;
-                if (sc > best) { best = sc; best_k = k; }
+        int chosen = -1;
+        // ---- the argmax in single precision, accepted only when it is PROVABLY the double-precision argmax (round 6) ----
+        // The reference scores are doubles, and visit counts must come out bit for bit -- but the argmax of a level needs
+        // the exact arithmetic only when its two best candidates are close.  With |W / n| <= 1 and u >= 0 a score s
+        // satisfies |q| + |u| <= 2 + |s|, so five correctly rounded fp32 operations are off by at most 3e-7 (2 + |s|) <
+        // 1e-6 (1 + |s|) from the double value: a candidate that leads every other one by more than 1e-4 (1 + |s|) in
+        // fp32 (100 x that bound) leads in double too, and is the unique maximum (no tie to break).  Otherwise -- near
+        // ties, exact ties (equal priors on unvisited children), NaN / non-finite scores -- the double path below decides
+        // as before.  The double arithmetic of a level (sqrt, two divisions, a 64-bit wave maximum) was the largest single
+        // item of the step (profiles/r05_pmc_sq_tree.md: 1.76 k of ~2.6 k cycles per level).
+        if (t.fast_select) {
+            const float sqf = sqrtf((float)(parent_n > 1 ? parent_n : 1));
+            const float cf = (float)t.c_puct;
+            float fs[2] = {-INFINITY, -INFINITY};
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                if (r == 1 && ne <= kWave) break;
+                if (r * kWave + lane < ne) {
+                    const int n = edge_n(mine[r].n_info);
+                    float q = 0.f;
+                    if (n > 0) {
+                        const float mv = (float)mine[r].W / (float)n;
+                        const int child_player = (edge_info(mine[r].n_info) & kInfoWhite) ? -1 : 1;
+                        q = child_player == node_player ? mv : -mv;
+                    }
+                    const float s = q + cf * mine[r].P * sqf / (1.0f + (float)n);
+                    fs[r] = s == s ? s : -INFINITY;             // a NaN is never a candidate (and sends the level to the double path
+                }                                               // if nothing else is one)
+            }
+            const float b = fs[1] > fs[0] ? fs[1] : fs[0];
+            const float m1 = lzw::wave_max_nonan(b);
+            const uint64_t w0 = __ballot(fs[0] == m1), w1 = __ballot(fs[1] == m1);
+            if (m1 > -INFINITY && m1 < INFINITY && __popcll(w0) + __popcll(w1) == 1) {
+                const int c = w0 ? __ffsll((unsigned long long)w0) - 1 : kWave + __ffsll((unsigned long long)w1) - 1;
+                const float b2 = (c & 63) == lane ? (c < kWave ? fs[1] : fs[0]) : b;
+                const float m2 = lzw::wave_max_nonan(b2);
+                if (m1 - m2 > 1e-4f * (1.0f + fabsf(m1))) chosen = c;        // m2 = -inf (a single child): +inf
             }
         }
-        const double mx = lzw::wave_max(best);
-        const uint64_t lo = __ballot(best_k >= 0 && best_k < kWave && best == mx);   // lowest index among the maxima
-        int chosen;
-        if (lo) chosen = __ffsll((unsigned long long)lo) - 1;
-        else {
-            const uint64_t hi = __ballot(best_k >= kWave && best == mx);
-            if (!hi) break;                                    // every score NaN (portable: best_child is None)
-            chosen = kWave + __ffsll((unsigned long long)hi) - 1;
+        if (chosen < 0) {
+            const double sq = sqrt((double)(parent_n > 1 ? parent_n : 1));
+            double best = -INFINITY;
+            int best_k = -1;
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                if (r == 1 && ne <= kWave) break;
+                const int k = r * kWave + lane;
+                if (k < ne) {
+                    const int n = edge_n(mine[r].n_info);
+                    double q = 0.0;
+                    if (n > 0) {
+                        const double mv = mine[r].W / (double)n;
+                        const int child_player = (edge_info(mine[r].n_info) & kInfoWhite) ? -1 : 1;
+                        q = child_player == node_player ? mv : -mv;
+                    }
+                    const double u = t.c_puct * (double)mine[r].P * sq / (1.0 + (double)n);
+                    const double sc = q + u;
+                    if (sc > best) { best = sc; best_k = k; }
+                }
+            }
+            const double mx = lzw::wave_max(best);
+            const uint64_t lo = __ballot(best_k >= 0 && best_k < kWave && best == mx);   // lowest index among the maxima
+            if (lo) chosen = __ffsll((unsigned long long)lo) - 1;
+            else {
+                const uint64_t hi = __ballot(best_k >= kWave && best == mx);
+                if (!hi) break;                                    // every score NaN (portable: best_child is None)
+                chosen = kWave + __ffsll((unsigned long long)hi) - 1;
+            }
         }
         chosen = __builtin_amdgcn_readfirstlane(chosen);
         const int src = chosen & 63;
@@ -654,6 +700,7 @@ Tree make_tree(const LzTreeDesc* d) {
     t.root_terminal = d->root_terminal; t.active = d->active;
     t.leaf_edge = d->leaf_edge; t.leaf_parent = d->leaf_parent;
     t.c_puct = d->exploration_weight;
+    { const char* e = getenv("LZ_TREE_F32SEL"); t.fast_select = !(e && e[0] == '0'); }
     const bool tr = d->trace_cap > 0 && d->trace_kind && d->trace_leaf && d->trace_heads && d->trace_priors && d->trace_value;
     t.trace_kind = tr ? d->trace_kind : nullptr;
     t.trace_leaf = tr ? reinterpret_cast<Packed*>(d->trace_leaf) : nullptr;

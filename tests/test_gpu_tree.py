@@ -847,6 +847,51 @@ def test_split_step_on_two_waves_builds_the_same_trees_as_the_one_wave_step(monk
     assert torch.equal(a.engine.buf["n_nodes"], b.engine.buf["n_nodes"]) and torch.equal(a.engine.buf["root_w"], b.engine.buf["root_w"])
 
 
+@pytest.mark.parametrize("flat_priors", [False, True])
+def test_single_precision_argmax_of_the_descent_never_changes_a_tree(monkeypatch, flat_priors):
+    """Round 6: a level's argmax is taken in fp32 when its best candidate leads by more than 100 x the fp32 error bound, in
+    double otherwise (near ties, exact ties, NaN).  LZ_TREE_F32SEL=0 (double everywhere) and the default build the same trees
+    byte for byte over 3 moves with kept subtrees; `flat_priors`: a network whose policy heads are zero -- every prior of a
+    node equal, so unvisited children tie EXACTLY and the double path has to break the ties by index."""
+    _need_gpu()
+    from liuzhou_amd.net import ChessNet, MODEL_CONFIGS
+    from liuzhou_amd.net_hip import FusedNet
+    from liuzhou_amd.tree_engine import PortableTreeMCTS
+    from tests.tree_parity import root_edges, EDGE_LOGICAL, to_gpu_batch
+    from liuzhou_amd import v0_core
+    torch.manual_seed(20260314)
+    m = ChessNet(**MODEL_CONFIGS["b6c64"]).eval()
+    if flat_priors:
+        with torch.no_grad():
+            for conv in (m.policy_head.out_pos1, m.policy_head.out_pos2, m.policy_head.out_mark):
+                conv.weight.zero_()
+    net = FusedNet(m.to(DEV))
+    st_all = states(load("g1_rules.npz"), "s")
+    idx = np.random.default_rng(11).integers(0, st_all["board"].shape[0], 192)
+    engines = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("LZ_TREE_F32SEL", flag)
+        batch = to_gpu_batch({f: np.ascontiguousarray(np.asarray(st_all[f])[idx]) for f in FIELDS}, DEV)
+        e = PortableTreeMCTS(net, 192, 160, DEV, add_dirichlet_noise=True, sample_moves=True, reuse_tree=True, seed=5)
+        temps = torch.ones(192, device=DEV)
+        picks = []
+        for mv in range(3):
+            out = e.search_batch(batch, temperatures=temps)
+            picks.append(out.chosen_action_indices.clone())
+            plies = torch.zeros(192, dtype=torch.int64, device=DEV); done = torch.zeros(192, dtype=torch.bool, device=DEV)
+            v0_core.self_play_step_inplace(*batch.tensors(), plies, done, torch.arange(192, device=DEV),
+                                           out.chosen_action_codes.clone(), out.terminal_mask.clone(),
+                                           out.chosen_valid_mask.clone(), 512, 2.0)
+        engines.append((e, picks, out.policy_dense.clone()))
+    (a, pa, pola), (b, pb, polb) = engines
+    for x, y in zip(pa, pb):
+        assert torch.equal(x, y)
+    assert torch.equal(pola, polb)
+    for x, y in zip(root_edges(a.engine), root_edges(b.engine)):
+        assert all(x[f].tobytes() == y[f].tobytes() for f in EDGE_LOGICAL)
+    assert torch.equal(a.engine.buf["n_nodes"], b.engine.buf["n_nodes"]) and torch.equal(a.engine.buf["root_w"], b.engine.buf["root_w"])
+
+
 def test_graph_capture_failure_falls_back_to_direct_launches(monkeypatch):
     """A failed capture (the reference retries a failed finalize-graph capture with the graph off,
     v1/python/self_play_worker.py:434-442) must not lose the move: same result as the direct path, flag recorded."""
