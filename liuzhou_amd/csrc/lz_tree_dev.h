@@ -265,19 +265,23 @@ __device__ __forceinline__ void tree_select(const Tree& t, int g, int lane, cons
         if (LZ_TSTAMP_ON(g)) { LZ_TCLOCK(g, lv_t1) LZ_TADD(g, 16, lv_t1 - lv_t0) lv_t0 = lv_t1; }   // wait for the run
 #endif
         int chosen = -1;
-        // ---- the argmax in single precision, accepted only when it is PROVABLY the double-precision argmax (round 6) ----
+        // ---- the argmax in single precision, accepted only when it is PROVABLY the double-precision argmax (round 6; opt-in:
+        // same-box A/B on the bench's random-init nets 19.0 - 19.7 -> 19.7 - 20.2 us at 2 048 games, 67.0 -> 68.9 us at 16 384,
+        // profiles/r06_tree_f32sel_ab.jsonl -- their priors are nearly flat, so most levels end in the double path anyway) ----
         // The reference scores are doubles, and visit counts must come out bit for bit -- but the argmax of a level needs
         // the exact arithmetic only when its two best candidates are close.  With |W / n| <= 1 and u >= 0 a score s
         // satisfies |q| + |u| <= 2 + |s|, so five correctly rounded fp32 operations are off by at most 3e-7 (2 + |s|) <
         // 1e-6 (1 + |s|) from the double value: a candidate that leads every other one by more than 1e-4 (1 + |s|) in
         // fp32 (100 x that bound) leads in double too, and is the unique maximum (no tie to break).  Otherwise -- near
         // ties, exact ties (equal priors on unvisited children), NaN / non-finite scores -- the double path below decides
-        // as before.  The double arithmetic of a level (sqrt, two divisions, a 64-bit wave maximum) was the largest single
-        // item of the step (profiles/r05_pmc_sq_tree.md: 1.76 k of ~2.6 k cycles per level).
+        // as before; so does a level on which some |W / n| exceeds 1 (an external evaluator with another value scale: the
+        // bound above assumes values in [-1, 1]).  The double arithmetic of a level (sqrt, two divisions, a 64-bit wave
+        // maximum) was the largest single item of the step (profiles/r05_pmc_sq_tree.md: 1.76 k of ~2.6 k cycles per level).
         if (t.fast_select) {
             const float sqf = sqrtf((float)(parent_n > 1 ? parent_n : 1));
             const float cf = (float)t.c_puct;
             float fs[2] = {-INFINITY, -INFINITY};
+            bool off_scale = false;
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
                 if (r == 1 && ne <= kWave) break;
@@ -288,6 +292,7 @@ __device__ __forceinline__ void tree_select(const Tree& t, int g, int lane, cons
                         const float mv = (float)mine[r].W / (float)n;
                         const int child_player = (edge_info(mine[r].n_info) & kInfoWhite) ? -1 : 1;
                         q = child_player == node_player ? mv : -mv;
+                        off_scale = off_scale || !(fabsf(mv) <= 1.0001f);
                     }
                     const float s = q + cf * mine[r].P * sqf / (1.0f + (float)n);
                     fs[r] = s == s ? s : -INFINITY;             // a NaN is never a candidate (and sends the level to the double path
@@ -296,7 +301,7 @@ __device__ __forceinline__ void tree_select(const Tree& t, int g, int lane, cons
             const float b = fs[1] > fs[0] ? fs[1] : fs[0];
             const float m1 = lzw::wave_max_nonan(b);
             const uint64_t w0 = __ballot(fs[0] == m1), w1 = __ballot(fs[1] == m1);
-            if (m1 > -INFINITY && m1 < INFINITY && __popcll(w0) + __popcll(w1) == 1) {
+            if (m1 > -INFINITY && m1 < INFINITY && __popcll(w0) + __popcll(w1) == 1 && __ballot(off_scale) == 0ull) {
                 const int c = w0 ? __ffsll((unsigned long long)w0) - 1 : kWave + __ffsll((unsigned long long)w1) - 1;
                 const float b2 = (c & 63) == lane ? (c < kWave ? fs[1] : fs[0]) : b;
                 const float m2 = lzw::wave_max_nonan(b2);
@@ -700,7 +705,9 @@ Tree make_tree(const LzTreeDesc* d) {
     t.root_terminal = d->root_terminal; t.active = d->active;
     t.leaf_edge = d->leaf_edge; t.leaf_parent = d->leaf_parent;
     t.c_puct = d->exploration_weight;
-    { const char* e = getenv("LZ_TREE_F32SEL"); t.fast_select = !(e && e[0] == '0'); }
+    // OFF unless LZ_TREE_F32SEL=1: measured slower on the bench's random-init nets (near-flat priors: the two best
+    // candidates of a level are usually within the margin, so the double path runs anyway, after the fp32 one)
+    { const char* e = getenv("LZ_TREE_F32SEL"); t.fast_select = (e && e[0] == '1'); }
     const bool tr = d->trace_cap > 0 && d->trace_kind && d->trace_leaf && d->trace_heads && d->trace_priors && d->trace_value;
     t.trace_kind = tr ? d->trace_kind : nullptr;
     t.trace_leaf = tr ? reinterpret_cast<Packed*>(d->trace_leaf) : nullptr;

@@ -849,8 +849,8 @@ def test_split_step_on_two_waves_builds_the_same_trees_as_the_one_wave_step(monk
 
 @pytest.mark.parametrize("flat_priors", [False, True])
 def test_single_precision_argmax_of_the_descent_never_changes_a_tree(monkeypatch, flat_priors):
-    """Round 6: a level's argmax is taken in fp32 when its best candidate leads by more than 100 x the fp32 error bound, in
-    double otherwise (near ties, exact ties, NaN).  LZ_TREE_F32SEL=0 (double everywhere) and the default build the same trees
+    """Round 6 (opt-in, LZ_TREE_F32SEL=1): a level's argmax is taken in fp32 when its best candidate leads by more than 100 x
+    the fp32 error bound, in double otherwise (near ties, exact ties, NaN).  Double everywhere (the default) and the fp32 form build the same trees
     byte for byte over 3 moves with kept subtrees; `flat_priors`: a network whose policy heads are zero -- every prior of a
     node equal, so unvisited children tie EXACTLY and the double path has to break the ties by index."""
     _need_gpu()
@@ -869,7 +869,7 @@ def test_single_precision_argmax_of_the_descent_never_changes_a_tree(monkeypatch
     st_all = states(load("g1_rules.npz"), "s")
     idx = np.random.default_rng(11).integers(0, st_all["board"].shape[0], 192)
     engines = []
-    for flag in ("1", "0"):
+    for flag in ("1", "0"):                                        # (the fp32 argmax is opt-in: measured slower on random-init nets)
         monkeypatch.setenv("LZ_TREE_F32SEL", flag)
         batch = to_gpu_batch({f: np.ascontiguousarray(np.asarray(st_all[f])[idx]) for f in FIELDS}, DEV)
         e = PortableTreeMCTS(net, 192, 160, DEV, add_dirichlet_noise=True, sample_moves=True, reuse_tree=True, seed=5)
