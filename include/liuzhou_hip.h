@@ -358,7 +358,8 @@ LZ_API int lz_prof_aux_summary(int kind, double* total_ms, int64_t* launches, in
  *   v1/python/portable_mcts.py:264-746 (PortableMCTS.search_batch) == src/mcts.py:280-548 with batch_K=1,
  *   v1/cpp/portable_mcts.cpp:448-979 (PrepareRoots / SelectLeaves / CompletePending / AdvanceRoots).
  * All buffers are caller-allocated device memory.  Per game g:
- *   nodes  [g*node_cap  .. +node_cap)   node_cap >= sims + 2 (+ the kept subtree with lz_tree_advance), <= 65536
+ *   nodes  [g*node_cap  .. +node_cap)   node_cap >= sims + 2 (+ the kept subtree with lz_tree_advance), <= 524288 (lz_tree_advance: four
+ *                                       waves per workgroup up to 65 536 nodes, one above)
  *   path   [g*path_cap  .. +path_cap)   path_cap >= 3; a descent stops at path_cap - 1 levels (a game lasts <= 144
  *                                       plies, so 160 entries hold every reachable path)
  * Per engine: ONE edge pool `edges` of pool_chunks x edge_chunk 32-byte records, handed to the games in chunks

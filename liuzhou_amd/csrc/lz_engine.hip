@@ -22,6 +22,8 @@
 #include <math.h>
 #include <stdint.h>
 
+#include <mutex>
+
 #include "lz_rng.h"
 #include "lz_tree_dev.h"
 
@@ -514,9 +516,12 @@ __global__ __launch_bounds__(kBlock) void tree_expand_wave_kernel(Tree t, WaveAr
 // survives; edges whose child fell past the cut keep their visit count and value sum and point to no node again (the
 // next visit expands that position afresh).  `pruned` counts pruned games, `dropped` the (only defensive) whole-subtree
 // drops.  Dynamic LDS: per wave ceil(node_cap / 64) mark words + as many prefix counts + 3 x 64 ints of batch offsets.
-constexpr int kMarkWordsMax = 1024;        // subtree reuse supports node_cap <= 65536
+constexpr int kMarkWordsMax = 1024;        // four waves per workgroup: node_cap <= 65 536 (48 KB of marks + prefix counts)
+constexpr int kMarkWordsBig = 8192;        // ONE wave per workgroup (round 6): node_cap <= 524 288 (96 KB) -- the arenas of a
+                                           // long single-game search (MCTSCore with tens of thousands of simulations)
 
-__global__ __launch_bounds__(kBlock) void tree_advance_kernel(Tree t, const int* __restrict__ played_action,
+template <int WPB>
+__global__ __launch_bounds__(WPB * kWave) void tree_advance_kernel(Tree t, const int* __restrict__ played_action,
                                                               const uint8_t* __restrict__ reset, int reserve_nodes,
                                                               int mark_words, int* __restrict__ dropped,
                                                               int* __restrict__ pruned, long long* __restrict__ ticks) {
@@ -525,12 +530,12 @@ __global__ __launch_bounds__(kBlock) void tree_advance_kernel(Tree t, const int*
     extern __shared__ uint64_t s_adv[];
     const int lane = lane_id();
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int g = wave_game();
+    const int g = blockIdx.x * WPB + wv;
     if (g >= t.B) return;
     Node* nodes = t.nodes + (size_t)g * t.node_cap;
     Edge* edges = t.edges;                                      // pool indices
     uint64_t* mark = s_adv + (size_t)wv * mark_words;
-    int* nprefix = reinterpret_cast<int*>(s_adv + (size_t)kWavesPerBlock * mark_words) + (size_t)wv * mark_words;
+    int* nprefix = reinterpret_cast<int*>(s_adv + (size_t)WPB * mark_words) + (size_t)wv * mark_words;
     const uint64_t lt = (1ull << lane) - 1ull;
     auto rank_of = [&](int id) { return nprefix[id >> 6] + __popcll(mark[id >> 6] & ((1ull << (id & 63)) - 1ull)); };
 
@@ -705,7 +710,7 @@ __global__ __launch_bounds__(kBlock) void tree_advance_kernel(Tree t, const int*
     // Safe in place: a run's new place ends no later than its old place does, and old places ascend with the node, so
     // nothing a round stores lies in what a later round loads ----
     constexpr int kFlat = 12;
-    int* bat = reinterpret_cast<int*>(s_adv + (size_t)kWavesPerBlock * mark_words) + (size_t)kWavesPerBlock * mark_words +
+    int* bat = reinterpret_cast<int*>(s_adv + (size_t)WPB * mark_words) + (size_t)WPB * mark_words +
                (size_t)wv * (3 * kWave);
     int* bP = bat; int* bOb = bat + kWave; int* bNb = bat + 2 * kWave;
     for (int base = 0; base < kept_nodes; base += kWave) {
@@ -1277,16 +1282,38 @@ int lz_tree_advance(const LzTreeDesc* d, const int32_t* played_action, const uin
     if (!tree_ok(d) || next_sims < 0) return LZ_ERR_ARG;
     if (d->num_games == 0) return LZ_OK;
     const int words = (d->node_cap + kWave - 1) / kWave;
-    if (words > kMarkWordsMax) return LZ_ERR_UNSUPPORTED;             // LDS mark words: <= 65536 nodes per game
+    if (words > kMarkWordsBig) return LZ_ERR_UNSUPPORTED;             // LDS mark words: <= 524 288 nodes per game
     const int64_t rn = next_sims + 1;
     if (rn > d->node_cap) return LZ_ERR_ARG;
     // a game's chunk list must be able to hold the worst case of its node arena (72 children everywhere), so that the
     // node budget is the only thing that can cut a kept subtree
     if ((int64_t)d->chunk_cap * (d->edge_chunk - (kMaxChildren - 1)) < (int64_t)d->node_cap * kMaxChildren) return LZ_ERR_ARG;
-    const size_t lds = (size_t)kWavesPerBlock * (words * (sizeof(uint64_t) + sizeof(int)) + 3 * kWave * sizeof(int));
+    const bool big = words > kMarkWordsMax;                           // arenas beyond 65 536 nodes: one wave per workgroup
+    const int wpb = big ? 1 : kWavesPerBlock;
+    const size_t lds = (size_t)wpb * (words * (sizeof(uint64_t) + sizeof(int)) + 3 * kWave * sizeof(int));
+    if (big) {
+        static std::mutex mu;
+        static bool configured[64] = {};
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return LZ_ERR_LAUNCH;
+        std::lock_guard<std::mutex> lk(mu);
+        if (!configured[dev]) {
+            const size_t most = (size_t)kMarkWordsBig * (sizeof(uint64_t) + sizeof(int)) + 3 * kWave * sizeof(int);
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(tree_advance_kernel<1>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)most) != hipSuccess) {
+                (void)hipGetLastError();
+                return LZ_ERR_LAUNCH;
+            }
+            configured[dev] = true;
+        }
+    }
     (void)lz_prof_aux_begin(1, stream);
-    hipLaunchKernelGGL(tree_advance_kernel, dim3(gw(d->num_games)), dim3(kBlock), lds, as_stream(stream), make_tree(d),
-                       played_action, reset, (int)rn, words, dropped, pruned, g_advance_ticks);
+    if (big)
+        hipLaunchKernelGGL(tree_advance_kernel<1>, dim3((unsigned)d->num_games), dim3(kWave), lds, as_stream(stream), make_tree(d),
+                           played_action, reset, (int)rn, words, dropped, pruned, g_advance_ticks);
+    else
+        hipLaunchKernelGGL(tree_advance_kernel<kWavesPerBlock>, dim3(gw(d->num_games)), dim3(kBlock), lds, as_stream(stream),
+                           make_tree(d), played_action, reset, (int)rn, words, dropped, pruned, g_advance_ticks);
     (void)lz_prof_aux_end(1, stream, d->num_games);
     return st();
 }

@@ -430,7 +430,7 @@ class MCTSCore:
         self._callback, self._fused = self._value_callback(lambda x, _b=batcher: _b.forward(x, int(x.shape[0]))), None
 
     # ---- tree ----
-    NODE_LIMIT = 65536          # tree_advance_kernel marks a game's nodes in LDS: 1024 words of 64 (csrc/lz_engine.hip)
+    NODE_LIMIT = 524288         # tree_advance_kernel marks a game's nodes in LDS: 8 192 words of 64 (csrc/lz_engine.hip; 65 536 until round 5)
 
     def _capacity(self) -> int:
         return max(1024, 4 * int(self.cfg.num_simulations))
@@ -440,7 +440,7 @@ class MCTSCore:
         self._root_like = state
         cap = self._capacity()
         if cap + 2 > self.NODE_LIMIT:
-            # the reference's tree is unbounded; ours is an arena of at most 65 536 nodes per game
+            # the reference's tree is unbounded; ours is an arena of at most 524 288 nodes per game
             raise ValueError(f"MCTSCore: num_simulations={self.cfg.num_simulations} needs an arena of {cap} nodes, above the "
                              f"{self.NODE_LIMIT}-node limit of a device tree (use num_simulations <= {(self.NODE_LIMIT - 2) // 4})")
         if self._engine is None or self._engine.max_sims < cap:

@@ -13,6 +13,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 import time
 from typing import Dict, List, Optional, Tuple
 
@@ -63,7 +64,9 @@ EDGE_CHUNK = 1024              # edges per chunk of the engine's edge pool (32 K
 # movement phase with 10-20 legal moves, and a kept subtree rarely exceeds the new search -- so 96 is 6 x head-room
 POOL_EDGES_PER_NODE = 32
 POOL_NODES_PER_SIM = 3
-MAX_NODE_CAP = 65536           # lz_tree_advance marks a game's nodes in LDS: 1024 words of 64
+MAX_NODE_CAP = 524288          # lz_tree_advance marks a game's nodes in LDS: 8 192 words of 64 with one wave per workgroup
+                               # (round 6; four waves per workgroup up to 65 536 nodes, the limit until round 5)
+AUTO_NODE_CAP = 65536          # arenas sized automatically (auto_reuse_factor) stay within the four-wave form
 PATH_CAP = 192                 # a game lasts <= 144 plies (game_state.py:87-89), so no descent is deeper than that
 REUSE_FACTOR_CAP = 40.0
 
@@ -78,7 +81,7 @@ def auto_reuse_factor(num_games: int, sims: int, device, memory_fraction: float 
     free, _total = torch.cuda.mem_get_info(torch.device(device))
     per_game = free * float(memory_fraction) / max(1, int(num_games))
     f = (per_game / 48.0 - (sims + 2)) / max(1, sims)
-    f = min(float(cap), f, (MAX_NODE_CAP - sims - 2) / max(1, sims))
+    f = min(float(cap), f, (AUTO_NODE_CAP - sims - 2) / max(1, sims))
     return max(1.0, float(int(f * 4) / 4.0))
 
 
@@ -888,6 +891,14 @@ class DualStreamTreeMCTS:
         self._searches = 0
         self._serial_seen = 0
         self.stream_redraws = 0
+        # Round 6: a THIRD way of not sharing the chip showed up (a (-1, 0) priority pair in bench.py's C2 runner leg, every
+        # time): both halves start together, take the same time -- and that time is what ONE half after the other takes
+        # (31 ms instead of 20.5: their kernels alternate instead of running side by side).  Neither "union ~ sum" nor
+        # "one nested in the other" sees that; only a reference does: one search of every run is launched with both halves
+        # on ONE stream on purpose (`_t_serial` = what no overlap costs), and a search whose union exceeds 0.85 of it has
+        # not overlapped, whatever its intervals look like (healthy: 0.66).
+        self._t_serial: Optional[float] = None
+        self.overlap_ratio: Optional[float] = None          # union / _t_serial of the last watched search (statistics)
 
     @property
     def leaf_evals(self) -> int:
@@ -919,16 +930,20 @@ class DualStreamTreeMCTS:
         for p in self.parts:
             p.reset_run(seed)
         self._watch, self._watch_left, self._searches, self._serial_seen = [], 6, 0, 0
+        self._t_serial = None                                # re-calibrated per run (the launch form may differ)
 
     def _check_overlap(self) -> None:
         """Look at finished overlap brackets (never waits) and re-draw the streams if the halves ran one after the other."""
         self._searches += 1
         if self._watch_left <= 0 and self._searches % 64 == 0:
             self._watch_left = 2
-        while self._watch and all(e.query() for e in self._watch[0]):
-            s0, e0, s1, e1 = self._watch.pop(0)
-            self._watch_left -= 1
+        while self._watch and all(e.query() for e in self._watch[0][:4]):
+            s0, e0, s1, e1, calib = self._watch.pop(0)
             d0, d1 = s0.elapsed_time(e0), s1.elapsed_time(e1)
+            if calib:                                            # the deliberately serialised search: the reference
+                self._t_serial = d0 + d1
+                continue
+            self._watch_left -= 1
             lead = s0.elapsed_time(s1)                           # start of part 1 relative to part 0 (ms, may be < 0)
             union = max(d0, lead + d1) - min(0.0, lead)
             # Two signatures of halves that do not share the chip: (a) one after the other on one hardware queue -- disjoint
@@ -937,6 +952,13 @@ class DualStreamTreeMCTS:
             # runner leg at 31.9 ms per ply, which test (a) alone did not flag).  Halves that overlap properly take about the
             # same time: they are equal work on equal shares of the chip.
             serial = union > 0.9 * (d0 + d1) or min(d0, d1) < 0.62 * max(d0, d1)
+            if self._t_serial is not None and self._t_serial > 2.0:
+                # (c) whatever the intervals look like: the search took what the two halves take one after the other
+                self.overlap_ratio = union / self._t_serial
+                serial = serial or union > 0.85 * self._t_serial
+            if os.environ.get("LZ_WATCH_DEBUG", "0") == "1":
+                print(f"[lz watch] search {self._searches}: d0 {d0:.2f} ms, d1 {d1:.2f} ms, lead {lead:.2f} ms, union {union:.2f}, "
+                      f"serial reference {self._t_serial} -> {'serial' if serial else 'ok'}", file=sys.stderr, flush=True)
             if d0 > 1.0 and d1 > 1.0 and serial:
                 self._serial_seen += 1
                 self._watch_left = max(self._watch_left, 2)
@@ -979,10 +1001,14 @@ class DualStreamTreeMCTS:
         cut = lambda t, a, b: None if t is None else t[a:b]
         outs = []
         self._check_overlap()
-        streams = (main,) * len(self.parts) if self.serialize else self.streams
+        # the reference search of a run: the 4th (the graphs of both launch keys exist by then), both halves on the caller's
+        # stream; retried at the next search if a part still captured something in it
+        calib = (not self.serialize and len(self.parts) == 2 and self._t_serial is None and self._searches >= 4 and
+                 not any(len(w) > 4 and w[4] for w in self._watch))
+        streams = (main,) * len(self.parts) if (self.serialize or calib) else self.streams
         subs = [state._map(lambda t, a=a, b=b: t[a:b]) for a, b in self.bounds]
         watch = None
-        if not self.serialize and len(self.parts) == 2 and self._watch_left > 0:
+        if not self.serialize and len(self.parts) == 2 and (self._watch_left > 0 or calib):
             watch = [torch.cuda.Event(enable_timing=True) for _ in range(4)]           # start / end of the two searches
         captures = sum(getattr(p, "captures", 0) for p in self.parts)
         for i, ((a, b), part, st, sub) in enumerate(zip(self.bounds, self.parts, streams, subs)):     # launch every part first ...
@@ -999,7 +1025,7 @@ class DualStreamTreeMCTS:
         # before part 1 starts: its bracket says "serial" whatever the streams do -- with subtree reuse the first two
         # searches of every run capture (fresh key, continued key) and drew a spurious new pair at the third
         if watch is not None and sum(getattr(p, "captures", 0) for p in self.parts) == captures:
-            self._watch.append(watch)
+            self._watch.append(watch + [calib])
         todo = list(zip(self.parts, streams))                  # leftover rounds (batch_k > 1): the parts take turns,
         while todo:                                            # so that their small rounds overlap on the device
             nxt = []
@@ -1302,6 +1328,10 @@ def self_play_tree_gpu(model, num_games: int, mcts_simulations: int, temperature
                        "engine_cache_hit": int(cache_hit), "setup_ms": int(setup_sec * 1e3), "build_ms": int(build_sec * 1e3),
                        "reuse_pruned": pruned, "reuse_dropped": dropped, "edge_pool_refused": refused,
                        "final_sync_ms": int(sync_ms), "stream_redraws": int(getattr(mcts, "stream_redraws", 0)),
+                       # two-stream search: last watched search / the run's one-stream reference search, in percent
+                       # (~66: the halves share the chip; ~100: they do not)
+                       **({"stream_overlap_pct": int(round(100.0 * mcts.overlap_ratio))}
+                          if getattr(mcts, "overlap_ratio", None) is not None else {}),
                        **({"loop_ms": int(tail.loop_ms), "host_wait_ms": int(tail.host_wait_ms),
                            "plies_launched": int(tail.plies_launched)} if tail is not None else {})},
         piece_delta_buckets={str(d - 18): int(v) for d, v in enumerate(hist)}, device=str(dev))

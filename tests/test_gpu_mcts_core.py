@@ -220,13 +220,45 @@ def test_mcts_core_root_noise_is_fresh_for_every_root():
         priors.append([s["prior"] for s in core.get_root_children_stats()])
     assert len(priors[0]) > 1
     assert priors[0] != priors[1] and priors[1] != priors[2] and priors[0] != priors[2]
-    # a large simulation budget is refused with a clear message instead of an arena error deep inside the engine
+    # a simulation budget beyond the arena limit (524 288 nodes since round 6; 65 536 before) is refused with a clear message
+    # instead of an arena error deep inside the engine
     big = v0_core.MCTSConfig()
-    big.device, big.num_simulations = DEV, 20000
+    big.device, big.num_simulations = DEV, 200000
     core2 = v0_core.MCTSCore(big)
     core2.set_forward_callback(forward)
-    with pytest.raises(ValueError, match="65536"):
+    with pytest.raises(ValueError, match="524288"):
         core2.set_root_state(_state_like(st, 10))
+
+
+def test_mcts_core_searches_17000_simulations_and_keeps_the_subtree_in_a_quarter_million_node_arena():
+    """Round 6: arenas beyond 65 536 nodes per game (the reference's tree is unbounded, v1/cpp/portable_mcts.cpp:739-769; until
+    round 5 `MCTSCore` refused num_simulations > 16 383).  17 000 simulations of one game need an arena of 272 002 nodes;
+    `advance_root` compacts it with the one-wave-per-workgroup form of lz_tree_advance (96 KB of LDS marks) and the next search
+    continues the kept subtree: visit counts add up exactly."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from liuzhou_amd import v0_core
+    from liuzhou_amd.net import ChessNet, MODEL_CONFIGS
+    torch.manual_seed(3)
+    model = ChessNet(**MODEL_CONFIGS["b6c64"]).eval()
+    cfg = v0_core.MCTSConfig()
+    cfg.device, cfg.num_simulations, cfg.add_dirichlet_noise, cfg.seed = DEV, 17000, False, 1
+    core = v0_core.MCTSCore(cfg)
+    core.set_inference_engine(v0_core.InferenceEngine(model, DEV, "float16", 64))
+    st = states(load("g1_rules.npz"), "s")
+    core.set_root_state(_state_like(st, 10))
+    assert core._engine.node_cap == 4 * 68000 + 2 > 65536
+    core.run_simulations(17000)
+    stats = core.get_root_children_stats()
+    assert core.root_visit_count == 17000 and sum(s["visit_count"] for s in stats) == 17000
+    best = max(stats, key=lambda s: (s["visit_count"], -s["action_index"]))
+    assert best["visit_count"] > 1000
+    core.advance_root(best["action_index"])
+    ts = core.get_tree_stats()
+    assert ts["reuse_dropped"] == 0 and ts["reuse_pruned"] == 0
+    core.run_simulations(50)
+    kept = best["visit_count"] - 1                          # the child's visits minus its own expansion = visits of ITS children
+    assert sum(s["visit_count"] for s in core.get_root_children_stats()) == kept + 50
 
 
 def test_torchscript_runner_and_eval_batcher_on_the_device(tmp_path):

@@ -447,8 +447,8 @@ def test_tree_engine_degenerate_sizes():
     d.nodes = None
     assert L.lib().lz_tree_begin(C.byref(d), None) == -1
     d.nodes = eng.desc.nodes
-    d.node_cap = 70000
-    assert L.lib().lz_tree_advance(C.byref(d), None, None, L.i64(4), None, None, None) == -2      # > 65536 nodes: unsupported
+    d.node_cap = 600000
+    assert L.lib().lz_tree_advance(C.byref(d), None, None, L.i64(4), None, None, None) == -2      # > 524288 nodes: unsupported
     d.node_cap = eng.desc.node_cap
     d.edge_chunk = 100                                           # not a power of two
     assert L.lib().lz_tree_begin(C.byref(d), None) == -1

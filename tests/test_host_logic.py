@@ -250,11 +250,12 @@ def test_overlap_watch_flags_disjoint_and_nested_halves(monkeypatch):
     def engine():
         d = DualStreamTreeMCTS.__new__(DualStreamTreeMCTS)
         d._watch, d._watch_left, d._searches, d._serial_seen, d.stream_redraws = [], 6, 0, 0, 0
+        d._t_serial, d.overlap_ratio = None, None
         d.parts, d.device, d.streams, d._pair_mode = [None, None], "cuda:0", ("a", "b"), "probe"
         return d
 
-    def feed(d, s0, e0, s1, e1):
-        d._watch.append([Ev(s0), Ev(e0), Ev(s1), Ev(e1)])
+    def feed(d, s0, e0, s1, e1, calib=False):
+        d._watch.append([Ev(s0), Ev(e0), Ev(s1), Ev(e1), calib])
         d._check_overlap()
 
     d = engine()
@@ -274,3 +275,16 @@ def test_overlap_watch_flags_disjoint_and_nested_halves(monkeypatch):
     for _ in range(6):
         feed(d, 0.0, 16.0, 0.3, 21.0)                      # uneven but sharing the chip (ratio 0.76): not a failure
     assert d.stream_redraws == 0 and d._serial_seen == 0
+    # (c) the third signature (round 6, a (-1, 0) priority pair in bench.py's runner leg): both halves side by side in TIME,
+    # equally long -- but as long as one half after the other.  Only the reference search of the run (both halves on one
+    # stream on purpose) tells: union > 0.85 of it = no overlap.
+    d = engine()
+    feed(d, 0.0, 31.2, 0.0, 31.0)
+    assert d._serial_seen == 0                                 # without a reference this looks healthy
+    feed(d, 0.0, 15.4, 15.5, 31.0, calib=True)                 # the reference: 15.4 + 15.5 ms one after the other
+    assert abs(d._t_serial - 30.9) < 1e-6 and d._serial_seen == 0 and d.stream_redraws == 0
+    feed(d, 0.0, 20.5, 0.0, 20.4)
+    assert d._serial_seen == 0 and abs(d.overlap_ratio - 20.5 / 30.9) < 1e-6
+    feed(d, 0.0, 31.2, 0.0, 31.0); feed(d, 0.0, 31.0, 0.0, 31.3)
+    assert d.stream_redraws == 1 and drawn[-1] == "probe"
+
