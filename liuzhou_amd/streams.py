@@ -61,12 +61,11 @@ def stream_pair_mode() -> str:
     """LZ_STREAM_PAIR: "probe" (default) = an equal-priority pair, probed when drawn; "priority" (round 6) = the k streams
     get DISTINCT priorities (-1, 0[, 1]), which the runtime serves from distinct hardware-queue pools -- the mapping is then
     a property of how the streams were created, not of what else the process has alive.  Same-box A/B inside bench.py at C2
-    (profiles/r06_experiments.md section 2): 196.4 / 196.6 k positions/s against 196.8 / 196.3 k for the probed pair, 0
-    re-draws either way; 8 isolated runner runs of either kind at 20.4 - 20.5 ms per ply.  But ONE default bench invocation
-    with the priority pair ran its whole C2 runner leg at 31.9 ms per ply (the serialised figure) without the overlap watch
-    noticing: distinct queues do not stop one chain from starving the other, and a starved half NESTS in the other's
-    interval instead of following it.  So the symmetric pair stays the default, the watch (DualStreamTreeMCTS) now flags
-    nested halves too, and a pair that fails is replaced by a freshly probed equal-priority pair."""
+    (profiles/r06_experiments.md section 2): 196.4 / 196.6 k positions/s against 196.8 / 196.3 k for the probed pair.  But
+    inside bench.py's default sequence the priority pair ran the whole C2 runner leg at 31 ms per ply instead of 20.5, every
+    time: both halves side by side in time and no faster than one after the other.  Distinct queues are not a guarantee;
+    the symmetric pair stays the default, and DualStreamTreeMCTS judges every run against a reference search with both
+    halves on one stream and replaces a pair that does not share the chip by a freshly probed equal-priority one."""
     return os.environ.get("LZ_STREAM_PAIR", "probe").strip().lower()
 
 
