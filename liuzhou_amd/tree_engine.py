@@ -1011,6 +1011,7 @@ class DualStreamTreeMCTS:
         if not self.serialize and len(self.parts) == 2 and (self._watch_left > 0 or calib):
             watch = [torch.cuda.Event(enable_timing=True) for _ in range(4)]           # start / end of the two searches
         captures = sum(getattr(p, "captures", 0) for p in self.parts)
+        t_host = time.perf_counter()
         for i, ((a, b), part, st, sub) in enumerate(zip(self.bounds, self.parts, streams, subs)):     # launch every part first ...
             st.wait_stream(main)
             with torch.cuda.stream(st):
@@ -1024,7 +1025,11 @@ class DualStreamTreeMCTS:
         # A search in which a part captured its graph (warm-up, host synchronisation, capture) finishes part 0 on the host
         # before part 1 starts: its bracket says "serial" whatever the streams do -- with subtree reuse the first two
         # searches of every run capture (fresh key, continued key) and drew a spurious new pair at the third
-        if watch is not None and sum(getattr(p, "captures", 0) for p in self.parts) == captures:
+        # ... and so does a search whose two launches the HOST spread out (another thread of the process held the runtime: the
+        # streaming worker's copier pins staging memory, ~80 ms per GB): part 1 then starts late for a reason no other pair of
+        # streams would cure.  Two graph replays take a few hundred microseconds to launch.
+        host_ms = (time.perf_counter() - t_host) * 1e3
+        if watch is not None and sum(getattr(p, "captures", 0) for p in self.parts) == captures and (host_ms < 6.0 or calib):
             self._watch.append(watch + [calib])
         todo = list(zip(self.parts, streams))                  # leftover rounds (batch_k > 1): the parts take turns,
         while todo:                                            # so that their small rounds overlap on the device
